@@ -1,0 +1,128 @@
+/* polydeal_hip.h — C ABI of the MI355X (gfx950) SIP assembly path.
+ *
+ * This is the drop-in boundary for ONE hot path of polyDEAL: the DG/SIP system-matrix assembly
+ * over agglomerated polytopal elements, i.e. what
+ *
+ *   PolyUtils::assemble_dg_matrix(MatrixType&, const FiniteElement<dim>&, const AgglomerationHandler<dim>&)
+ *       reference include/poly_utils.h:2000-2195
+ *   and the hand-written loops of examples/poisson.cc:694-988, examples/minimal_SIP.cc:143-365,
+ *   examples/diffusion_reaction.cc:420-696
+ *
+ * do on the CPU through AgglomerationHandler::reinit / reinit_interface
+ * (reference source/agglomeration_handler.cc:729-906, 1103-1243), MappingBox
+ * (source/mapping_box.cc:393-531) and FE_DGQ / FE_AggloDGP (source/fe_agglodgp.cc:27-55).
+ *
+ * The reference has no FFI layer (it is a set of C++ templates over deal.II types); the entry
+ * points below are what a deal.II-side adapter binds (INTEGRATION.md shows it).  Plain pointers and
+ * sizes only, no exceptions cross the boundary: every function returns 0 on success or a negative
+ * PDH_E* code, and pdh_last_error() gives the message.  One pdh_ctx per device and per host thread
+ * (not re-entrant, like the reference's handler: include/agglomeration_handler.h:834-851).
+ *
+ * All arithmetic is fp64.  Indices are 32-bit except CSR row pointers / point offsets (64-bit).
+ */
+#ifndef POLYDEAL_HIP_H
+#define POLYDEAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDH_BASIS_DGQ 0      /* FE_DGQ<dim>(p): tensor Lagrange on Gauss-Lobatto nodes, (p+1)^dim dofs   */
+#define PDH_BASIS_AGGLODGP 1 /* FE_AggloDGP<dim>(p): Legendre P_p, C(p+dim,dim) dofs (fe_agglodgp.cc:27) */
+
+#define PDH_OK 0
+#define PDH_EINVAL -1     /* malformed problem description                */
+#define PDH_EUNSUPPORTED -2 /* valid but outside what the kernels implement */
+#define PDH_EDEVICE -3    /* HIP runtime error (no GPU, OOM, launch failure) */
+#define PDH_ESTATE -4     /* call order (e.g. assemble before set_problem)  */
+
+typedef struct pdh_ctx pdh_ctx; /* opaque; owns all device memory */
+
+/* Flattened description of one agglomerated mesh + SIP variant.  All pointers are caller-owned host
+ * memory, read-only, and need to stay valid only for the duration of the call they are passed to.
+ * Letters in brackets refer to SURVEY.md section 8(a).                                            */
+typedef struct pdh_problem
+{
+  int32_t dim;     /* 2 or 3                                                                       */
+  int32_t degree;  /* polynomial degree p                                                          */
+  int32_t basis;   /* PDH_BASIS_*                                                                  */
+  int32_t n_agg;   /* number of polytopes (agglomerates)                                           */
+  int32_t n_faces; /* polytopal faces; each interior face stored ONCE (in/out), boundary: out = -1 */
+  int32_t n_rows;  /* global number of dofs = n_dofs_per_cell * n_agg                              */
+  int32_t diag_first; /* 1: deal.II SparsityPattern row layout (diagonal first, then ascending);
+                         0: plain ascending columns (Epetra local CSR)                       [A4] */
+  int32_t reserved;
+  double reaction_c; /* adds c * phi_i phi_j to the volume term (diffusion_reaction.cc:495-501)    */
+
+  const double  *bbox;       /* [n_agg][2][dim] lower, upper corner of the bounding box      [A1] */
+  const int32_t *dof_offset; /* [n_agg] first global dof of each polytope                    [A2] */
+
+  const int64_t *vq_ptr; /* [n_agg+1] CSR offsets into the volume quadrature arrays           [A5] */
+  const double  *vq_x;   /* [dim][Nq_tot] REAL quadrature points (structure of arrays)             */
+  const double  *vq_w;   /* [Nq_tot] JxW of the sub-cell rules (agglomeration_handler.cc:639-653)  */
+
+  const int32_t *face_in;  /* [n_faces] polytope on side 0                                    [A3] */
+  const int32_t *face_out; /* [n_faces] polytope on side 1, or -1 on the domain boundary           */
+  const int64_t *fq_ptr;   /* [n_faces+1] CSR offsets into the face quadrature arrays         [A8] */
+  const double  *fq_x;     /* [dim][Nqf_tot] REAL points                                           */
+  const double  *fq_n;     /* [dim][Nqf_tot] outward unit normal of side 0 (poly_utils.h:1881)     */
+  const double  *fq_w;     /* [Nqf_tot] JxW seen from side 0                                       */
+  const double  *fq_w_out; /* [Nqf_tot] JxW seen from side 1, or NULL if identical     */
+  const double  *face_sigma; /* [n_faces] penalty sigma = C / h_f, resolved per caller variant     */
+
+  const int64_t *rowptr; /* [n_rows+1] target CSR row pointers                                [A4] */
+  const int32_t *colind; /* [nnz] target CSR columns, or NULL: canonical DG block pattern assumed  */
+} pdh_problem;
+
+/* Lifetime -------------------------------------------------------------------------------------- */
+int pdh_create(pdh_ctx **out, int device_id);
+void pdh_destroy(pdh_ctx *ctx);
+const char *pdh_last_error(const pdh_ctx *ctx); /* valid until the next call on ctx; ctx may be NULL */
+
+/* Setup: validates the description, derives the per-polytope block positions inside the CSR rows and
+ * uploads the repacked tables to HBM.  Plays the role of the caches AgglomerationHandler builds in
+ * distribute_agglomerated_dofs / initialize_fe_values (agglomeration_handler.cc:210-236, 326-379).
+ * [row_begin,row_end) selects the dof rows this context owns (multi-GPU: one contiguous range per
+ * rank, whole polytopes only, like the reference asserts at agglomeration_handler.cc:83-87).     */
+int pdh_set_problem(pdh_ctx *ctx, const pdh_problem *problem);
+int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *problem, int32_t row_begin, int32_t row_end);
+
+/* The hot path.  Replaces the body of assemble_dg_matrix (poly_utils.h:2034-2193): volume term,
+ * boundary (Nitsche) term and the four interface blocks, written straight into CSR value order.
+ *   pdh_assemble_device : values stay in HBM (pointer from pdh_device_values); asynchronous on the
+ *                         context's stream; nothing crosses PCIe.
+ *   pdh_assemble        : same + copy of the owned rows' values into `values`
+ *                         (length rowptr[row_end]-rowptr[row_begin]); overwrites, does not add.
+ *   pdh_assemble_sip    : set_problem + assemble in one call (all rows).                           */
+int pdh_assemble_device(pdh_ctx *ctx);
+int pdh_assemble(pdh_ctx *ctx, double *values);
+int pdh_assemble_sip(pdh_ctx *ctx, const pdh_problem *problem, double *values);
+int pdh_assemble_sip_local(pdh_ctx *ctx, const pdh_problem *problem, int32_t row_begin, int32_t row_end,
+                           double *values);
+
+/* Access to device-resident results and synchronisation. */
+int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values);
+int pdh_synchronize(pdh_ctx *ctx);
+void *pdh_stream(pdh_ctx *ctx); /* hipStream_t the kernels are launched on */
+
+/* Measurement helpers (HIP events on the context's stream).  kernel 0 = diagonal-block kernel
+ * (volume + own-side face terms), kernel 1 = off-diagonal (interface coupling) kernel.            */
+#define PDH_N_KERNELS 2
+int pdh_set_profiling(pdh_ctx *ctx, int enabled);
+int pdh_kernel_times_ms(pdh_ctx *ctx, float *ms /* [PDH_N_KERNELS], last launch */);
+int pdh_problem_stats(pdh_ctx *ctx, int64_t *stats /* [8]: n_owned_agg, n_offdiag_items, n_vq_points,
+                        n_face_side_points, n_values, dofs_per_cell, lds_bytes_diag, lds_bytes_offdiag */);
+
+/* Host-only validation of a problem description: runs every check of pdh_set_problem_local without
+ * touching a GPU (usable on a build machine).  stats as in pdh_problem_stats, may be NULL.          */
+int pdh_check_problem(const pdh_problem *problem, int32_t row_begin, int32_t row_end, int64_t *stats);
+
+/* Version / build info: "polydeal_hip <version> gfx950". */
+const char *pdh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYDEAL_HIP_H */

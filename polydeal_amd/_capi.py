@@ -1,0 +1,187 @@
+"""ctypes binding of the C ABI in include/polydeal_hip.h (libpolydeal_hip.so, built in-tree).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is present every compute
+entry point raises.  Nothing here imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpolydeal_hip.so")
+
+PDH_BASIS_DGQ = 0
+PDH_BASIS_AGGLODGP = 1
+PDH_OK = 0
+PDH_EINVAL, PDH_EUNSUPPORTED, PDH_EDEVICE, PDH_ESTATE = -1, -2, -3, -4
+
+
+class PdhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pdh error %d: %s" % (code, msg))
+        self.code = code
+
+
+class pdh_problem(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("degree", C.c_int32), ("basis", C.c_int32), ("n_agg", C.c_int32),
+        ("n_faces", C.c_int32), ("n_rows", C.c_int32), ("diag_first", C.c_int32), ("reserved", C.c_int32),
+        ("reaction_c", C.c_double),
+        ("bbox", C.c_void_p), ("dof_offset", C.c_void_p),
+        ("vq_ptr", C.c_void_p), ("vq_x", C.c_void_p), ("vq_w", C.c_void_p),
+        ("face_in", C.c_void_p), ("face_out", C.c_void_p), ("fq_ptr", C.c_void_p),
+        ("fq_x", C.c_void_p), ("fq_n", C.c_void_p), ("fq_w", C.c_void_p), ("fq_w_out", C.c_void_p),
+        ("face_sigma", C.c_void_p),
+        ("rowptr", C.c_void_p), ("colind", C.c_void_p),
+    ]
+
+
+EXPORTS = [
+    "pdh_create", "pdh_destroy", "pdh_last_error", "pdh_set_problem", "pdh_set_problem_local",
+    "pdh_assemble_device", "pdh_assemble", "pdh_assemble_sip", "pdh_assemble_sip_local",
+    "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
+    "pdh_problem_stats", "pdh_check_problem", "pdh_version",
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads libpolydeal_hip.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "polydeal_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C polydeal_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.pdh_create.argtypes = [P(C.c_void_p), C.c_int]
+    lib.pdh_destroy.argtypes = [C.c_void_p]
+    lib.pdh_destroy.restype = None
+    lib.pdh_last_error.argtypes = [C.c_void_p]
+    lib.pdh_last_error.restype = C.c_char_p
+    lib.pdh_set_problem.argtypes = [C.c_void_p, P(pdh_problem)]
+    lib.pdh_set_problem_local.argtypes = [C.c_void_p, P(pdh_problem), C.c_int32, C.c_int32]
+    lib.pdh_assemble_device.argtypes = [C.c_void_p]
+    lib.pdh_assemble.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdh_assemble_sip.argtypes = [C.c_void_p, P(pdh_problem), C.c_void_p]
+    lib.pdh_assemble_sip_local.argtypes = [C.c_void_p, P(pdh_problem), C.c_int32, C.c_int32, C.c_void_p]
+    lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
+    lib.pdh_synchronize.argtypes = [C.c_void_p]
+    lib.pdh_stream.argtypes = [C.c_void_p]
+    lib.pdh_stream.restype = C.c_void_p
+    lib.pdh_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.pdh_kernel_times_ms.argtypes = [C.c_void_p, P(C.c_float)]
+    lib.pdh_problem_stats.argtypes = [C.c_void_p, P(C.c_int64)]
+    lib.pdh_check_problem.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, P(C.c_int64)]
+    lib.pdh_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+_DTYPES = {
+    "bbox": np.float64, "dof_offset": np.int32, "vq_ptr": np.int64, "vq_x": np.float64, "vq_w": np.float64,
+    "face_in": np.int32, "face_out": np.int32, "fq_ptr": np.int64, "fq_x": np.float64, "fq_n": np.float64,
+    "fq_w": np.float64, "fq_w_out": np.float64, "face_sigma": np.float64, "rowptr": np.int64, "colind": np.int32,
+}
+
+
+class Problem:
+    """Owns the NumPy arrays behind a pdh_problem (keeps them alive while the struct is in use)."""
+
+    def __init__(self, *, dim, degree, basis, n_agg, n_faces, n_rows, diag_first=1, reaction_c=0.0, **arrays):
+        self.arrays = {}
+        self.c = pdh_problem()
+        self.c.dim, self.c.degree, self.c.basis = dim, degree, basis
+        self.c.n_agg, self.c.n_faces, self.c.n_rows = n_agg, n_faces, n_rows
+        self.c.diag_first, self.c.reaction_c = int(diag_first), float(reaction_c)
+        for name, dt in _DTYPES.items():
+            a = arrays.get(name)
+            if a is None:
+                setattr(self.c, name, None)
+                continue
+            a = np.ascontiguousarray(a, dtype=dt)
+            self.arrays[name] = a
+            setattr(self.c, name, a.ctypes.data)
+
+    @property
+    def nnz(self):
+        return int(self.arrays["rowptr"][-1])
+
+    def check(self, row_begin=0, row_end=None):
+        lib = load_library()
+        stats = (C.c_int64 * 8)()
+        rc = lib.pdh_check_problem(C.byref(self.c), row_begin, self.c.n_rows if row_end is None else row_end, stats)
+        if rc != PDH_OK:
+            raise PdhError(rc, lib.pdh_last_error(None).decode())
+        return list(stats)
+
+
+class Context:
+    """pdh_ctx wrapper (one per device and host thread)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.pdh_create(C.byref(h), device)
+        if rc != PDH_OK:
+            raise PdhError(rc, self.lib.pdh_last_error(None).decode())
+        self.h = h
+        self.n_values = 0
+
+    def _chk(self, rc):
+        if rc != PDH_OK:
+            raise PdhError(rc, self.lib.pdh_last_error(self.h).decode())
+
+    def set_problem(self, prob: Problem, row_begin=0, row_end=None):
+        row_end = prob.c.n_rows if row_end is None else row_end
+        self._chk(self.lib.pdh_set_problem_local(self.h, C.byref(prob.c), row_begin, row_end))
+        rp = prob.arrays["rowptr"]
+        self.n_values = int(rp[row_end] - rp[row_begin])
+
+    def assemble_device(self):
+        self._chk(self.lib.pdh_assemble_device(self.h))
+
+    def synchronize(self):
+        self._chk(self.lib.pdh_synchronize(self.h))
+
+    def assemble(self):
+        out = np.empty(self.n_values, dtype=np.float64)
+        self._chk(self.lib.pdh_assemble(self.h, out.ctypes.data))
+        return out
+
+    def device_values(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.pdh_device_values(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_profiling(self, on=True):
+        self._chk(self.lib.pdh_set_profiling(self.h, int(on)))
+
+    def kernel_times_ms(self):
+        ms = (C.c_float * 2)()
+        self._chk(self.lib.pdh_kernel_times_ms(self.h, ms))
+        return [float(ms[0]), float(ms[1])]
+
+    def stats(self):
+        st = (C.c_int64 * 8)()
+        self._chk(self.lib.pdh_problem_stats(self.h, st))
+        keys = ["n_owned_agg", "n_offdiag_items", "n_vq_points", "n_face_side_points", "n_values",
+                "dofs_per_cell", "lds_bytes_diag", "lds_bytes_offdiag"]
+        return dict(zip(keys, [int(x) for x in st]))
+
+    def close(self):
+        if self.h:
+            self.lib.pdh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,155 @@
+// pdh_basis.h — host-side tables of the two finite elements the path supports.
+//
+// FE_DGQ<dim>(p)     : tensor-product Lagrange basis on the p+1 Gauss-Lobatto points of [0,1],
+//                      lexicographic numbering, x fastest  [deal.II convention, SURVEY.md 8(c) item 4].
+// FE_AggloDGP<dim>(p): reference source/fe_agglodgp.cc:27-55 — PolynomialSpace<dim> over
+//                      Polynomials::Legendre (L_k(x) = sqrt(2k+1) P_k(2x-1), L2-orthonormal on [0,1]);
+//                      index order "for iz: for iy < n1d-iz: for ix < n1d-iy-iz" (x fastest);
+//                      C(p+dim,dim) dofs (source/fe_agglodgp.cc:89-101).
+//
+// The kernels evaluate 1-D basis functions by Horner's rule from monomial coefficients; the
+// coefficients are generated here in long double.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace pdh
+{
+struct Basis1D
+{
+  int n1d = 0;
+  std::vector<std::vector<long double>> coef; // coef[k][m]
+};
+
+inline std::vector<long double> gauss_lobatto_nodes(int p)
+{
+  std::vector<long double> x(p + 1);
+  if (p == 0)
+    {
+      x[0] = 0.5L;
+      return x;
+    }
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int i = 0; i <= p; ++i)
+    {
+      long double t = -std::cos(pi * i / p); // Chebyshev-Gauss-Lobatto start
+      if (i != 0 && i != p)
+        for (int it = 0; it < 100; ++it)
+          {
+            // Newton on q(t) = P_p'(t): use (1-t^2) P_p' = p (P_{p-1} - t P_p)
+            long double p0 = 1.0L, p1 = t;
+            for (int k = 1; k < p; ++k)
+              {
+                const long double p2 = ((2 * k + 1) * t * p1 - k * p0) / (k + 1);
+                p0 = p1;
+                p1 = p2;
+              }
+            // p1 = P_p, p0 = P_{p-1}
+            const long double dP = p * (p0 - t * p1) / (1 - t * t);
+            const long double d2P = (2 * t * dP - p * (p + 1) * p1) / (1 - t * t);
+            const long double dt = dP / d2P;
+            t -= dt;
+            if (std::fabs((double)dt) < 1e-19)
+              break;
+          }
+      x[i] = 0.5L * (t + 1.0L);
+    }
+  x[0] = 0.0L;
+  x[p] = 1.0L;
+  return x;
+}
+
+inline Basis1D lagrange_basis(int p)
+{
+  Basis1D b;
+  b.n1d = p + 1;
+  const auto nodes = gauss_lobatto_nodes(p);
+  b.coef.assign(p + 1, std::vector<long double>(p + 1, 0.0L));
+  for (int k = 0; k <= p; ++k)
+    {
+      std::vector<long double> c(1, 1.0L);
+      long double denom = 1.0L;
+      for (int j = 0; j <= p; ++j)
+        if (j != k)
+          {
+            std::vector<long double> d(c.size() + 1, 0.0L);
+            for (size_t m = 0; m < c.size(); ++m)
+              {
+                d[m + 1] += c[m];
+                d[m] -= nodes[j] * c[m];
+              }
+            c.swap(d);
+            denom *= nodes[k] - nodes[j];
+          }
+      for (int m = 0; m <= p; ++m)
+        b.coef[k][m] = c[m] / denom;
+    }
+  return b;
+}
+
+inline Basis1D legendre_basis(int p)
+{
+  Basis1D b;
+  b.n1d = p + 1;
+  std::vector<std::vector<long double>> P(p + 1, std::vector<long double>(p + 1, 0.0L));
+  P[0][0] = 1.0L;
+  if (p >= 1)
+    {
+      P[1][0] = -1.0L;
+      P[1][1] = 2.0L;
+    }
+  for (int k = 1; k < p; ++k)
+    for (int m = 0; m <= p; ++m)
+      {
+        long double v = -(long double)(2 * k + 1) * P[k][m];
+        if (m > 0)
+          v += (long double)(2 * k + 1) * 2.0L * P[k][m - 1];
+        v -= (long double)k * P[k - 1][m];
+        P[k + 1][m] = v / (k + 1);
+      }
+  b.coef.assign(p + 1, std::vector<long double>(p + 1, 0.0L));
+  for (int k = 0; k <= p; ++k)
+    {
+      const long double s = std::sqrt((long double)(2 * k + 1));
+      for (int m = 0; m <= p; ++m)
+        b.coef[k][m] = s * P[k][m];
+    }
+  return b;
+}
+
+// multi-index of every dof, packed k0 | k1<<8 | k2<<16
+inline std::vector<uint32_t> multi_indices(int dim, int p, int basis /*0 DGQ, 1 AggloDGP*/)
+{
+  std::vector<uint32_t> mi;
+  const int n1d = p + 1;
+  if (basis == 0)
+    {
+      const int n = (dim == 2) ? n1d * n1d : n1d * n1d * n1d;
+      for (int i = 0; i < n; ++i)
+        {
+          const int i0 = i % n1d, i1 = (i / n1d) % n1d, i2 = i / (n1d * n1d);
+          mi.push_back((uint32_t)i0 | ((uint32_t)i1 << 8) | ((uint32_t)i2 << 16));
+        }
+    }
+  else if (dim == 2)
+    {
+      for (int iy = 0; iy < n1d; ++iy)
+        for (int ix = 0; ix < n1d - iy; ++ix)
+          mi.push_back((uint32_t)ix | ((uint32_t)iy << 8));
+    }
+  else
+    {
+      for (int iz = 0; iz < n1d; ++iz)
+        for (int iy = 0; iy < n1d - iz; ++iy)
+          for (int ix = 0; ix < n1d - iy - iz; ++ix)
+            mi.push_back((uint32_t)ix | ((uint32_t)iy << 8) | ((uint32_t)iz << 16));
+    }
+  return mi;
+}
+
+inline int n_dofs_per_cell(int dim, int p, int basis)
+{
+  return (int)multi_indices(dim, p, basis).size();
+}
+} // namespace pdh

@@ -1,0 +1,569 @@
+// pdh_capi.cpp — implementation of the C ABI declared in include/polydeal_hip.h.
+//
+// Host work done here is SETUP only (what the reference does once per mesh in
+// AgglomerationHandler::distribute_agglomerated_dofs / setup_connectivity_of_agglomeration /
+// create_agglomeration_sparsity_pattern, source/agglomeration_handler.cc:326-379, 495-527, 910-1022):
+// validation, repacking of the face tables per owning polytope, block positions inside CSR rows, upload.
+// The assembly itself (pdh_assemble_device) only launches the two HIP kernels of pdh_kernels.h.
+#include "../../include/polydeal_hip.h"
+#include "pdh_basis.h"
+#include "pdh_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+typedef hipError_t (*pdh_launch_fn)(int lb, int which, const PdhDev *P, int count, size_t lds, hipStream_t stream);
+#define PDH_DECL(d, n) hipError_t pdh_launch_##d##_##n(int, int, const PdhDev *, int, size_t, hipStream_t);
+PDH_DECL(2, 1) PDH_DECL(2, 2) PDH_DECL(2, 3) PDH_DECL(2, 4)
+PDH_DECL(3, 1) PDH_DECL(3, 2) PDH_DECL(3, 3) PDH_DECL(3, 4)
+#undef PDH_DECL
+}
+
+static pdh_launch_fn g_launch[2][4] = {
+  {pdh_launch_2_1, pdh_launch_2_2, pdh_launch_2_3, pdh_launch_2_4},
+  {pdh_launch_3_1, pdh_launch_3_2, pdh_launch_3_3, pdh_launch_3_4},
+};
+
+struct pdh_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool has_problem = false;
+  std::vector<void *> allocs;
+  PdhDev dev;
+  int n_owned = 0, n_items = 0, NT = 0, LB = 0;
+  size_t lds_diag = 0, lds_off = 0;
+  int64_t n_values = 0, n_vq = 0, n_ap = 0;
+  bool profiling = false;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  float last_ms[PDH_N_KERNELS] = {0.f, 0.f};
+  bool timed = false;
+};
+
+static thread_local std::string g_err_noctx;
+
+static int fail(pdh_ctx *ctx, int code, const std::string &msg)
+{
+  if (ctx)
+    ctx->err = msg;
+  else
+    g_err_noctx = msg;
+  return code;
+}
+
+#define PDH_HIP(ctx, call)                                                                         \
+  do                                                                                               \
+    {                                                                                              \
+      hipError_t e_ = (call);                                                                      \
+      if (e_ != hipSuccess)                                                                        \
+        return fail(ctx, PDH_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_));          \
+    }                                                                                              \
+  while (0)
+
+static void free_problem(pdh_ctx *ctx)
+{
+  for (void *p : ctx->allocs)
+    (void)hipFree(p);
+  ctx->allocs.clear();
+  ctx->has_problem = false;
+}
+
+template <class T>
+static int upload(pdh_ctx *ctx, const std::vector<T> &h, const T **dptr)
+{
+  void *d = nullptr;
+  const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  PDH_HIP(ctx, hipMalloc(&d, bytes));
+  ctx->allocs.push_back(d);
+  if (!h.empty())
+    PDH_HIP(ctx, hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dptr = static_cast<const T *>(d);
+  return PDH_OK;
+}
+
+extern "C" const char *pdh_version(void) { return "polydeal_hip 0.1 gfx950"; }
+
+extern "C" const char *pdh_last_error(const pdh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err_noctx.c_str(); }
+
+extern "C" int pdh_create(pdh_ctx **out, int device_id)
+{
+  if (!out)
+    return fail(nullptr, PDH_EINVAL, "pdh_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, PDH_EDEVICE,
+                std::string("pdh_create: no HIP device available (") + hipGetErrorString(e) +
+                  "); this library has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev)
+    return fail(nullptr, PDH_EINVAL, "pdh_create: device_id out of range");
+  pdh_ctx *ctx = new pdh_ctx;
+  ctx->device = device_id;
+  PDH_HIP(nullptr, hipSetDevice(device_id));
+  if (hipStreamCreate(&ctx->stream) != hipSuccess)
+    {
+      delete ctx;
+      return fail(nullptr, PDH_EDEVICE, "pdh_create: hipStreamCreate failed");
+    }
+  for (auto &ev : ctx->ev)
+    (void)hipEventCreate(&ev);
+  *out = ctx;
+  return PDH_OK;
+}
+
+extern "C" void pdh_destroy(pdh_ctx *ctx)
+{
+  if (!ctx)
+    return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_problem(ctx);
+  for (auto &ev : ctx->ev)
+    if (ev)
+      (void)hipEventDestroy(ev);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host-only part of set_problem: validation + repacking.  Kept separate so that it can be exercised on
+// a machine without a GPU (tests call pdh_check_problem).
+// ---------------------------------------------------------------------------------------------------
+struct Packed
+{
+  int n = 0, n1d = 0, NT = 0, LB = 0;
+  std::vector<int32_t> midx;
+  PdhBasisTab tab;
+  std::vector<int32_t> own_agg, row_len, diag_L, it_own, it_nbr, it_pcnt, it_pos;
+  std::vector<int64_t> row_base, vq_ptr, ap_ptr, it_pbeg;
+  std::vector<double> vq_x, vq_w, ap_x, ap_n, ap_wself, ap_wcross, ap_sig;
+  int64_t n_values = 0;
+};
+
+static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end, Packed &K)
+{
+  if (!p)
+    return fail(ctx, PDH_EINVAL, "problem is NULL");
+  if (p->dim != 2 && p->dim != 3)
+    return fail(ctx, PDH_EINVAL, "dim must be 2 or 3");
+  if (p->basis != PDH_BASIS_DGQ && p->basis != PDH_BASIS_AGGLODGP)
+    return fail(ctx, PDH_EINVAL, "unknown basis");
+  if (p->degree < 0 || p->degree + 1 > PDH_MAX_N1D)
+    return fail(ctx, PDH_EUNSUPPORTED, "degree must be in [0,7]");
+  if (p->n_agg <= 0 || p->n_faces < 0)
+    return fail(ctx, PDH_EINVAL, "n_agg must be positive and n_faces non-negative");
+  if (!p->bbox || !p->dof_offset || !p->vq_ptr || !p->vq_x || !p->vq_w || !p->rowptr)
+    return fail(ctx, PDH_EINVAL, "a required array is NULL");
+  if (p->n_faces > 0 && (!p->face_in || !p->face_out || !p->fq_ptr || !p->fq_x || !p->fq_n || !p->fq_w || !p->face_sigma))
+    return fail(ctx, PDH_EINVAL, "a required face array is NULL");
+  const int dim = p->dim;
+  const int n = pdh::n_dofs_per_cell(dim, p->degree, p->basis);
+  if (n > 64)
+    return fail(ctx, PDH_EUNSUPPORTED, "more than 64 dofs per polytope are not supported by this build");
+  if ((int64_t)n * p->n_agg != p->n_rows)
+    return fail(ctx, PDH_EINVAL, "n_rows != dofs_per_cell * n_agg");
+  if (row_begin < 0 || row_end > p->n_rows || row_begin > row_end || row_begin % n || row_end % n)
+    return fail(ctx, PDH_EINVAL, "owned row range must be aligned to whole polytopes");
+  K.n = n;
+  K.n1d = p->degree + 1;
+  const int T = (n + 3) / 4;
+  K.NT = (T + 3) / 4;
+  K.LB = T - 4 * (K.NT - 1);
+
+  // basis tables
+  const pdh::Basis1D b1 = (p->basis == PDH_BASIS_DGQ) ? pdh::lagrange_basis(p->degree) : pdh::legendre_basis(p->degree);
+  std::memset(&K.tab, 0, sizeof(K.tab));
+  for (int k = 0; k < K.n1d; ++k)
+    for (int m = 0; m < K.n1d; ++m)
+      K.tab.coef[k][m] = (double)b1.coef[k][m];
+  const auto mi = pdh::multi_indices(dim, p->degree, p->basis);
+  K.midx.assign(16 * K.NT, (int32_t)0xffffffffu);
+  for (int i = 0; i < n; ++i)
+    K.midx[i] = (int32_t)mi[i];
+
+  const int nA = p->n_agg, nF = p->n_faces;
+  for (int a = 0; a < nA; ++a)
+    {
+      const int off = p->dof_offset[a];
+      if (off < 0 || off % n || off + n > p->n_rows)
+        return fail(ctx, PDH_EINVAL, "dof_offset must be a multiple of dofs_per_cell inside [0,n_rows)");
+      if (p->vq_ptr[a + 1] < p->vq_ptr[a])
+        return fail(ctx, PDH_EINVAL, "vq_ptr must be non-decreasing");
+      for (int c = 0; c < dim; ++c)
+        if (!(p->bbox[(size_t)a * 2 * dim + dim + c] > p->bbox[(size_t)a * 2 * dim + c]))
+          return fail(ctx, PDH_EINVAL, "degenerate bounding box");
+    }
+  // faces per polytope (CSR by counting)
+  std::vector<int64_t> fptr(nA + 1, 0);
+  for (int f = 0; f < nF; ++f)
+    {
+      const int in = p->face_in[f], out = p->face_out[f];
+      if (in < 0 || in >= nA || out < -1 || out >= nA || out == in)
+        return fail(ctx, PDH_EINVAL, "face_in/face_out out of range");
+      if (p->fq_ptr[f + 1] < p->fq_ptr[f])
+        return fail(ctx, PDH_EINVAL, "fq_ptr must be non-decreasing");
+      ++fptr[in + 1];
+      if (out >= 0)
+        ++fptr[out + 1];
+    }
+  for (int a = 0; a < nA; ++a)
+    fptr[a + 1] += fptr[a];
+  std::vector<int32_t> flist(fptr[nA]);
+  {
+    std::vector<int64_t> cur(fptr.begin(), fptr.end() - 1);
+    for (int f = 0; f < nF; ++f)
+      {
+        flist[cur[p->face_in[f]]++] = f;
+        if (p->face_out[f] >= 0)
+          flist[cur[p->face_out[f]]++] = f;
+      }
+  }
+
+  const int64_t nq_tot = p->vq_ptr[nA];
+  const int64_t nqf_tot = nF ? p->fq_ptr[nF] : 0;
+  const int64_t val_base = p->rowptr[row_begin];
+  K.n_values = p->rowptr[row_end] - val_base;
+
+  // owned polytopes in polytope order
+  K.vq_ptr.push_back(0);
+  K.ap_ptr.push_back(0);
+  std::vector<std::pair<int32_t, int32_t>> blocks; // (dof offset, polytope)
+  for (int a = 0; a < nA; ++a)
+    {
+      const int off = p->dof_offset[a];
+      if (off < row_begin || off >= row_end)
+        continue;
+      const int slot = (int)K.own_agg.size();
+      K.own_agg.push_back(a);
+      // coupled blocks, ascending by dof offset (reference :954-975)
+      blocks.clear();
+      blocks.emplace_back(off, a);
+      for (int64_t t = fptr[a]; t < fptr[a + 1]; ++t)
+        {
+          const int f = flist[t];
+          const int other = (p->face_in[f] == a) ? p->face_out[f] : p->face_in[f];
+          if (other >= 0)
+            blocks.emplace_back(p->dof_offset[other], other);
+        }
+      std::sort(blocks.begin(), blocks.end());
+      for (size_t t = 1; t < blocks.size(); ++t)
+        if (blocks[t].first == blocks[t - 1].first)
+          return fail(ctx, PDH_EINVAL, "two faces couple the same pair of polytopes (faces must be merged per neighbour)");
+      const int64_t r0 = p->rowptr[off];
+      const int64_t rl = p->rowptr[off + 1] - r0;
+      if (rl != (int64_t)blocks.size() * n)
+        return fail(ctx, PDH_EINVAL, "row length does not match (1 + #neighbours) * dofs_per_cell for polytope " + std::to_string(a));
+      for (int i = 1; i < n; ++i)
+        if (p->rowptr[off + i + 1] - p->rowptr[off + i] != rl)
+          return fail(ctx, PDH_EINVAL, "rows of one polytope must have equal length");
+      K.row_base.push_back(r0 - val_base);
+      K.row_len.push_back((int32_t)rl);
+      int own_rank = 0;
+      for (size_t t = 0; t < blocks.size(); ++t)
+        if (blocks[t].second == a)
+          own_rank = (int)t;
+      K.diag_L.push_back(own_rank * n);
+      if (p->colind)
+        { // verify the first row of the polytope against the canonical layout
+          const int32_t *ci = p->colind + r0;
+          for (size_t t = 0; t < blocks.size(); ++t)
+            for (int j = 0; j < n; j += (n > 1 ? n - 1 : 1))
+              {
+                const int col = blocks[t].first + j;
+                int64_t pos = (int64_t)t * n + j;
+                if (p->diag_first)
+                  pos = (col == off) ? 0 : (col < off ? pos + 1 : pos);
+                if (ci[pos] != col)
+                  return fail(ctx, PDH_EINVAL, "colind does not have the DG block layout expected for polytope " + std::to_string(a));
+              }
+        }
+      // volume points
+      for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q)
+        K.vq_w.push_back(p->vq_w[q]);
+      K.vq_ptr.push_back((int64_t)K.vq_w.size());
+      // own-side face points + coupling items
+      for (int64_t t = fptr[a]; t < fptr[a + 1]; ++t)
+        {
+          const int f = flist[t];
+          const bool side0 = (p->face_in[f] == a);
+          const int other = side0 ? p->face_out[f] : p->face_in[f];
+          const int64_t qb = p->fq_ptr[f], qe = p->fq_ptr[f + 1];
+          const double sig = p->face_sigma[f];
+          if (other >= 0)
+            {
+              K.it_own.push_back(slot);
+              K.it_nbr.push_back(other);
+              K.it_pbeg.push_back((int64_t)K.ap_wself.size());
+              K.it_pcnt.push_back((int32_t)(qe - qb));
+              size_t rank = 0;
+              for (size_t u = 0; u < blocks.size(); ++u)
+                if (blocks[u].second == other)
+                  rank = u;
+              int pos = (int)rank * n;
+              if (p->diag_first && p->dof_offset[other] < off)
+                pos += 1;
+              K.it_pos.push_back(pos);
+            }
+          for (int64_t q = qb; q < qe; ++q)
+            {
+              const double w_in = p->fq_w[q];
+              const double w_out = p->fq_w_out ? p->fq_w_out[q] : w_in;
+              if (other < 0)
+                { // Nitsche boundary: same form with 2 JxW and sigma / 2 (exact scalings)
+                  K.ap_wself.push_back(2.0 * w_in);
+                  K.ap_wcross.push_back(0.0);
+                  K.ap_sig.push_back(0.5 * sig);
+                }
+              else
+                {
+                  K.ap_wself.push_back(side0 ? w_in : w_out); // M11 uses JxW_0, M22 JxW_1 (poly_utils.h:1898, 1922)
+                  K.ap_wcross.push_back(w_out);               // M12, M21 use JxW_1 (poly_utils.h:1906, 1914)
+                  K.ap_sig.push_back(sig);
+                }
+            }
+        }
+      K.ap_ptr.push_back((int64_t)K.ap_wself.size());
+    }
+  if ((int64_t)K.own_agg.size() * n != (int64_t)(row_end - row_begin))
+    return fail(ctx, PDH_EINVAL, "dof_offset values do not tile the owned row range");
+
+  // second pass: coordinates / normals in SoA with the final strides
+  const int64_t nvq = (int64_t)K.vq_w.size(), nap = (int64_t)K.ap_wself.size();
+  K.vq_x.resize((size_t)dim * nvq);
+  K.ap_x.resize((size_t)dim * nap);
+  K.ap_n.resize((size_t)dim * nap);
+  int64_t vq = 0, ap = 0;
+  for (int a : K.own_agg)
+    {
+      for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q, ++vq)
+        for (int c = 0; c < dim; ++c)
+          K.vq_x[c * nvq + vq] = p->vq_x[c * nq_tot + q];
+      for (int64_t t = fptr[a]; t < fptr[a + 1]; ++t)
+        {
+          const int f = flist[t];
+          const double sgn = (p->face_in[f] == a) ? 1.0 : -1.0;
+          for (int64_t q = p->fq_ptr[f]; q < p->fq_ptr[f + 1]; ++q, ++ap)
+            for (int c = 0; c < dim; ++c)
+              {
+                K.ap_x[c * nap + ap] = p->fq_x[c * nqf_tot + q];
+                K.ap_n[c * nap + ap] = sgn * p->fq_n[c * nqf_tot + q];
+              }
+        }
+    }
+  return PDH_OK;
+}
+
+// Host-only validation (no GPU needed): runs exactly the checks of pdh_set_problem.
+extern "C" int pdh_check_problem(const pdh_problem *p, int32_t row_begin, int32_t row_end, int64_t *stats)
+{
+  Packed K;
+  g_err_noctx.clear();
+  const int rc = pack_problem(nullptr, p, row_begin, row_end, K);
+  if (rc == PDH_OK && stats)
+    {
+      stats[0] = (int64_t)K.own_agg.size();
+      stats[1] = (int64_t)K.it_own.size();
+      stats[2] = (int64_t)K.vq_w.size();
+      stats[3] = (int64_t)K.ap_wself.size();
+      stats[4] = K.n_values;
+      stats[5] = K.n;
+      stats[6] = (int64_t)pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
+      stats[7] = (int64_t)pdh::lds_bytes_offdiag(p->dim, K.n1d, K.NT);
+    }
+  return rc;
+}
+
+extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_problem(ctx);
+  Packed K;
+  int rc = pack_problem(ctx, p, row_begin, row_end, K);
+  if (rc != PDH_OK)
+    return rc;
+
+  PdhDev &D = ctx->dev;
+  std::memset(&D, 0, sizeof(D));
+  D.dim = p->dim;
+  D.n = K.n;
+  D.n1d = K.n1d;
+  D.diag_first = p->diag_first ? 1 : 0;
+  D.reaction_c = p->reaction_c;
+  D.tab = K.tab;
+  std::vector<double> bbox(p->bbox, p->bbox + (size_t)p->n_agg * 2 * p->dim);
+#define PDH_UP(vec, field)                                                                         \
+  if ((rc = upload(ctx, vec, &D.field)) != PDH_OK)                                                 \
+    {                                                                                              \
+      free_problem(ctx);                                                                           \
+      return rc;                                                                                   \
+    }
+  PDH_UP(bbox, bbox)
+  PDH_UP(K.midx, midx)
+  PDH_UP(K.vq_ptr, vq_ptr)
+  PDH_UP(K.vq_x, vq_x)
+  PDH_UP(K.vq_w, vq_w)
+  PDH_UP(K.ap_ptr, ap_ptr)
+  PDH_UP(K.ap_x, ap_x)
+  PDH_UP(K.ap_n, ap_n)
+  PDH_UP(K.ap_wself, ap_wself)
+  PDH_UP(K.ap_wcross, ap_wcross)
+  PDH_UP(K.ap_sig, ap_sig)
+  PDH_UP(K.own_agg, own_agg)
+  PDH_UP(K.row_base, row_base)
+  PDH_UP(K.row_len, row_len)
+  PDH_UP(K.diag_L, diag_L)
+  PDH_UP(K.it_own, it_own)
+  PDH_UP(K.it_nbr, it_nbr)
+  PDH_UP(K.it_pbeg, it_pbeg)
+  PDH_UP(K.it_pcnt, it_pcnt)
+  PDH_UP(K.it_pos, it_pos)
+#undef PDH_UP
+  D.vq_stride = (int64_t)K.vq_w.size();
+  D.ap_stride = (int64_t)K.ap_wself.size();
+  void *dv = nullptr;
+  hipError_t e = hipMalloc(&dv, std::max<int64_t>(K.n_values, 1) * sizeof(double));
+  if (e != hipSuccess)
+    {
+      free_problem(ctx);
+      return fail(ctx, PDH_EDEVICE, std::string("hipMalloc(values): ") + hipGetErrorString(e));
+    }
+  ctx->allocs.push_back(dv);
+  D.values = static_cast<double *>(dv);
+  ctx->n_values = K.n_values;
+  ctx->n_owned = (int)K.own_agg.size();
+  ctx->n_items = (int)K.it_own.size();
+  ctx->n_vq = (int64_t)K.vq_w.size();
+  ctx->n_ap = (int64_t)K.ap_wself.size();
+  ctx->NT = K.NT;
+  ctx->LB = K.LB;
+  ctx->lds_diag = pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
+  ctx->lds_off = pdh::lds_bytes_offdiag(p->dim, K.n1d, K.NT);
+  ctx->has_problem = true;
+  ctx->timed = false;
+  return PDH_OK;
+}
+
+extern "C" int pdh_set_problem(pdh_ctx *ctx, const pdh_problem *p)
+{
+  if (!p)
+    return fail(ctx, PDH_EINVAL, "problem is NULL");
+  return pdh_set_problem_local(ctx, p, 0, p->n_rows);
+}
+
+extern "C" int pdh_assemble_device(pdh_ctx *ctx)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (!ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "pdh_assemble_device called before pdh_set_problem");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  pdh_launch_fn fn = g_launch[ctx->dev.dim - 2][ctx->NT - 1];
+  if (ctx->profiling)
+    PDH_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  PDH_HIP(ctx, fn(ctx->LB, 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
+  if (ctx->profiling)
+    PDH_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  PDH_HIP(ctx, fn(ctx->LB, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
+  if (ctx->profiling)
+    {
+      PDH_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      ctx->timed = true;
+    }
+  return PDH_OK;
+}
+
+extern "C" int pdh_synchronize(pdh_ctx *ctx)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PDH_OK;
+}
+
+extern "C" void *pdh_stream(pdh_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int pdh_assemble(pdh_ctx *ctx, double *values)
+{
+  if (!values)
+    return fail(ctx, PDH_EINVAL, "values is NULL");
+  int rc = pdh_assemble_device(ctx);
+  if (rc != PDH_OK)
+    return rc;
+  PDH_HIP(ctx, hipMemcpyAsync(values, ctx->dev.values, ctx->n_values * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PDH_OK;
+}
+
+extern "C" int pdh_assemble_sip_local(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end, double *values)
+{
+  int rc = pdh_set_problem_local(ctx, p, row_begin, row_end);
+  if (rc != PDH_OK)
+    return rc;
+  return pdh_assemble(ctx, values);
+}
+
+extern "C" int pdh_assemble_sip(pdh_ctx *ctx, const pdh_problem *p, double *values)
+{
+  if (!p)
+    return fail(ctx, PDH_EINVAL, "problem is NULL");
+  return pdh_assemble_sip_local(ctx, p, 0, p->n_rows, values);
+}
+
+extern "C" int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values)
+{
+  if (!ctx || !ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "no problem resident");
+  if (device_ptr)
+    *device_ptr = ctx->dev.values;
+  if (n_values)
+    *n_values = ctx->n_values;
+  return PDH_OK;
+}
+
+extern "C" int pdh_set_profiling(pdh_ctx *ctx, int enabled)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  ctx->profiling = enabled != 0;
+  ctx->timed = false;
+  return PDH_OK;
+}
+
+extern "C" int pdh_kernel_times_ms(pdh_ctx *ctx, float *ms)
+{
+  if (!ctx || !ms)
+    return fail(ctx, PDH_EINVAL, "ctx or ms is NULL");
+  if (!ctx->timed)
+    return fail(ctx, PDH_ESTATE, "no profiled launch recorded (pdh_set_profiling(1) then pdh_assemble_device)");
+  PDH_HIP(ctx, hipEventSynchronize(ctx->ev[2]));
+  PDH_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[1]));
+  PDH_HIP(ctx, hipEventElapsedTime(&ms[1], ctx->ev[1], ctx->ev[2]));
+  return PDH_OK;
+}
+
+extern "C" int pdh_problem_stats(pdh_ctx *ctx, int64_t *stats)
+{
+  if (!ctx || !ctx->has_problem || !stats)
+    return fail(ctx, PDH_ESTATE, "no problem resident");
+  stats[0] = ctx->n_owned;
+  stats[1] = ctx->n_items;
+  stats[2] = ctx->n_vq;
+  stats[3] = ctx->n_ap;
+  stats[4] = ctx->n_values;
+  stats[5] = ctx->dev.n;
+  stats[6] = (int64_t)ctx->lds_diag;
+  stats[7] = (int64_t)ctx->lds_off;
+  return PDH_OK;
+}
