@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — assembled DoF/s of the SIP Poisson matrix (p=3, 3-D) on N MI355X.
+
+One "step" = one full pass of the hot path: volume + SIP face/interface terms + CSR value write of the
+whole matrix, inputs resident in HBM (what the reference times around assemble_system():
+examples/poisson.cc:1099-1103).  Workload = BASELINE.json configs[2]: unit cube, 64^3 hex background
+mesh, 32^3 = 32 768 polytopes of 2x2x2 cells, p = 3, QGauss(4) cell and face rules (examples/poisson.cc:
+702-709), SIP variant of examples/poisson.cc.  Headline FE is FE_DGQ(3) ((p+1)^3 = 64 dofs/polytope,
+2 097 152 dofs); the FE_AggloDGP(3) number (20 dofs/polytope, what poisson.cc instantiates) is reported
+under "extra".  N > 1: strong scaling, polytopes (matrix rows) split into N contiguous ranges, one rank
+per GPU, every rank owns its rows outright (owner-computes-rows) so the data path has no collective.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; see DESIGN.md
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_work(flat, n):
+    """flops and compulsory HBM bytes, split per kernel.
+    volume 2 d Nq n^2 per polytope; interior face 24 Nqf n^2 (12 of them in the two diagonal blocks,
+    12 in the two coupling blocks); boundary face 6 Nqf n^2.  Bytes: every CSR value written once
+    + quadrature data read once (8 (d+1) per volume point, 8 (2d+1) per face point per side)."""
+    import numpy as np
+    c = flat.c
+    d = c.dim
+    arr = flat.arrays()
+    nq = flat.nq_tot
+    fq_ptr = arr["fq_ptr"]
+    cnt = np.diff(fq_ptr) if fq_ptr is not None else np.zeros(0)
+    interior = arr["face_out"] >= 0 if c.n_faces else np.zeros(0, bool)
+    nqf_int = float(cnt[interior].sum()) if c.n_faces else 0.0
+    nqf_bdr = float(cnt[~interior].sum()) if c.n_faces else 0.0
+    n2 = float(n) * n
+    fl_diag = 2.0 * d * nq * n2 + 12.0 * nqf_int * n2 + 6.0 * nqf_bdr * n2
+    fl_off = 12.0 * nqf_int * n2
+    n_int = int(interior.sum()) if c.n_faces else 0
+    by_diag = 8.0 * n2 * c.n_agg + 8.0 * (d + 1) * nq + 8.0 * (2 * d + 1) * (2 * nqf_int + nqf_bdr)
+    by_off = 8.0 * n2 * 2 * n_int + 8.0 * (2 * d + 1) * 2 * nqf_int
+    return dict(flops=[fl_diag, fl_off], bytes=[by_diag, by_off])
+
+
+def build_handler(pa, dim, cells, block, basis, degree, nq):
+    lg = cells.bit_length() - 1
+    if (1 << lg) == cells:
+        grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, lg)
+    else:
+        grid = pa.BackgroundGrid.subdivided_hyper_cube(dim, cells, 0.0, 1.0)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_block_agglomerates(block)
+    fe = (pa.FE_DGQ if basis == "dgq" else pa.FE_AggloDGP)(dim, degree)
+    ah.initialize_fe_values(nq, nq)
+    ah.distribute_agglomerated_dofs(fe)
+    return grid, ah, fe
+
+
+def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup):
+    t0 = time.time()
+    grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1)
+    var = pa.SipVariant.poisson_example(fe)
+    flat = ah.flatten(var, diag_first=True, with_colind=False)
+    n = fe.n_dofs_per_cell
+    n_agg = ah.n_agglomerates
+    # contiguous dof-row ranges of whole polytopes per rank (strong scaling)
+    a0 = (n_agg * rank) // world
+    a1 = (n_agg * (rank + 1)) // world
+    ctx = pa.Context(local_rank)
+    ctx.set_problem(flat, a0 * n, a1 * n)
+    t_setup = time.time() - t0
+    for _ in range(warmup):
+        ctx.assemble_device()
+    ctx.synchronize()
+    ctx.set_profiling(True)
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync_all()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        ctx.assemble_device()
+    sync_all()
+    dt = time.perf_counter() - t1
+    kms, nl = ctx.kernel_times_ms()
+    ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = ctx.stats()
+    work = algorithmic_work(flat, n) if rank == 0 else None
+    # checksum of this rank's rows (sanity: finite, non-zero)
+    import ctypes
+    import numpy as np
+    vals = ctx.assemble() if stats["n_values"] <= 64_000_000 else None
+    chk = float(np.sum(vals)) if vals is not None else None
+    ctx.close()
+    return dict(n_dofs=ah.n_dofs, n_agg=n_agg, n=n, dt=dt, kms=kms, nl=nl, stats=stats, work=work,
+                t_setup=t_setup, nnz=flat.nnz, checksum=chk)
+
+
+def cpu_baseline(pa, args, basis):
+    """Reference-shaped C restatement (oracle/sip_ref.c) timed on the host cores on a bounded sample:
+    same FE / rules / variant / block size, fewer polytopes (cost per polytope is size-independent).
+    A 1-core calibration run sizes the two samples to about args.cpu_seconds of CPU wall time each."""
+    from oracle import sip_ref
+    cores = os.cpu_count() or 1
+    nthreads = max(1, min(cores, sip_ref.max_threads()))
+
+    def run(nb, thr):
+        cells = nb * args.block
+        grid, ah, fe = build_handler(pa, args.dim, cells, args.block, basis, args.degree, args.degree + 1)
+        flat = ah.flatten(pa.SipVariant.poisson_example(fe), diag_first=True, with_colind=True)
+        kw = flat.arrays()
+        c = flat.c
+        kw.update(dim=c.dim, degree=c.degree, basis=c.basis, n_agg=c.n_agg, n_faces=c.n_faces, n_rows=c.n_rows,
+                  diag_first=c.diag_first, reaction_c=c.reaction_c)
+        _, secs = sip_ref.assemble(kw, nthreads=thr)
+        return dict(dofs=ah.n_dofs, secs=secs, threads=thr, n_agg=ah.n_agglomerates, nb=nb)
+
+    cal = run(3, 1)
+    per_poly = cal["secs"] / cal["n_agg"]
+    root = 1.0 / args.dim
+    nb_one = int(max(3, min(args.cpu_max_blocks, round((args.cpu_seconds / per_poly) ** root))))
+    nb_all = int(max(3, min(args.cpu_max_blocks, round((args.cpu_seconds * nthreads / per_poly) ** root))))
+    return dict(all=run(nb_all, nthreads), one=run(nb_one, 1)), cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--cells", type=int, default=64, help="background cells per direction")
+    ap.add_argument("--block", type=int, default=2, help="cells per direction in one polytope")
+    ap.add_argument("--degree", type=int, default=3)
+    ap.add_argument("--fe", choices=["dgq", "dgp"], default="dgq")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary FE measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU wall time of each baseline sample")
+    ap.add_argument("--cpu-max-blocks", type=int, default=20, help="cap on polytopes per direction of a CPU sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import polydeal_amd as pa
+
+    main_res = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, args.steps, args.warmup)
+    extra = {}
+    other = "dgp" if args.fe == "dgq" else "dgq"
+    if not args.no_extra:
+        r2 = run_gpu(pa, torch, dist, args, other, rank, world, local_rank, args.steps, args.warmup)
+        extra = {"fe": ("FE_AggloDGP" if other == "dgp" else "FE_DGQ") + "(%d)" % args.degree,
+                 "dofs_per_polytope": r2["n"], "n_dofs": r2["n_dofs"],
+                 "value": r2["n_dofs"] / (r2["dt"] / args.steps), "ms_per_step": 1e3 * r2["dt"] / args.steps,
+                 "kernel_ms": {"k_diag": r2["kms"][0], "k_offdiag": r2["kms"][1]}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res, cores = cpu_baseline(pa, args, args.fe)
+        a, o = res["all"], res["one"]
+        cpu = {"value": a["dofs"] / a["secs"], "unit": "DoF/s", "cores": a["threads"], "kind": "port",
+               "sample": "oracle/sip_ref.c (reference-shaped C restatement, gcc -O2, OpenMP over polytopes) on %d^%d=%d polytopes "
+                         "of the same workload (%d dofs) in %.1f s on %d threads; 1 core: %d polytopes in %.1f s"
+                         % (a["nb"], args.dim, a["n_agg"], a["dofs"], a["secs"], a["threads"], o["n_agg"], o["secs"]),
+               "value_1core": o["dofs"] / o["secs"], "host_cores": cores}
+
+    if rank == 0:
+        r = main_res
+        ms_step = 1e3 * r["dt"] / args.steps
+        value = r["n_dofs"] / (r["dt"] / args.steps)
+        w = r["work"]
+        # dominant kernel: k_diag (volume + own-side face terms).  At N>1 rank 0 holds 1/N of the launch.
+        frac_rows = r["stats"]["n_owned_agg"] / r["n_agg"]
+        kd = r["kms"][0] * 1e-3
+        ach_tf = w["flops"][0] * frac_rows / kd * 1e-12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        wl = "%dD cells=%d block=%d %s p=%d" % (args.dim, args.cells, args.block, args.fe, args.degree)
+        if os.path.exists(tpath) and world == 1:
+            try:
+                traffic = json.load(open(tpath)).get(wl, {}).get("k_diag_bytes")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "assembled DoF/s (SIP Poisson, p=%d, %dD)" % (args.degree, args.dim),
+            "value": value, "unit": "DoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dD SIP Poisson, unit cube, %d^%d hex cells, %d polytopes of %d^%d cells, %s(%d) n=%d, "
+                                   "QGauss(%d), variant examples/poisson.cc; %d dofs, %d nnz"
+                                   % (args.dim, args.cells, args.dim, r["n_agg"], args.block, args.dim,
+                                      "FE_DGQ" if args.fe == "dgq" else "FE_AggloDGP", args.degree, r["n"],
+                                      args.degree + 1, r["n_dofs"], r["nnz"]),
+                       "parallelism": "rows(polytopes) split in %d contiguous ranges, owner-computes-rows, no collective" % world},
+            "roofline": {"bound": "mfma", "kernel": "k_diag", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel_ms": kd * 1e3, "launches_timed": r["nl"],
+                         "algorithmic_flops_per_launch": w["flops"][0] * frac_rows,
+                         "algorithmic_bytes_per_launch": w["bytes"][0] * frac_rows,
+                         "hbm_achieved_GBs": w["bytes"][0] * frac_rows / kd * 1e-9, "hbm_peak_GBs": HBM_PEAK_GBS,
+                         "k_offdiag": {"kernel_ms": r["kms"][1],
+                                       "achieved": w["flops"][1] * frac_rows / (r["kms"][1] * 1e-3) * 1e-12,
+                                       "hbm_achieved_GBs": w["bytes"][1] * frac_rows / (r["kms"][1] * 1e-3) * 1e-9},
+                         "whole_step_TFLOPs": (w["flops"][0] + w["flops"][1]) / (r["dt"] / args.steps) * 1e-12},
+            "cpu_baseline": cpu,
+            "extra": extra,
+            "setup_s": r["t_setup"], "checksum": r["checksum"],
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

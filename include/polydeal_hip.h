@@ -110,8 +110,9 @@ void *pdh_stream(pdh_ctx *ctx); /* hipStream_t the kernels are launched on */
 /* Measurement helpers (HIP events on the context's stream).  kernel 0 = diagonal-block kernel
  * (volume + own-side face terms), kernel 1 = off-diagonal (interface coupling) kernel.            */
 #define PDH_N_KERNELS 2
-int pdh_set_profiling(pdh_ctx *ctx, int enabled);
-int pdh_kernel_times_ms(pdh_ctx *ctx, float *ms /* [PDH_N_KERNELS], last launch */);
+int pdh_set_profiling(pdh_ctx *ctx, int enabled); /* enabling (re)starts the accumulation */
+int pdh_kernel_times_ms(pdh_ctx *ctx, float *ms /* [PDH_N_KERNELS] average per launch */,
+                        int *n_launches /* launches averaged over, may be NULL */);
 int pdh_problem_stats(pdh_ctx *ctx, int64_t *stats /* [8]: n_owned_agg, n_offdiag_items, n_vq_points,
                         n_face_side_points, n_values, dofs_per_cell, lds_bytes_diag, lds_bytes_offdiag */);
 

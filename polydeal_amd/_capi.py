@@ -76,7 +76,7 @@ def load_library():
     lib.pdh_stream.argtypes = [C.c_void_p]
     lib.pdh_stream.restype = C.c_void_p
     lib.pdh_set_profiling.argtypes = [C.c_void_p, C.c_int]
-    lib.pdh_kernel_times_ms.argtypes = [C.c_void_p, P(C.c_float)]
+    lib.pdh_kernel_times_ms.argtypes = [C.c_void_p, P(C.c_float), P(C.c_int)]
     lib.pdh_problem_stats.argtypes = [C.c_void_p, P(C.c_int64)]
     lib.pdh_check_problem.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, P(C.c_int64)]
     lib.pdh_version.restype = C.c_char_p
@@ -138,11 +138,11 @@ class Context:
         if rc != PDH_OK:
             raise PdhError(rc, self.lib.pdh_last_error(self.h).decode())
 
-    def set_problem(self, prob: Problem, row_begin=0, row_end=None):
+    def set_problem(self, prob, row_begin=0, row_end=None):
+        """prob: a Problem (NumPy-backed) or anything with a `.c` pdh_problem (e.g. handler.FlatView)."""
         row_end = prob.c.n_rows if row_end is None else row_end
         self._chk(self.lib.pdh_set_problem_local(self.h, C.byref(prob.c), row_begin, row_end))
-        rp = prob.arrays["rowptr"]
-        self.n_values = int(rp[row_end] - rp[row_begin])
+        self.n_values = self.stats()["n_values"]
 
     def assemble_device(self):
         self._chk(self.lib.pdh_assemble_device(self.h))
@@ -165,8 +165,9 @@ class Context:
 
     def kernel_times_ms(self):
         ms = (C.c_float * 2)()
-        self._chk(self.lib.pdh_kernel_times_ms(self.h, ms))
-        return [float(ms[0]), float(ms[1])]
+        n = C.c_int()
+        self._chk(self.lib.pdh_kernel_times_ms(self.h, ms, C.byref(n)))
+        return [float(ms[0]), float(ms[1])], int(n.value)
 
     def stats(self):
         st = (C.c_int64 * 8)()

@@ -1,0 +1,871 @@
+// polydeal_host.h — C++17 host-side mirror of the reference's operator surface for the SIP path.
+//
+// deal.II is not available where this builds, so this header provides just enough of the objects the
+// reference's callers touch (examples/minimal_SIP.cc, examples/poisson.cc, include/poly_utils.h:2000-2195)
+// for the path to be driven exactly like the reference drives it:
+//
+//   BackgroundGrid          ~ Triangulation<dim> built by GridGenerator::hyper_cube + refine_global /
+//                             subdivided_hyper_cube (quad/hex cells, deal.II numbering conventions)
+//   FiniteElement           ~ FE_DGQ<dim>(p) / FE_AggloDGP<dim>(p)        (include/fe_agglodgp.h:310-471)
+//   AgglomerationHandler    ~ include/agglomeration_handler.h:203-452: define_agglomerate,
+//                             distribute_agglomerated_dofs, initialize_fe_values,
+//                             create_agglomeration_sparsity_pattern, polytope accessors
+//                             (include/agglomeration_accessor.h:55-203)
+//   PolyUtilsHIP::assemble_dg_matrix(values, fe, ah, variant) ~ PolyUtils::assemble_dg_matrix
+//                             (include/poly_utils.h:2000-2195), calling the HIP kernels through the C ABI.
+//
+// The algorithms that matter for parity are restated from the reference and cite it:
+//   * master/slave bookkeeping and bounding boxes      source/agglomeration_handler.cc:44-104, 476-491
+//   * face enumeration with the global visited set     source/agglomeration_handler.cc:1253-1645
+//   * DoF numbering (masters in ascending cell order)  source/agglomeration_handler.cc:326-379, 711-725
+//   * DG sparsity with flux couplings                  source/agglomeration_handler.cc:910-1022
+//   * concatenated sub-cell quadratures                source/agglomeration_handler.cc:622-707, 1146-1165
+// This file is independent of oracle/ (which re-derives the same things in NumPy to cross-check it).
+#pragma once
+
+#include "../../../include/polydeal_hip.h"
+#include "../pdh_basis.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace polydeal_hip
+{
+constexpr int invalid_index = -1;
+
+// ---------------------------------------------------------------------------------------------------
+// 1-D Gauss-Legendre rule on [0,1]  (QGauss<1>(n))  [deal.II]
+// ---------------------------------------------------------------------------------------------------
+inline void qgauss_1d(int n, std::vector<double> &x, std::vector<double> &w)
+{
+  x.assign(n, 0.0);
+  w.assign(n, 0.0);
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int i = 0; i < n; ++i)
+    {
+      long double t = -std::cos(pi * (i + 0.75L) / (n + 0.5L));
+      long double dp = 1.0L;
+      for (int it = 0; it < 100; ++it)
+        {
+          long double p0 = 1.0L, p1 = t;
+          for (int k = 1; k < n; ++k)
+            {
+              const long double p2 = ((2 * k + 1) * t * p1 - k * p0) / (k + 1);
+              p0 = p1;
+              p1 = p2;
+            }
+          dp = n * (p0 - t * p1) / (1 - t * t);
+          const long double dt = p1 / dp;
+          t -= dt;
+          if (std::fabs((double)dt) < 1e-19)
+            break;
+        }
+      // recompute derivative at the converged root
+      {
+        long double p0 = 1.0L, p1 = t;
+        for (int k = 1; k < n; ++k)
+          {
+            const long double p2 = ((2 * k + 1) * t * p1 - k * p0) / (k + 1);
+            p0 = p1;
+            p1 = p2;
+          }
+        dp = n * (p0 - t * p1) / (1 - t * t);
+      }
+      x[i] = (double)(0.5L * (t + 1.0L));
+      w[i] = (double)(1.0L / ((1 - t * t) * dp * dp)); // = 2/((1-t^2)P'^2) / 2
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Finite elements (descriptors; the basis itself lives in pdh_basis.h / the kernels)
+// ---------------------------------------------------------------------------------------------------
+struct FiniteElement
+{
+  int dim = 2, degree = 1, basis = PDH_BASIS_DGQ;
+  int n_dofs_per_cell() const { return pdh::n_dofs_per_cell(dim, degree, basis); }
+  std::string get_name() const
+  {
+    return std::string(basis == PDH_BASIS_DGQ ? "FE_DGQ<" : "FE_AggloDGP<") + std::to_string(dim) + ">(" +
+           std::to_string(degree) + ")";
+  }
+};
+template <int dim>
+struct FE_DGQ : FiniteElement
+{
+  explicit FE_DGQ(unsigned int p)
+  {
+    this->dim = dim;
+    degree = (int)p;
+    basis = PDH_BASIS_DGQ;
+  }
+};
+template <int dim>
+struct FE_AggloDGP : FiniteElement // reference include/fe_agglodgp.h:317
+{
+  explicit FE_AggloDGP(unsigned int p)
+  {
+    this->dim = dim;
+    degree = (int)p;
+    basis = PDH_BASIS_AGGLODGP;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Background grid with deal.II conventions [deal.II]: faces 0:-x 1:+x 2:-y 3:+y 4:-z 5:+z,
+// vertex v at ((v&1),(v>>1)&1,(v>>2)&1); hyper_cube + refine_global(k) numbers active cells in Morton
+// order (child c at offset (c&1,(c>>1)&1,(c>>2)&1)); subdivided_hyper_cube numbers lexicographically.
+// ---------------------------------------------------------------------------------------------------
+class BackgroundGrid
+{
+public:
+  int dim = 2, n_per_dir = 1;
+  std::vector<std::array<int, 3>> cell_ijk;
+  std::vector<int> lut;             // ijk -> cell
+  std::vector<double> vertices;     // [cell][2^dim][dim]
+
+  static BackgroundGrid hyper_cube_refined(int dim, double lo, double hi, int n_refine)
+  {
+    return build(dim, 1 << n_refine, lo, hi, true);
+  }
+  static BackgroundGrid subdivided_hyper_cube(int dim, int n, double lo, double hi)
+  {
+    return build(dim, n, lo, hi, false);
+  }
+  int n_active_cells() const { return (int)cell_ijk.size(); }
+  int n_faces_per_cell() const { return 2 * dim; }
+  int nv() const { return 1 << dim; }
+  const double *vertex(int cell, int v) const { return &vertices[((size_t)cell * nv() + v) * dim]; }
+  int neighbor(int cell, int f) const
+  {
+    std::array<int, 3> ijk = cell_ijk[cell];
+    const int ax = f / 2;
+    ijk[ax] += (f & 1) ? 1 : -1;
+    if (ijk[ax] < 0 || ijk[ax] >= n_per_dir)
+      return invalid_index;
+    return lut[lin(ijk)];
+  }
+  static int neighbor_of_neighbor(int f) { return f ^ 1; }
+  int cell_at(int ix, int iy, int iz = 0) const { return lut[lin({ix, iy, iz})]; }
+
+  // random interior-vertex jitter (stand-in for GridTools::distort_random, exact_solutions_dgp.cc:306)
+  void distort(double factor, unsigned seed)
+  {
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    const int n = n_per_dir;
+    const double h = vertex(0, nv() - 1)[0] - vertex(0, 0)[0];
+    size_t nvert = 1;
+    for (int c = 0; c < dim; ++c)
+      nvert *= (size_t)(n + 1);
+    std::vector<double> jit(nvert * dim, 0.0);
+    for (size_t v = 0; v < nvert; ++v)
+      {
+        size_t r = v;
+        bool interior = true;
+        for (int c = 0; c < dim; ++c)
+          {
+            const int i = (int)(r % (n + 1));
+            r /= (n + 1);
+            if (i == 0 || i == n)
+              interior = false;
+          }
+        for (int c = 0; c < dim; ++c)
+          {
+            const double u = U(rng);
+            if (interior)
+              jit[v * dim + c] = u * factor * h;
+          }
+      }
+    for (int cell = 0; cell < n_active_cells(); ++cell)
+      for (int v = 0; v < nv(); ++v)
+        {
+          size_t vid = 0, mul = 1;
+          for (int c = 0; c < dim; ++c)
+            {
+              vid += mul * (size_t)(cell_ijk[cell][c] + ((v >> c) & 1));
+              mul *= (size_t)(n + 1);
+            }
+          for (int c = 0; c < dim; ++c)
+            vertices[((size_t)cell * nv() + v) * dim + c] += jit[vid * dim + c];
+        }
+  }
+
+private:
+  int lin(const std::array<int, 3> &ijk) const
+  {
+    return ijk[0] + n_per_dir * (ijk[1] + (dim == 3 ? n_per_dir * ijk[2] : 0));
+  }
+  static BackgroundGrid build(int dim, int n, double lo, double hi, bool morton)
+  {
+    if (dim != 2 && dim != 3)
+      throw std::invalid_argument("BackgroundGrid: dim must be 2 or 3");
+    BackgroundGrid g;
+    g.dim = dim;
+    g.n_per_dir = n;
+    const size_t nc = (dim == 2) ? (size_t)n * n : (size_t)n * n * n;
+    g.cell_ijk.resize(nc);
+    g.lut.assign(nc, 0);
+    int levels = 0;
+    while ((1 << levels) < n)
+      ++levels;
+    if (morton && (1 << levels) != n)
+      throw std::invalid_argument("BackgroundGrid: Morton order needs a power-of-two size");
+    for (size_t l = 0; l < nc; ++l)
+      {
+        std::array<int, 3> ijk = {(int)(l % n), (int)((l / n) % n), (int)(dim == 3 ? l / ((size_t)n * n) : 0)};
+        size_t idx = l;
+        if (morton)
+          {
+            idx = 0;
+            for (int lev = 0; lev < levels; ++lev)
+              for (int c = 0; c < dim; ++c)
+                idx |= (size_t)((ijk[c] >> lev) & 1) << (dim * lev + c);
+          }
+        g.cell_ijk[idx] = ijk;
+        g.lut[l] = (int)idx;
+      }
+    const double h = (hi - lo) / n;
+    g.vertices.resize(nc * (size_t)(1 << dim) * dim);
+    for (size_t cell = 0; cell < nc; ++cell)
+      for (int v = 0; v < (1 << dim); ++v)
+        for (int c = 0; c < dim; ++c)
+          g.vertices[(cell * (1 << dim) + v) * dim + c] = lo + (g.cell_ijk[cell][c] + ((v >> c) & 1)) * h;
+    return g;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Q1 mapping of a cell / a face: what FEValues / FEFaceValues on FE_Nothing give the reference
+// (source/agglomeration_handler.cc:224-235, 639-653, 1146-1165).
+// ---------------------------------------------------------------------------------------------------
+struct QPoints
+{
+  std::vector<double> x, n; // [npts][dim]
+  std::vector<double> w;    // JxW
+};
+
+inline void q1_map(const BackgroundGrid &g, int cell, const double *xi, double *x, double J[3][3])
+{
+  const int dim = g.dim, nv = g.nv();
+  for (int r = 0; r < dim; ++r)
+    {
+      x[r] = 0.0;
+      for (int c = 0; c < dim; ++c)
+        J[r][c] = 0.0;
+    }
+  for (int v = 0; v < nv; ++v)
+    {
+      double N = 1.0, dN[3] = {1.0, 1.0, 1.0};
+      for (int c = 0; c < dim; ++c)
+        {
+          const int b = (v >> c) & 1;
+          const double f = b ? xi[c] : 1.0 - xi[c];
+          const double df = b ? 1.0 : -1.0;
+          N *= f;
+          for (int d = 0; d < dim; ++d)
+            dN[d] *= (d == c) ? df : f;
+        }
+      const double *X = g.vertex(cell, v);
+      for (int r = 0; r < dim; ++r)
+        {
+          x[r] += N * X[r];
+          for (int c = 0; c < dim; ++c)
+            J[r][c] += dN[c] * X[r];
+        }
+    }
+}
+
+// QGauss<dim>(nq) on a cell: real points + JxW, x fastest  [deal.II]
+inline void cell_quadrature(const BackgroundGrid &g, int cell, int nq, QPoints &out)
+{
+  std::vector<double> x1, w1;
+  qgauss_1d(nq, x1, w1);
+  const int dim = g.dim;
+  const int np = (dim == 2) ? nq * nq : nq * nq * nq;
+  for (int q = 0; q < np; ++q)
+    {
+      const int i[3] = {q % nq, (q / nq) % nq, q / (nq * nq)};
+      double xi[3], x[3], J[3][3], w = 1.0;
+      for (int c = 0; c < dim; ++c)
+        {
+          xi[c] = x1[i[c]];
+          w *= w1[i[c]];
+        }
+      q1_map(g, cell, xi, x, J);
+      double det;
+      if (dim == 2)
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      else
+        det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+              J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+      for (int c = 0; c < dim; ++c)
+        out.x.push_back(x[c]);
+      out.w.push_back(w * std::fabs(det));
+    }
+}
+
+// QGauss<dim-1>(nqf) on face f of a cell: real points, JxW, outward unit normal.  Point order follows
+// QProjector::project_to_face [deal.II]: 3-D faces 0/1 -> (s,t)=(y,z), 2/3 -> (z,x), 4/5 -> (x,y), s fastest.
+inline void face_quadrature(const BackgroundGrid &g, int cell, int f, int nqf, QPoints &out)
+{
+  std::vector<double> x1, w1;
+  qgauss_1d(nqf, x1, w1);
+  const int dim = g.dim, ax = f / 2, side = f & 1;
+  const int np = (dim == 2) ? nqf : nqf * nqf;
+  int tang[2];
+  if (dim == 2)
+    tang[0] = tang[1] = 1 - ax;
+  else if (ax == 0)
+    tang[0] = 1, tang[1] = 2;
+  else if (ax == 1)
+    tang[0] = 2, tang[1] = 0;
+  else
+    tang[0] = 0, tang[1] = 1;
+  for (int q = 0; q < np; ++q)
+    {
+      double xi[3] = {0, 0, 0}, x[3], J[3][3], w;
+      xi[ax] = side;
+      if (dim == 2)
+        {
+          xi[tang[0]] = x1[q];
+          w = w1[q];
+        }
+      else
+        {
+          xi[tang[0]] = x1[q % nqf];
+          xi[tang[1]] = x1[q / nqf];
+          w = w1[q % nqf] * w1[q / nqf];
+        }
+      q1_map(g, cell, xi, x, J);
+      double nr[3] = {0, 0, 0}, area;
+      if (dim == 2)
+        {
+          const double t0 = J[0][tang[0]], t1 = J[1][tang[0]];
+          area = std::sqrt(t0 * t0 + t1 * t1);
+          nr[0] = t1;
+          nr[1] = -t0;
+        }
+      else
+        {
+          const double a[3] = {J[0][tang[0]], J[1][tang[0]], J[2][tang[0]]};
+          const double b[3] = {J[0][tang[1]], J[1][tang[1]], J[2][tang[1]]};
+          nr[0] = a[1] * b[2] - a[2] * b[1];
+          nr[1] = a[2] * b[0] - a[0] * b[2];
+          nr[2] = a[0] * b[1] - a[1] * b[0];
+          area = std::sqrt(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+        }
+      double nn = 0.0, dot = 0.0;
+      for (int c = 0; c < dim; ++c)
+        nn += nr[c] * nr[c];
+      nn = std::sqrt(nn);
+      for (int c = 0; c < dim; ++c)
+        {
+          nr[c] /= nn;
+          dot += nr[c] * J[c][ax] * (side ? 1.0 : -1.0);
+        }
+      const double sgn = dot < 0 ? -1.0 : 1.0;
+      for (int c = 0; c < dim; ++c)
+        {
+          out.x.push_back(x[c]);
+          out.n.push_back(sgn * nr[c]);
+        }
+      out.w.push_back(w * area);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SIP variants of the reference's callers (SURVEY.md 8(a), table "Variants")
+// ---------------------------------------------------------------------------------------------------
+struct SipVariant
+{
+  double penalty_constant = -1.0; // < 0: 10 (p+dim)(p+1)   (include/poly_utils.h:2018-2019)
+  int owner_rule = 0;             // 0: id() < id() (poly_utils.h:2089); 1: index() < index() (poisson.cc:841)
+  int h_rule = 0;                 // 0: C / diameter(owner); 1: C (h_f = 1); 2: C max(1/h_in, 1/h_out)
+  int boundary = 0;               // 0: Nitsche; 1: zeroed (examples/minimal_SIP.cc:230-248)
+  double reaction_c = 0.0;        // examples/diffusion_reaction.cc:495-501
+
+  static SipVariant assemble_dg_matrix() { return SipVariant(); }
+  static SipVariant poisson_example(const FiniteElement &fe) // examples/poisson.cc:476, 841, 900-901
+  {
+    SipVariant v;
+    v.penalty_constant = 10.0 * (fe.degree + 1) * (fe.degree + fe.dim);
+    v.owner_rule = 1;
+    return v;
+  }
+  static SipVariant minimal_sip_test() // test/polydeal/minimal_SIP_Poisson.cc:101, 308
+  {
+    SipVariant v;
+    v.penalty_constant = 20.0;
+    v.owner_rule = 1;
+    v.h_rule = 1;
+    return v;
+  }
+  static SipVariant minimal_sip_example() // examples/minimal_SIP.cc:230-262
+  {
+    SipVariant v;
+    v.penalty_constant = 10.0;
+    v.owner_rule = 1;
+    v.h_rule = 2;
+    v.boundary = 1;
+    return v;
+  }
+  static SipVariant diffusion_reaction(const FiniteElement &fe) // examples/diffusion_reaction.cc:366, 515, 563
+  {
+    SipVariant v;
+    v.penalty_constant = 10.0 * fe.degree * fe.degree;
+    v.reaction_c = 0.5;
+    return v;
+  }
+};
+
+// Flattened problem: owns the arrays a pdh_problem points to.
+struct FlatProblem
+{
+  pdh_problem c{};
+  std::vector<double> bbox, vq_x, vq_w, fq_x, fq_n, fq_w, fq_w_out, face_sigma;
+  std::vector<int32_t> dof_offset, face_in, face_out, colind;
+  std::vector<int64_t> vq_ptr, fq_ptr, rowptr;
+  void bind()
+  {
+    c.bbox = bbox.data();
+    c.dof_offset = dof_offset.data();
+    c.vq_ptr = vq_ptr.data();
+    c.vq_x = vq_x.data();
+    c.vq_w = vq_w.data();
+    c.face_in = face_in.data();
+    c.face_out = face_out.data();
+    c.fq_ptr = fq_ptr.data();
+    c.fq_x = fq_x.data();
+    c.fq_n = fq_n.data();
+    c.fq_w = fq_w.data();
+    c.fq_w_out = fq_w_out.empty() ? nullptr : fq_w_out.data();
+    c.face_sigma = face_sigma.data();
+    c.rowptr = rowptr.data();
+    c.colind = colind.empty() ? nullptr : colind.data();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// AgglomerationHandler
+// ---------------------------------------------------------------------------------------------------
+class AgglomerationHandler
+{
+public:
+  explicit AgglomerationHandler(const BackgroundGrid &grid)
+    : tria(&grid)
+    , master_of(grid.n_active_cells(), invalid_index)
+  {}
+
+  // source/agglomeration_handler.cc:44-104: cells[0] is the master, polytope index = call order
+  int define_agglomerate(const std::vector<int> &cells)
+  {
+    if (cells.empty())
+      throw std::invalid_argument("No cells to be agglomerated.");
+    const int master = cells[0];
+    const int poly = (int)master_cells.size();
+    master_cells.push_back(master);
+    master_of.at(master) = master;
+    std::vector<int> slaves(cells.begin() + 1, cells.end());
+    for (int s : slaves)
+      master_of.at(s) = master;
+    master2slaves[master] = slaves;
+    master2polygon[master] = poly;
+    // create_bounding_box (:476-491): box of all vertices of all cells
+    const int dim = tria->dim;
+    std::array<double, 6> bb;
+    for (int c = 0; c < dim; ++c)
+      {
+        bb[c] = 1e300;
+        bb[3 + c] = -1e300;
+      }
+    for (int cell : cells)
+      for (int v = 0; v < tria->nv(); ++v)
+        for (int c = 0; c < dim; ++c)
+          {
+            bb[c] = std::min(bb[c], tria->vertex(cell, v)[c]);
+            bb[3 + c] = std::max(bb[3 + c], tria->vertex(cell, v)[c]);
+          }
+    bboxes.push_back(bb);
+    connectivity_ready = false;
+    return poly;
+  }
+
+  unsigned int n_agglomerates() const { return (unsigned int)master_cells.size(); }
+  const BackgroundGrid &get_triangulation() const { return *tria; }
+  const FiniteElement &get_fe() const { return fe; }
+  unsigned int n_dofs_per_cell() const { return (unsigned int)fe.n_dofs_per_cell(); }
+  unsigned int n_dofs() const { return n_dofs_; }
+  int master_index(int P) const { return master_cells.at(P); }
+  int cell_to_polytope_index(int cell) const { return master2polygon.at(master_of.at(cell)); }
+  bool is_master_cell(int cell) const { return master_of.at(cell) == cell; }
+  // value stored in master_slave_relationships (include/agglomeration_handler.h:688)
+  int master_slave_value(int cell) const { return is_master_cell(cell) ? -1 : master_of.at(cell); }
+  // slaves in insertion order, then the master (include/agglomeration_handler.h:1022-1032)
+  std::vector<int> get_agglomerate(int P) const
+  {
+    const int m = master_cells.at(P);
+    std::vector<int> a = master2slaves.at(m);
+    a.push_back(m);
+    return a;
+  }
+  const std::array<double, 6> &bbox(int P) const { return bboxes.at(P); }
+
+  // source/agglomeration_handler.cc:210-236: number of Gauss points per direction
+  void initialize_fe_values(int n_q_points_1d, int n_face_q_points_1d)
+  {
+    nq = n_q_points_1d;
+    nqf = n_face_q_points_1d;
+  }
+
+  // source/agglomeration_handler.cc:326-379 (+711-725): masters get the FE, slaves FE_Nothing; dofs are
+  // numbered consecutively over master cells in ascending active-cell order [deal.II]
+  void distribute_agglomerated_dofs(const FiniteElement &fe_space)
+  {
+    for (int m : master_of)
+      if (m == invalid_index)
+        throw std::logic_error("every cell must belong to an agglomerate before distributing dofs");
+    fe = fe_space;
+    if (fe.dim != tria->dim)
+      throw std::invalid_argument("finite element and triangulation dimensions differ");
+    const int n = fe.n_dofs_per_cell();
+    std::vector<int> order(master_cells.size());
+    for (size_t i = 0; i < order.size(); ++i)
+      order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return master_cells[a] < master_cells[b]; });
+    dof_offset.assign(master_cells.size(), 0);
+    for (size_t r = 0; r < order.size(); ++r)
+      dof_offset[order[r]] = (int)r * n;
+    n_dofs_ = (unsigned int)(n * master_cells.size());
+    setup_connectivity_of_agglomeration();
+  }
+
+  // ---- accessor-level queries (include/agglomeration_accessor.h) ----------------------------------
+  unsigned int n_faces(int P) const { return (unsigned int)face_nbr.at(P).size(); }                 // :324-331
+  bool at_boundary(int P, unsigned f) const { return face_nbr.at(P).at(f) == invalid_index; }       // :736-772
+  int neighbor(int P, unsigned f) const { return face_nbr.at(P).at(f); }                           // :335-422
+  int neighbor_of_agglomerated_neighbor(int P, unsigned f) const                                    // :426-481
+  {
+    if (at_boundary(P, f))
+      return invalid_index;
+    const int Q = neighbor(P, f);
+    for (unsigned fo = 0; fo < n_faces(Q); ++fo)
+      if (!at_boundary(Q, fo) && neighbor(Q, fo) == P)
+        return (int)fo;
+    return invalid_index;
+  }
+  double diameter(int P) const // :582-601: diagonal of the bounding box
+  {
+    double s = 0;
+    for (int c = 0; c < tria->dim; ++c)
+      s += (bboxes[P][3 + c] - bboxes[P][c]) * (bboxes[P][3 + c] - bboxes[P][c]);
+    return std::sqrt(s);
+  }
+  double volume(int P) const // :617-632
+  {
+    double v = 1;
+    for (int c = 0; c < tria->dim; ++c)
+      v *= bboxes[P][3 + c] - bboxes[P][c];
+    return v;
+  }
+  void get_dof_indices(int P, std::vector<unsigned int> &idx) const // :534-558
+  {
+    idx.resize(n_dofs_per_cell());
+    for (unsigned i = 0; i < idx.size(); ++i)
+      idx[i] = (unsigned)dof_offset.at(P) + i;
+  }
+  int dof_offset_of(int P) const { return dof_offset.at(P); }
+  // polytope_cache.interface[{id_in,id_out}] (include/agglomeration_handler.h:355-356); Q == P: boundary
+  const std::vector<std::pair<int, int>> &get_interface(int P, int Q) const { return interface.at(key(P, Q)); }
+
+  // ---- source/agglomeration_handler.cc:910-1022 -----------------------------------------------------
+  // CSR of the DG pattern: own block + one block per valid neighbour.  diag_first = deal.II SparsityPattern
+  // (diagonal entry first, then ascending) [deal.II]; otherwise plain ascending (DynamicSparsityPattern/Epetra).
+  void create_agglomeration_sparsity_pattern(std::vector<int64_t> &rowptr, std::vector<int32_t> *colind,
+                                             bool diag_first = true) const
+  {
+    const int n = fe.n_dofs_per_cell();
+    rowptr.assign((size_t)n_dofs_ + 1, 0);
+    std::vector<std::vector<int>> blocks(master_cells.size());
+    for (size_t P = 0; P < master_cells.size(); ++P)
+      {
+        auto &b = blocks[P];
+        b.push_back(dof_offset[P]);
+        for (int Q : face_nbr[P])
+          if (Q != invalid_index)
+            b.push_back(dof_offset[Q]);
+        std::sort(b.begin(), b.end());
+        for (int i = 0; i < n; ++i)
+          rowptr[(size_t)dof_offset[P] + i + 1] = (int64_t)b.size() * n;
+      }
+    for (size_t r = 0; r < n_dofs_; ++r)
+      rowptr[r + 1] += rowptr[r];
+    if (!colind)
+      return;
+    colind->resize((size_t)rowptr[n_dofs_]);
+    for (size_t P = 0; P < master_cells.size(); ++P)
+      for (int i = 0; i < n; ++i)
+        {
+          const int r = dof_offset[P] + i;
+          int32_t *out = colind->data() + rowptr[r];
+          if (diag_first)
+            *out++ = r;
+          for (int off : blocks[P])
+            for (int j = 0; j < n; ++j)
+              if (!(diag_first && off + j == r))
+                *out++ = off + j;
+        }
+  }
+
+  // ---- quadrature views used by tests ----------------------------------------------------------------
+  // source/agglomeration_handler.cc:622-707: concatenation over get_agglomerate() order
+  void agglomerated_quadrature(int P, QPoints &out) const
+  {
+    for (int cell : get_agglomerate(P))
+      cell_quadrature(*tria, cell, nq, out);
+  }
+  // reinit_master, source/agglomeration_handler.cc:1129-1165
+  void face_quadrature_of(int P, unsigned f, QPoints &out) const
+  {
+    const int Q = at_boundary(P, f) ? P : neighbor(P, f);
+    for (const auto &cf : get_interface(P, Q))
+      face_quadrature(*tria, cf.first, cf.second, nqf, out);
+  }
+
+  // ---- flattening for the HIP path (what the deal.II adapter does by walking the public API) ----------
+  bool owns(const SipVariant &v, int P, int Q) const
+  {
+    return v.owner_rule == 1 ? (P < Q) : (master_cells[P] < master_cells[Q]); // index() vs id() (CellId order)
+  }
+  double sigma(const SipVariant &v, int P, int Q) const
+  {
+    const double C = v.penalty_constant >= 0 ? v.penalty_constant : 10.0 * (fe.degree + fe.dim) * (fe.degree + 1);
+    if (v.h_rule == 1)
+      return C;
+    if (v.h_rule == 2 && Q != invalid_index)
+      return C * std::max(1.0 / diameter(P), 1.0 / diameter(Q));
+    return C / std::fabs(diameter(P));
+  }
+
+  void flatten(const SipVariant &var, FlatProblem &F, bool diag_first = true, bool with_colind = false) const
+  {
+    if (!connectivity_ready)
+      throw std::logic_error("distribute_agglomerated_dofs must be called first");
+    if (nq <= 0 || nqf <= 0)
+      throw std::logic_error("initialize_fe_values must be called first");
+    const int dim = tria->dim, nA = (int)master_cells.size();
+    F = FlatProblem();
+    F.c.dim = dim;
+    F.c.degree = fe.degree;
+    F.c.basis = fe.basis;
+    F.c.n_agg = nA;
+    F.c.n_rows = (int32_t)n_dofs_;
+    F.c.diag_first = diag_first ? 1 : 0;
+    F.c.reaction_c = var.reaction_c;
+    F.bbox.resize((size_t)nA * 2 * dim);
+    F.dof_offset.assign(dof_offset.begin(), dof_offset.end());
+    F.vq_ptr.assign(1, 0);
+    QPoints vol;
+    for (int P = 0; P < nA; ++P)
+      {
+        for (int c = 0; c < dim; ++c)
+          {
+            F.bbox[(size_t)P * 2 * dim + c] = bboxes[P][c];
+            F.bbox[(size_t)P * 2 * dim + dim + c] = bboxes[P][3 + c];
+          }
+        agglomerated_quadrature(P, vol);
+        F.vq_ptr.push_back((int64_t)vol.w.size());
+      }
+    const size_t nqt = vol.w.size();
+    F.vq_w = std::move(vol.w);
+    F.vq_x.resize(nqt * dim);
+    for (size_t q = 0; q < nqt; ++q)
+      for (int c = 0; c < dim; ++c)
+        F.vq_x[c * nqt + q] = vol.x[q * dim + c];
+    vol = QPoints();
+
+    QPoints fin, fout;
+    F.fq_ptr.assign(1, 0);
+    for (int P = 0; P < nA; ++P)
+      for (unsigned f = 0; f < n_faces(P); ++f)
+        {
+          if (at_boundary(P, f))
+            {
+              if (var.boundary == 1)
+                continue;
+              const size_t before = fin.w.size();
+              face_quadrature_of(P, f, fin);
+              fout.w.insert(fout.w.end(), fin.w.begin() + before, fin.w.end()); // unused on the boundary
+              F.face_in.push_back(P);
+              F.face_out.push_back(-1);
+              F.face_sigma.push_back(sigma(var, P, invalid_index));
+            }
+          else
+            {
+              const int Q = neighbor(P, f);
+              if (!owns(var, P, Q))
+                continue;
+              const int nofn = neighbor_of_agglomerated_neighbor(P, f);
+              face_quadrature_of(P, f, fin);
+              QPoints tmp;
+              face_quadrature_of(Q, (unsigned)nofn, tmp); // side 1: only its JxW is used (poly_utils.h:1906-1922)
+              if (fout.w.size() + tmp.w.size() != fin.w.size())
+                throw std::logic_error("interface lists of the two sides differ in length");
+              fout.w.insert(fout.w.end(), tmp.w.begin(), tmp.w.end());
+              F.face_in.push_back(P);
+              F.face_out.push_back(Q);
+              F.face_sigma.push_back(sigma(var, P, Q));
+            }
+          F.fq_ptr.push_back((int64_t)fin.w.size());
+        }
+    F.c.n_faces = (int32_t)F.face_in.size();
+    const size_t nft = fin.w.size();
+    F.fq_w = std::move(fin.w);
+    F.fq_w_out = std::move(fout.w);
+    F.fq_x.resize(nft * dim);
+    F.fq_n.resize(nft * dim);
+    for (size_t q = 0; q < nft; ++q)
+      for (int c = 0; c < dim; ++c)
+        {
+          F.fq_x[c * nft + q] = fin.x[q * dim + c];
+          F.fq_n[c * nft + q] = fin.n[q * dim + c];
+        }
+    create_agglomeration_sparsity_pattern(F.rowptr, with_colind ? &F.colind : nullptr, diag_first);
+    F.bind();
+  }
+
+private:
+  static uint64_t key(int P, int Q) { return ((uint64_t)(uint32_t)P << 32) | (uint32_t)Q; }
+
+  // source/agglomeration_handler.cc:495-527 + 1253-1645 (serial branches): see SURVEY.md Appendix A.1
+  void setup_connectivity_of_agglomeration()
+  {
+    const BackgroundGrid &g = *tria;
+    const int nP = (int)master_cells.size(), nf = g.n_faces_per_cell();
+    face_nbr.assign(nP, {});
+    interface.clear();
+    std::vector<uint8_t> visited((size_t)g.n_active_cells() * nf, 0); // GLOBAL visited_cell_and_faces
+    std::vector<int> seen_stamp(nP + 1, -1);                         // per-master visited_polygonal_neighbors
+    for (int P = 0; P < nP; ++P)
+      {
+        for (int cell : get_agglomerate(P))
+          for (int f = 0; f < nf; ++f)
+            {
+              const int nb = g.neighbor(cell, f);
+              if (nb != invalid_index)
+                {
+                  if (master_of[nb] == master_of[cell])
+                    continue; // are_cells_agglomerated (:1300-1301)
+                  const int Q = master2polygon.at(master_of[nb]);
+                  const int nof = g.neighbor_of_neighbor(f);
+                  if (seen_stamp[Q] != P)
+                    { // first contact with polytope Q: new polytopal face (:1346-1367 / 1412-1433)
+                      face_nbr[P].push_back(Q);
+                      seen_stamp[Q] = P;
+                    }
+                  if (!visited[(size_t)cell * nf + f])
+                    {
+                      interface[key(P, Q)].emplace_back(cell, f); // (:1370-1382)
+                      visited[(size_t)cell * nf + f] = 1;
+                    }
+                  if (!visited[(size_t)nb * nf + nof])
+                    {
+                      interface[key(Q, P)].emplace_back(nb, nof); // (:1385-1397)
+                      visited[(size_t)nb * nf + nof] = 1;
+                    }
+                }
+              else
+                { // all domain-boundary sub-faces form ONE polytopal face (:1575-1613)
+                  if (seen_stamp[nP] != P)
+                    {
+                      face_nbr[P].push_back(invalid_index);
+                      seen_stamp[nP] = P;
+                    }
+                  if (!visited[(size_t)cell * nf + f])
+                    {
+                      interface[key(P, P)].emplace_back(cell, f);
+                      visited[(size_t)cell * nf + f] = 1;
+                    }
+                }
+            }
+      }
+    connectivity_ready = true;
+  }
+
+  const BackgroundGrid *tria;
+  FiniteElement fe;
+  std::vector<int> master_of;     // master cell of every cell
+  std::vector<int> master_cells;  // master_cells_container (polytope order)
+  std::unordered_map<int, std::vector<int>> master2slaves;
+  std::unordered_map<int, int> master2polygon;
+  std::vector<std::array<double, 6>> bboxes;
+  std::vector<int> dof_offset;
+  unsigned int n_dofs_ = 0;
+  std::vector<std::vector<int>> face_nbr; // per polytope: neighbour polytope per local face, -1 = boundary
+  std::unordered_map<uint64_t, std::vector<std::pair<int, int>>> interface;
+  int nq = 0, nqf = 0;
+  bool connectivity_ready = false;
+};
+
+// Block agglomeration of a structured grid: b^dim cells per polytope, cells in mesh order inside a block
+// (master = lowest index, as PolyUtils::collect_cells_for_agglomeration yields: include/poly_utils.h:532-538),
+// blocks enumerated lexicographically.  Stand-in for METIS / R-tree levels on structured grids
+// (on which the reference's R-tree levels are exactly such blocks: test/polydeal/rtree_mesh.output).
+inline void define_block_agglomerates(AgglomerationHandler &ah, int b)
+{
+  const BackgroundGrid &g = ah.get_triangulation();
+  const int n = g.n_per_dir, dim = g.dim;
+  if (b <= 0 || n % b)
+    throw std::invalid_argument("block size must divide the number of cells per direction");
+  const int nb = n / b;
+  const int nblocks = (dim == 2) ? nb * nb : nb * nb * nb;
+  const int ncb = (dim == 2) ? b * b : b * b * b;
+  std::vector<int> cells(ncb);
+  for (int B = 0; B < nblocks; ++B)
+    {
+      const int bi[3] = {B % nb, (B / nb) % nb, B / (nb * nb)};
+      for (int l = 0; l < ncb; ++l)
+        {
+          const int o[3] = {l % b, (l / b) % b, l / (b * b)};
+          cells[l] = g.cell_at(bi[0] * b + o[0], bi[1] * b + o[1], dim == 3 ? bi[2] * b + o[2] : 0);
+        }
+      std::sort(cells.begin(), cells.end());
+      ah.define_agglomerate(cells);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Drop-in for PolyUtils::assemble_dg_matrix (include/poly_utils.h:2000-2195): fills `values` (CSR value
+// array of the pattern create_agglomeration_sparsity_pattern produces) on the GPU.  Throws on error, like
+// the reference's AssertThrow; never falls back to a CPU path.
+// ---------------------------------------------------------------------------------------------------
+namespace PolyUtilsHIP
+{
+inline void assemble_dg_matrix(std::vector<double> &values, const FiniteElement &fe_dg, const AgglomerationHandler &ah,
+                               const SipVariant &variant = SipVariant::assemble_dg_matrix(), bool diag_first = true,
+                               int device = 0)
+{
+  if (fe_dg.basis != ah.get_fe().basis || fe_dg.degree != ah.get_fe().degree)
+    throw std::invalid_argument("FE passed to assemble_dg_matrix differs from the handler's");
+  FlatProblem F;
+  ah.flatten(variant, F, diag_first, false);
+  pdh_ctx *ctx = nullptr;
+  if (pdh_create(&ctx, device) != PDH_OK)
+    throw std::runtime_error(std::string("pdh_create: ") + pdh_last_error(nullptr));
+  values.assign((size_t)F.rowptr.back(), 0.0);
+  const int rc = pdh_assemble_sip(ctx, &F.c, values.data());
+  const std::string msg = rc == PDH_OK ? "" : pdh_last_error(ctx);
+  pdh_destroy(ctx);
+  if (rc != PDH_OK)
+    throw std::runtime_error("pdh_assemble_sip: " + msg);
+}
+} // namespace PolyUtilsHIP
+} // namespace polydeal_hip

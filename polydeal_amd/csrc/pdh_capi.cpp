@@ -42,9 +42,19 @@ struct pdh_ctx
   size_t lds_diag = 0, lds_off = 0;
   int64_t n_values = 0, n_vq = 0, n_ap = 0;
   bool profiling = false;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-  float last_ms[PDH_N_KERNELS] = {0.f, 0.f};
-  bool timed = false;
+  std::vector<hipEvent_t> events; // 3 per profiled launch: before k_diag, between, after k_offdiag
+  size_t ev_used = 0;
+  hipEvent_t next_event()
+  {
+    if (ev_used == events.size())
+      {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess)
+          return nullptr;
+        events.push_back(e);
+      }
+    return events[ev_used++];
+  }
 };
 
 static thread_local std::string g_err_noctx;
@@ -113,8 +123,6 @@ extern "C" int pdh_create(pdh_ctx **out, int device_id)
       delete ctx;
       return fail(nullptr, PDH_EDEVICE, "pdh_create: hipStreamCreate failed");
     }
-  for (auto &ev : ctx->ev)
-    (void)hipEventCreate(&ev);
   *out = ctx;
   return PDH_OK;
 }
@@ -126,7 +134,7 @@ extern "C" void pdh_destroy(pdh_ctx *ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   free_problem(ctx);
-  for (auto &ev : ctx->ev)
+  for (auto &ev : ctx->events)
     if (ev)
       (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(ctx->stream);
@@ -450,7 +458,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   ctx->lds_diag = pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
   ctx->lds_off = pdh::lds_bytes_offdiag(p->dim, K.n1d, K.NT);
   ctx->has_problem = true;
-  ctx->timed = false;
+  ctx->ev_used = 0;
   return PDH_OK;
 }
 
@@ -469,17 +477,22 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
     return fail(ctx, PDH_ESTATE, "pdh_assemble_device called before pdh_set_problem");
   PDH_HIP(ctx, hipSetDevice(ctx->device));
   pdh_launch_fn fn = g_launch[ctx->dev.dim - 2][ctx->NT - 1];
-  if (ctx->profiling)
-    PDH_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  PDH_HIP(ctx, fn(ctx->LB, 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
-  if (ctx->profiling)
-    PDH_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  PDH_HIP(ctx, fn(ctx->LB, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   if (ctx->profiling)
     {
-      PDH_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-      ctx->timed = true;
+      e0 = ctx->next_event();
+      e1 = ctx->next_event();
+      e2 = ctx->next_event();
+      if (!e0 || !e1 || !e2)
+        return fail(ctx, PDH_EDEVICE, "hipEventCreate failed");
+      PDH_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
+  PDH_HIP(ctx, fn(ctx->LB, 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
+  if (ctx->profiling)
+    PDH_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  PDH_HIP(ctx, fn(ctx->LB, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
+  if (ctx->profiling)
+    PDH_HIP(ctx, hipEventRecord(e2, ctx->stream));
   return PDH_OK;
 }
 
@@ -536,20 +549,34 @@ extern "C" int pdh_set_profiling(pdh_ctx *ctx, int enabled)
 {
   if (!ctx)
     return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->profiling = enabled != 0;
-  ctx->timed = false;
+  ctx->ev_used = 0;
   return PDH_OK;
 }
 
-extern "C" int pdh_kernel_times_ms(pdh_ctx *ctx, float *ms)
+extern "C" int pdh_kernel_times_ms(pdh_ctx *ctx, float *ms, int *n_launches)
 {
   if (!ctx || !ms)
     return fail(ctx, PDH_EINVAL, "ctx or ms is NULL");
-  if (!ctx->timed)
+  const size_t nl = ctx->ev_used / 3;
+  if (nl == 0)
     return fail(ctx, PDH_ESTATE, "no profiled launch recorded (pdh_set_profiling(1) then pdh_assemble_device)");
-  PDH_HIP(ctx, hipEventSynchronize(ctx->ev[2]));
-  PDH_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[1]));
-  PDH_HIP(ctx, hipEventElapsedTime(&ms[1], ctx->ev[1], ctx->ev[2]));
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double sum[PDH_N_KERNELS] = {0.0, 0.0};
+  for (size_t l = 0; l < nl; ++l)
+    for (int k = 0; k < PDH_N_KERNELS; ++k)
+      {
+        float t = 0.f;
+        PDH_HIP(ctx, hipEventElapsedTime(&t, ctx->events[3 * l + k], ctx->events[3 * l + k + 1]));
+        sum[k] += t;
+      }
+  for (int k = 0; k < PDH_N_KERNELS; ++k)
+    ms[k] = (float)(sum[k] / (double)nl);
+  if (n_launches)
+    *n_launches = (int)nl;
   return PDH_OK;
 }
 

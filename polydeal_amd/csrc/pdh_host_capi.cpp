@@ -1,0 +1,285 @@
+// pdh_host_capi.cpp — C entry points onto the C++ host mirror (host/polydeal_host.h) so that Python
+// (bench.py, tests, the polydeal_amd package) can drive it.  Handle based; errors are returned as
+// negative codes with the message available from pdhh_last_error().  Nothing here needs a GPU except
+// pdhh_assemble_dg_matrix, which goes through the C ABI of polydeal_hip.h.
+#include "host/polydeal_host.h"
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+using namespace polydeal_hip;
+
+namespace
+{
+thread_local std::string g_host_err;
+struct GridH
+{
+  BackgroundGrid g;
+};
+struct HandlerH
+{
+  explicit HandlerH(const BackgroundGrid &g)
+    : ah(g)
+  {}
+  AgglomerationHandler ah;
+  FlatProblem flat;
+};
+template <class F>
+int guarded(F &&f)
+{
+  try
+    {
+      return f();
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return -1;
+    }
+}
+} // namespace
+
+extern "C" {
+const char *pdhh_last_error(void) { return g_host_err.c_str(); }
+
+void *pdhh_grid_create(int dim, int n_per_dir, int morton, double lo, double hi)
+{
+  try
+    {
+      auto *h = new GridH;
+      if (morton)
+        {
+          int lev = 0;
+          while ((1 << lev) < n_per_dir)
+            ++lev;
+          if ((1 << lev) != n_per_dir)
+            throw std::invalid_argument("Morton grids need a power-of-two number of cells per direction");
+          h->g = BackgroundGrid::hyper_cube_refined(dim, lo, hi, lev);
+        }
+      else
+        h->g = BackgroundGrid::subdivided_hyper_cube(dim, n_per_dir, lo, hi);
+      return h;
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return nullptr;
+    }
+}
+void pdhh_grid_destroy(void *g) { delete static_cast<GridH *>(g); }
+int pdhh_grid_n_cells(void *g) { return static_cast<GridH *>(g)->g.n_active_cells(); }
+int pdhh_grid_distort(void *g, double factor, unsigned seed)
+{
+  return guarded([&] {
+    static_cast<GridH *>(g)->g.distort(factor, seed);
+    return 0;
+  });
+}
+int pdhh_grid_vertices(void *g, int cell, double *out /*[2^dim][dim]*/)
+{
+  return guarded([&] {
+    const BackgroundGrid &G = static_cast<GridH *>(g)->g;
+    std::memcpy(out, G.vertex(cell, 0), sizeof(double) * G.nv() * G.dim);
+    return 0;
+  });
+}
+
+void *pdhh_handler_create(void *g)
+{
+  return new HandlerH(static_cast<GridH *>(g)->g);
+}
+void pdhh_handler_destroy(void *h) { delete static_cast<HandlerH *>(h); }
+#define AH (static_cast<HandlerH *>(h)->ah)
+int pdhh_define_agglomerate(void *h, const int32_t *cells, int n)
+{
+  return guarded([&] { return AH.define_agglomerate(std::vector<int>(cells, cells + n)); });
+}
+int pdhh_define_block_agglomerates(void *h, int b)
+{
+  return guarded([&] {
+    define_block_agglomerates(AH, b);
+    return 0;
+  });
+}
+int pdhh_initialize_fe_values(void *h, int nq, int nqf)
+{
+  return guarded([&] {
+    AH.initialize_fe_values(nq, nqf);
+    return 0;
+  });
+}
+int pdhh_distribute_agglomerated_dofs(void *h, int basis, int degree)
+{
+  return guarded([&] {
+    FiniteElement fe;
+    fe.dim = AH.get_triangulation().dim;
+    fe.degree = degree;
+    fe.basis = basis;
+    AH.distribute_agglomerated_dofs(fe);
+    return 0;
+  });
+}
+int pdhh_n_agglomerates(void *h) { return (int)AH.n_agglomerates(); }
+int pdhh_n_dofs(void *h) { return (int)AH.n_dofs(); }
+int pdhh_n_dofs_per_cell(void *h) { return (int)AH.n_dofs_per_cell(); }
+int pdhh_master_index(void *h, int P)
+{
+  return guarded([&] { return AH.master_index(P); });
+}
+int pdhh_master_slave_value(void *h, int cell)
+{
+  return guarded([&] { return AH.master_slave_value(cell); });
+}
+int pdhh_n_faces(void *h, int P)
+{
+  return guarded([&] { return (int)AH.n_faces(P); });
+}
+int pdhh_at_boundary(void *h, int P, int f)
+{
+  return guarded([&] { return AH.at_boundary(P, (unsigned)f) ? 1 : 0; });
+}
+int pdhh_neighbor(void *h, int P, int f)
+{
+  try
+    {
+      return AH.neighbor(P, (unsigned)f);
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return -2;
+    }
+}
+int pdhh_neighbor_of_agglomerated_neighbor(void *h, int P, int f)
+{
+  try
+    {
+      return AH.neighbor_of_agglomerated_neighbor(P, (unsigned)f);
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return -2;
+    }
+}
+int pdhh_interface(void *h, int P, int Q, int32_t *cells, int32_t *faces, int cap)
+{
+  return guarded([&] {
+    const auto &v = AH.get_interface(P, Q);
+    for (int i = 0; i < (int)v.size() && i < cap; ++i)
+      {
+        cells[i] = v[i].first;
+        faces[i] = v[i].second;
+      }
+    return (int)v.size();
+  });
+}
+int pdhh_bbox(void *h, int P, double *lo_hi /*[2][dim]*/)
+{
+  return guarded([&] {
+    const int dim = AH.get_triangulation().dim;
+    for (int c = 0; c < dim; ++c)
+      {
+        lo_hi[c] = AH.bbox(P)[c];
+        lo_hi[dim + c] = AH.bbox(P)[3 + c];
+      }
+    return 0;
+  });
+}
+double pdhh_diameter(void *h, int P) { return AH.diameter(P); }
+int pdhh_dof_offset(void *h, int P)
+{
+  return guarded([&] { return AH.dof_offset_of(P); });
+}
+double pdhh_volume_jxw_sum(void *h, int P)
+{
+  QPoints q;
+  AH.agglomerated_quadrature(P, q);
+  double s = 0;
+  for (double w : q.w)
+    s += w;
+  return s;
+}
+double pdhh_face_jxw_sum(void *h, int P, int f)
+{
+  QPoints q;
+  AH.face_quadrature_of(P, (unsigned)f, q);
+  double s = 0;
+  for (double w : q.w)
+    s += w;
+  return s;
+}
+// Sparsity: first call with colind == NULL to get nnz (rowptr must have n_dofs+1 entries).
+int64_t pdhh_sparsity(void *h, int diag_first, int64_t *rowptr, int32_t *colind)
+{
+  try
+    {
+      std::vector<int64_t> rp;
+      std::vector<int32_t> ci;
+      AH.create_agglomeration_sparsity_pattern(rp, colind ? &ci : nullptr, diag_first != 0);
+      std::memcpy(rowptr, rp.data(), rp.size() * sizeof(int64_t));
+      if (colind)
+        std::memcpy(colind, ci.data(), ci.size() * sizeof(int32_t));
+      return rp.back();
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return -1;
+    }
+}
+
+// Flatten into a pdh_problem owned by the handle (valid until the next flatten / destroy).
+const pdh_problem *pdhh_flatten(void *h, double penalty_constant, int owner_rule, int h_rule, int boundary,
+                                double reaction_c, int diag_first, int with_colind)
+{
+  try
+    {
+      SipVariant v;
+      v.penalty_constant = penalty_constant;
+      v.owner_rule = owner_rule;
+      v.h_rule = h_rule;
+      v.boundary = boundary;
+      v.reaction_c = reaction_c;
+      HandlerH *H = static_cast<HandlerH *>(h);
+      H->ah.flatten(v, H->flat, diag_first != 0, with_colind != 0);
+      return &H->flat.c;
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return nullptr;
+    }
+}
+int64_t pdhh_flat_sizes(void *h, int64_t *out /*[4]: Nq_tot, Nqf_tot, nnz, n_faces*/)
+{
+  HandlerH *H = static_cast<HandlerH *>(h);
+  out[0] = (int64_t)H->flat.vq_w.size();
+  out[1] = (int64_t)H->flat.fq_w.size();
+  out[2] = H->flat.rowptr.empty() ? 0 : H->flat.rowptr.back();
+  out[3] = (int64_t)H->flat.face_in.size();
+  return 0;
+}
+
+// PolyUtilsHIP::assemble_dg_matrix through C: values must hold nnz doubles.
+int pdhh_assemble_dg_matrix(void *h, double penalty_constant, int owner_rule, int h_rule, int boundary,
+                            double reaction_c, int diag_first, int device, double *values, int64_t n_values)
+{
+  return guarded([&] {
+    SipVariant v;
+    v.penalty_constant = penalty_constant;
+    v.owner_rule = owner_rule;
+    v.h_rule = h_rule;
+    v.boundary = boundary;
+    v.reaction_c = reaction_c;
+    std::vector<double> vals;
+    PolyUtilsHIP::assemble_dg_matrix(vals, AH.get_fe(), AH, v, diag_first != 0, device);
+    if ((int64_t)vals.size() != n_values)
+      throw std::invalid_argument("values buffer has the wrong length");
+    std::memcpy(values, vals.data(), vals.size() * sizeof(double));
+    return 0;
+  });
+}
+#undef AH
+}

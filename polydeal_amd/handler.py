@@ -1,0 +1,336 @@
+"""Python face of the C++ host mirror (polydeal_amd/csrc/host/polydeal_host.h) — same names as the
+reference's operator surface for this path: AgglomerationHandler, FE_DGQ, FE_AggloDGP,
+assemble_dg_matrix (reference include/agglomeration_handler.h:203-452, include/fe_agglodgp.h:317,
+include/poly_utils.h:2000-2195).  All logic lives in C++; this file only marshals."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _capi
+from ._capi import PDH_BASIS_AGGLODGP, PDH_BASIS_DGQ, Context, PdhError, pdh_problem
+
+_ready = False
+
+
+def _lib():
+    global _ready
+    lib = _capi.load_library()
+    if not _ready:
+        lib.pdhh_last_error.restype = C.c_char_p
+        lib.pdhh_grid_create.restype = C.c_void_p
+        lib.pdhh_grid_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+        lib.pdhh_grid_destroy.argtypes = [C.c_void_p]
+        lib.pdhh_grid_destroy.restype = None
+        lib.pdhh_grid_n_cells.argtypes = [C.c_void_p]
+        lib.pdhh_grid_distort.argtypes = [C.c_void_p, C.c_double, C.c_uint]
+        lib.pdhh_grid_vertices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.pdhh_handler_create.restype = C.c_void_p
+        lib.pdhh_handler_create.argtypes = [C.c_void_p]
+        lib.pdhh_handler_destroy.argtypes = [C.c_void_p]
+        lib.pdhh_handler_destroy.restype = None
+        lib.pdhh_define_agglomerate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.pdhh_define_block_agglomerates.argtypes = [C.c_void_p, C.c_int]
+        lib.pdhh_initialize_fe_values.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.pdhh_distribute_agglomerated_dofs.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        for name in ("pdhh_n_agglomerates", "pdhh_n_dofs", "pdhh_n_dofs_per_cell"):
+            getattr(lib, name).argtypes = [C.c_void_p]
+        for name in ("pdhh_master_index", "pdhh_master_slave_value", "pdhh_n_faces", "pdhh_dof_offset"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_int]
+        for name in ("pdhh_at_boundary", "pdhh_neighbor", "pdhh_neighbor_of_agglomerated_neighbor"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.pdhh_interface.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        lib.pdhh_bbox.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.pdhh_diameter.argtypes = [C.c_void_p, C.c_int]
+        lib.pdhh_diameter.restype = C.c_double
+        lib.pdhh_volume_jxw_sum.argtypes = [C.c_void_p, C.c_int]
+        lib.pdhh_volume_jxw_sum.restype = C.c_double
+        lib.pdhh_face_jxw_sum.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.pdhh_face_jxw_sum.restype = C.c_double
+        lib.pdhh_sparsity.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lib.pdhh_sparsity.restype = C.c_int64
+        lib.pdhh_flatten.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+        lib.pdhh_flatten.restype = C.POINTER(pdh_problem)
+        lib.pdhh_flat_sizes.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pdhh_flat_sizes.restype = C.c_int64
+        lib.pdhh_assemble_dg_matrix.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        _ready = True
+    return lib
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _raise():
+    raise HostError(_lib().pdhh_last_error().decode())
+
+
+@dataclass(frozen=True)
+class FiniteElement:
+    dim: int
+    degree: int
+    basis: int
+
+    @property
+    def n_dofs_per_cell(self):
+        import math
+        if self.basis == PDH_BASIS_DGQ:
+            return (self.degree + 1) ** self.dim
+        return math.comb(self.degree + self.dim, self.dim)
+
+
+def FE_DGQ(dim, degree):
+    return FiniteElement(dim, degree, PDH_BASIS_DGQ)
+
+
+def FE_AggloDGP(dim, degree):
+    return FiniteElement(dim, degree, PDH_BASIS_AGGLODGP)
+
+
+@dataclass
+class SipVariant:
+    """Scalars that differ between the reference's callers (SURVEY.md 8(a) 'Variants')."""
+    penalty_constant: float = -1.0  # <0: 10 (p+dim)(p+1)   poly_utils.h:2018-2019
+    owner_rule: int = 0  # 0: id()<id() (poly_utils.h:2089), 1: index()<index() (poisson.cc:841)
+    h_rule: int = 0  # 0: C/diameter(owner), 1: C (h_f=1), 2: C max(1/h_in,1/h_out) (minimal_SIP.cc:256-259)
+    boundary: int = 0  # 0: Nitsche, 1: zeroed (minimal_SIP.cc:230-248)
+    reaction_c: float = 0.0  # diffusion_reaction.cc:495-501
+
+    @staticmethod
+    def assemble_dg_matrix():
+        return SipVariant()
+
+    @staticmethod
+    def poisson_example(fe):
+        return SipVariant(10.0 * (fe.degree + 1) * (fe.degree + fe.dim), 1)
+
+    @staticmethod
+    def minimal_sip_test():
+        return SipVariant(20.0, 1, 1)
+
+    @staticmethod
+    def minimal_sip_example():
+        return SipVariant(10.0, 1, 2, 1)
+
+    @staticmethod
+    def diffusion_reaction(fe):
+        return SipVariant(10.0 * fe.degree ** 2, 0, 0, 0, 0.5)
+
+
+class BackgroundGrid:
+    """hyper_cube + refine_global (Morton order) or subdivided_hyper_cube (lexicographic)."""
+
+    def __init__(self, dim, n_per_dir, lo=0.0, hi=1.0, morton=True):
+        self.dim, self.n_per_dir = dim, n_per_dir
+        self.h = _lib().pdhh_grid_create(dim, n_per_dir, int(morton), lo, hi)
+        if not self.h:
+            _raise()
+
+    @staticmethod
+    def hyper_cube_refined(dim, lo, hi, n_refine):
+        return BackgroundGrid(dim, 2 ** n_refine, lo, hi, True)
+
+    @staticmethod
+    def subdivided_hyper_cube(dim, n, lo=0.0, hi=1.0):
+        return BackgroundGrid(dim, n, lo, hi, False)
+
+    @property
+    def n_cells(self):
+        return _lib().pdhh_grid_n_cells(self.h)
+
+    def distort(self, factor, seed=0):
+        if _lib().pdhh_grid_distort(self.h, factor, seed) < 0:
+            _raise()
+        return self
+
+    def cell_vertices(self, cell):
+        out = np.zeros((2 ** self.dim, self.dim))
+        if _lib().pdhh_grid_vertices(self.h, cell, out.ctypes.data) < 0:
+            _raise()
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib().pdhh_grid_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class FlatView:
+    """NumPy views onto the pdh_problem a handler flattened (owned by the C++ handle)."""
+
+    def __init__(self, handler, cptr):
+        self.handler = handler  # keeps the owner alive
+        self.c = cptr.contents
+        sizes = (C.c_int64 * 4)()
+        _lib().pdhh_flat_sizes(handler.h, sizes)
+        self.nq_tot, self.nqf_tot, self.nnz, self.n_faces = [int(x) for x in sizes]
+
+    def _arr(self, field, ctype, n):
+        p = getattr(self.c, field)
+        if not p or n == 0:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n,))
+
+    def arrays(self):
+        c, d = self.c, self.c.dim
+        return dict(
+            bbox=self._arr("bbox", C.c_double, c.n_agg * 2 * d), dof_offset=self._arr("dof_offset", C.c_int32, c.n_agg),
+            vq_ptr=self._arr("vq_ptr", C.c_int64, c.n_agg + 1), vq_x=self._arr("vq_x", C.c_double, d * self.nq_tot),
+            vq_w=self._arr("vq_w", C.c_double, self.nq_tot),
+            face_in=self._arr("face_in", C.c_int32, c.n_faces), face_out=self._arr("face_out", C.c_int32, c.n_faces),
+            fq_ptr=self._arr("fq_ptr", C.c_int64, c.n_faces + 1), fq_x=self._arr("fq_x", C.c_double, d * self.nqf_tot),
+            fq_n=self._arr("fq_n", C.c_double, d * self.nqf_tot), fq_w=self._arr("fq_w", C.c_double, self.nqf_tot),
+            fq_w_out=self._arr("fq_w_out", C.c_double, self.nqf_tot),
+            face_sigma=self._arr("face_sigma", C.c_double, c.n_faces),
+            rowptr=self._arr("rowptr", C.c_int64, c.n_rows + 1), colind=self._arr("colind", C.c_int32, self.nnz),
+        )
+
+
+class AgglomerationHandler:
+    """Mirror of AgglomerationHandler<dim> restricted to the SIP path (polytopes addressed by index())."""
+
+    def __init__(self, grid: BackgroundGrid):
+        self.grid = grid
+        self.h = _lib().pdhh_handler_create(grid.h)
+        self.fe = None
+
+    # -- reference API -------------------------------------------------------------------------------
+    def define_agglomerate(self, cells):
+        a = np.ascontiguousarray(cells, dtype=np.int32)
+        r = _lib().pdhh_define_agglomerate(self.h, a.ctypes.data, len(a))
+        if r < 0:
+            _raise()
+        return r
+
+    def define_block_agglomerates(self, b):
+        if _lib().pdhh_define_block_agglomerates(self.h, b) < 0:
+            _raise()
+
+    def initialize_fe_values(self, n_q_points_1d, n_face_q_points_1d):
+        if _lib().pdhh_initialize_fe_values(self.h, n_q_points_1d, n_face_q_points_1d) < 0:
+            _raise()
+
+    def distribute_agglomerated_dofs(self, fe: FiniteElement):
+        if _lib().pdhh_distribute_agglomerated_dofs(self.h, fe.basis, fe.degree) < 0:
+            _raise()
+        self.fe = fe
+
+    @property
+    def n_agglomerates(self):
+        return _lib().pdhh_n_agglomerates(self.h)
+
+    @property
+    def n_dofs(self):
+        return _lib().pdhh_n_dofs(self.h)
+
+    @property
+    def n_dofs_per_cell(self):
+        return _lib().pdhh_n_dofs_per_cell(self.h)
+
+    # -- accessor-level queries (shared protocol with the oracle, see tests/golden_cases.py) -----------
+    def master_index(self, P):
+        return _lib().pdhh_master_index(self.h, P)
+
+    def master_slave_value(self, cell):
+        return _lib().pdhh_master_slave_value(self.h, cell)
+
+    def n_faces_of(self, P):
+        return _lib().pdhh_n_faces(self.h, P)
+
+    def at_boundary(self, P, f):
+        return bool(_lib().pdhh_at_boundary(self.h, P, f))
+
+    def neighbor(self, P, f):
+        r = _lib().pdhh_neighbor(self.h, P, f)
+        if r == -2:
+            _raise()
+        return r
+
+    def neighbor_of_agglomerated_neighbor(self, P, f):
+        r = _lib().pdhh_neighbor_of_agglomerated_neighbor(self.h, P, f)
+        if r == -2:
+            _raise()
+        return r
+
+    def interface_list(self, P, Q):
+        cap = 4096
+        cells = np.zeros(cap, dtype=np.int32)
+        faces = np.zeros(cap, dtype=np.int32)
+        n = _lib().pdhh_interface(self.h, P, Q, cells.ctypes.data, faces.ctypes.data, cap)
+        if n < 0:
+            _raise()
+        return [(int(cells[i]), int(faces[i])) for i in range(min(n, cap))]
+
+    def bbox(self, P):
+        d = self.grid.dim
+        out = np.zeros(2 * d)
+        if _lib().pdhh_bbox(self.h, P, out.ctypes.data) < 0:
+            _raise()
+        return out[:d], out[d:]
+
+    def diameter(self, P):
+        return _lib().pdhh_diameter(self.h, P)
+
+    def dof_indices(self, P):
+        off = _lib().pdhh_dof_offset(self.h, P)
+        return np.arange(off, off + self.n_dofs_per_cell)
+
+    def volume_jxw_sum(self, P):
+        return _lib().pdhh_volume_jxw_sum(self.h, P)
+
+    def face_jxw_sum(self, P, f):
+        return _lib().pdhh_face_jxw_sum(self.h, P, f)
+
+    def sparsity_pattern(self, diag_first=True):
+        """create_agglomeration_sparsity_pattern -> (rowptr, colind)."""
+        rowptr = np.zeros(self.n_dofs + 1, dtype=np.int64)
+        nnz = _lib().pdhh_sparsity(self.h, int(diag_first), rowptr.ctypes.data, None)
+        if nnz < 0:
+            _raise()
+        colind = np.zeros(nnz, dtype=np.int32)
+        _lib().pdhh_sparsity(self.h, int(diag_first), rowptr.ctypes.data, colind.ctypes.data)
+        return rowptr, colind
+
+    def sparsity_rows(self):
+        rp, ci = self.sparsity_pattern(diag_first=False)
+        return [ci[rp[r]:rp[r + 1]] for r in range(self.n_dofs)]
+
+    # -- flattening + assembly -----------------------------------------------------------------------
+    def flatten(self, variant: SipVariant, diag_first=True, with_colind=False) -> FlatView:
+        p = _lib().pdhh_flatten(self.h, variant.penalty_constant, variant.owner_rule, variant.h_rule,
+                                variant.boundary, variant.reaction_c, int(diag_first), int(with_colind))
+        if not p:
+            _raise()
+        return FlatView(self, p)
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib().pdhh_handler_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def assemble_dg_matrix(fe: FiniteElement, ah: AgglomerationHandler, variant: SipVariant | None = None,
+                       diag_first=True, device=0):
+    """PolyUtils::assemble_dg_matrix (include/poly_utils.h:2000-2195) on the GPU.
+    Returns (rowptr, colind, values) of the pattern the handler creates.  Raises if no HIP device."""
+    if fe != ah.fe:
+        raise ValueError("FE passed to assemble_dg_matrix differs from the handler's")
+    variant = variant or SipVariant.assemble_dg_matrix()
+    rowptr, colind = ah.sparsity_pattern(diag_first)
+    values = np.zeros(int(rowptr[-1]))
+    rc = _lib().pdhh_assemble_dg_matrix(ah.h, variant.penalty_constant, variant.owner_rule, variant.h_rule,
+                                         variant.boundary, variant.reaction_c, int(diag_first), device,
+                                         values.ctypes.data, len(values))
+    if rc < 0:
+        _raise()
+    return rowptr, colind, values
