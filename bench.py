@@ -71,10 +71,10 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     n = fe.n_dofs_per_cell
     n_agg = ah.n_agglomerates
     # contiguous dof-row ranges of whole polytopes per rank (strong scaling)
-    a0 = (n_agg * rank) // world
-    a1 = (n_agg * (rank + 1)) // world
+    from polydeal_amd.partition import row_range
+    r0, r1 = row_range(n_agg, n, rank, world)
     ctx = pa.Context(local_rank)
-    ctx.set_problem(flat, a0 * n, a1 * n)
+    ctx.set_problem(flat, r0, r1)
     t_setup = time.time() - t0
     for _ in range(warmup):
         ctx.assemble_device()

@@ -17,18 +17,29 @@
 #include <string>
 #include <vector>
 
+#include "pdh_combos.h"
+
 extern "C" {
-typedef hipError_t (*pdh_launch_fn)(int lb, int which, const PdhDev *P, int count, size_t lds, hipStream_t stream);
-#define PDH_DECL(d, n) hipError_t pdh_launch_##d##_##n(int, int, const PdhDev *, int, size_t, hipStream_t);
-PDH_DECL(2, 1) PDH_DECL(2, 2) PDH_DECL(2, 3) PDH_DECL(2, 4)
-PDH_DECL(3, 1) PDH_DECL(3, 2) PDH_DECL(3, 3) PDH_DECL(3, 4)
+typedef hipError_t (*pdh_launch_fn)(int dim, int n1d, int nt, int lb, int which, const PdhDev *P, int count, size_t lds,
+                                    hipStream_t stream);
+#define PDH_DECL(g) hipError_t pdh_launch_g##g(int, int, int, int, int, const PdhDev *, int, size_t, hipStream_t);
+PDH_DECL(0) PDH_DECL(1) PDH_DECL(2) PDH_DECL(3) PDH_DECL(4) PDH_DECL(5) PDH_DECL(6) PDH_DECL(7)
 #undef PDH_DECL
 }
 
-static pdh_launch_fn g_launch[2][4] = {
-  {pdh_launch_2_1, pdh_launch_2_2, pdh_launch_2_3, pdh_launch_2_4},
-  {pdh_launch_3_1, pdh_launch_3_2, pdh_launch_3_3, pdh_launch_3_4},
-};
+static pdh_launch_fn g_launch[PDH_N_GROUPS] = {pdh_launch_g0, pdh_launch_g1, pdh_launch_g2, pdh_launch_g3,
+                                               pdh_launch_g4, pdh_launch_g5, pdh_launch_g6, pdh_launch_g7};
+
+// translation-unit group holding the kernels of a combo, or -1 if that combo is not instantiated
+static int combo_group(int dim, int n1d, int nt, int lb)
+{
+#define PDH_X(G, D, N, T, L)                                                                       \
+  if (dim == D && n1d == N && nt == T && lb == L)                                                  \
+    return G;
+  PDH_COMBOS(PDH_X)
+#undef PDH_X
+  return -1;
+}
 
 struct pdh_ctx
 {
@@ -38,7 +49,7 @@ struct pdh_ctx
   bool has_problem = false;
   std::vector<void *> allocs;
   PdhDev dev;
-  int n_owned = 0, n_items = 0, NT = 0, LB = 0;
+  int n_owned = 0, n_items = 0, NT = 0, LB = 0, group = -1;
   size_t lds_diag = 0, lds_off = 0;
   int64_t n_values = 0, n_vq = 0, n_ap = 0;
   bool profiling = false;
@@ -150,7 +161,7 @@ struct Packed
   int n = 0, n1d = 0, NT = 0, LB = 0;
   std::vector<int32_t> midx;
   PdhBasisTab tab;
-  std::vector<int32_t> own_agg, row_len, diag_L, it_own, it_nbr, it_pcnt, it_pos;
+  std::vector<int32_t> own_agg, row_len, diag_L, it_own, it_nbr, it_pcnt, it_pos, it_nbr_slot, it_pos_t;
   std::vector<int64_t> row_base, vq_ptr, ap_ptr, it_pbeg;
   std::vector<double> vq_x, vq_w, ap_x, ap_n, ap_wself, ap_wcross, ap_sig;
   int64_t n_values = 0;
@@ -185,6 +196,8 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
   const int T = (n + 3) / 4;
   K.NT = (T + 3) / 4;
   K.LB = T - 4 * (K.NT - 1);
+  if (combo_group(dim, K.n1d, K.NT, K.LB) < 0)
+    return fail(ctx, PDH_EUNSUPPORTED, "no kernel instantiated for this (dim, basis, degree)");
 
   // basis tables
   const pdh::Basis1D b1 = (p->basis == PDH_BASIS_DGQ) ? pdh::lagrange_basis(p->degree) : pdh::legendre_basis(p->degree);
@@ -205,6 +218,9 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
         return fail(ctx, PDH_EINVAL, "dof_offset must be a multiple of dofs_per_cell inside [0,n_rows)");
       if (p->vq_ptr[a + 1] < p->vq_ptr[a])
         return fail(ctx, PDH_EINVAL, "vq_ptr must be non-decreasing");
+      for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q)
+        if (!(p->vq_w[q] >= 0.0))
+          return fail(ctx, PDH_EINVAL, "quadrature weights (JxW) must be non-negative");
       for (int c = 0; c < dim; ++c)
         if (!(p->bbox[(size_t)a * 2 * dim + dim + c] > p->bbox[(size_t)a * 2 * dim + c]))
           return fail(ctx, PDH_EINVAL, "degenerate bounding box");
@@ -218,6 +234,9 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
         return fail(ctx, PDH_EINVAL, "face_in/face_out out of range");
       if (p->fq_ptr[f + 1] < p->fq_ptr[f])
         return fail(ctx, PDH_EINVAL, "fq_ptr must be non-decreasing");
+      for (int64_t q = p->fq_ptr[f]; q < p->fq_ptr[f + 1]; ++q)
+        if (!(p->fq_w[q] >= 0.0) || (p->fq_w_out && !(p->fq_w_out[q] >= 0.0)))
+          return fail(ctx, PDH_EINVAL, "face quadrature weights (JxW) must be non-negative");
       ++fptr[in + 1];
       if (out >= 0)
         ++fptr[out + 1];
@@ -307,18 +326,27 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           const double sig = p->face_sigma[f];
           if (other >= 0)
             {
-              K.it_own.push_back(slot);
-              K.it_nbr.push_back(other);
-              K.it_pbeg.push_back((int64_t)K.ap_wself.size());
-              K.it_pcnt.push_back((int32_t)(qe - qb));
-              size_t rank = 0;
-              for (size_t u = 0; u < blocks.size(); ++u)
-                if (blocks[u].second == other)
-                  rank = u;
-              int pos = (int)rank * n;
-              if (p->diag_first && p->dof_offset[other] < off)
-                pos += 1;
-              K.it_pos.push_back(pos);
+              const int ooff = p->dof_offset[other];
+              const bool other_owned = (ooff >= row_begin && ooff < row_end);
+              // one item per interior face: the owned side with the lower polytope id computes A[P,Q]
+              // and also writes A[Q,P] = A[P,Q]^T when Q's rows are owned here too
+              if (!other_owned || a < other)
+                {
+                  K.it_own.push_back(slot);
+                  K.it_nbr.push_back(other);
+                  K.it_pbeg.push_back((int64_t)K.ap_wself.size());
+                  K.it_pcnt.push_back((int32_t)(qe - qb));
+                  size_t rank = 0;
+                  for (size_t u = 0; u < blocks.size(); ++u)
+                    if (blocks[u].second == other)
+                      rank = u;
+                  int pos = (int)rank * n;
+                  if (p->diag_first && ooff < off)
+                    pos += 1;
+                  K.it_pos.push_back(pos);
+                  K.it_nbr_slot.push_back(other_owned ? other : -1); // polytope id for now, slot resolved below
+                  K.it_pos_t.push_back(0);
+                }
             }
           for (int64_t q = qb; q < qe; ++q)
             {
@@ -342,6 +370,34 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
     }
   if ((int64_t)K.own_agg.size() * n != (int64_t)(row_end - row_begin))
     return fail(ctx, PDH_EINVAL, "dof_offset values do not tile the owned row range");
+  {
+    // resolve the neighbour's owned slot and the position of P's block inside Q's rows
+    std::vector<int32_t> slot_of(nA, -1);
+    for (size_t sl = 0; sl < K.own_agg.size(); ++sl)
+      slot_of[K.own_agg[sl]] = (int32_t)sl;
+    for (size_t it = 0; it < K.it_own.size(); ++it)
+      {
+        const int q = K.it_nbr_slot[it];
+        if (q < 0)
+          continue;
+        const int pa = K.own_agg[K.it_own[it]];
+        const int poff = p->dof_offset[pa], qoff = p->dof_offset[q];
+        // rank of P's block among Q's coupled blocks = number of Q's blocks with a smaller dof offset
+        int rank = (qoff < poff) ? 1 : 0;
+        for (int64_t t = fptr[q]; t < fptr[q + 1]; ++t)
+          {
+            const int f = flist[t];
+            const int o = (p->face_in[f] == q) ? p->face_out[f] : p->face_in[f];
+            if (o >= 0 && o != pa && p->dof_offset[o] < poff)
+              ++rank;
+          }
+        int pos = rank * n;
+        if (p->diag_first && poff < qoff)
+          pos += 1;
+        K.it_pos_t[it] = pos;
+        K.it_nbr_slot[it] = slot_of[q];
+      }
+  }
 
   // second pass: coordinates / normals in SoA with the final strides
   const int64_t nvq = (int64_t)K.vq_w.size(), nap = (int64_t)K.ap_wself.size();
@@ -436,6 +492,8 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   PDH_UP(K.it_pbeg, it_pbeg)
   PDH_UP(K.it_pcnt, it_pcnt)
   PDH_UP(K.it_pos, it_pos)
+  PDH_UP(K.it_nbr_slot, it_nbr_slot)
+  PDH_UP(K.it_pos_t, it_pos_t)
 #undef PDH_UP
   D.vq_stride = (int64_t)K.vq_w.size();
   D.ap_stride = (int64_t)K.ap_wself.size();
@@ -455,6 +513,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   ctx->n_ap = (int64_t)K.ap_wself.size();
   ctx->NT = K.NT;
   ctx->LB = K.LB;
+  ctx->group = combo_group(p->dim, K.n1d, K.NT, K.LB);
   ctx->lds_diag = pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
   ctx->lds_off = pdh::lds_bytes_offdiag(p->dim, K.n1d, K.NT);
   ctx->has_problem = true;
@@ -476,7 +535,8 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
   if (!ctx->has_problem)
     return fail(ctx, PDH_ESTATE, "pdh_assemble_device called before pdh_set_problem");
   PDH_HIP(ctx, hipSetDevice(ctx->device));
-  pdh_launch_fn fn = g_launch[ctx->dev.dim - 2][ctx->NT - 1];
+  pdh_launch_fn fn = g_launch[ctx->group];
+  const int dim = ctx->dev.dim, n1d = ctx->dev.n1d, nt = ctx->NT, lb = ctx->LB;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   if (ctx->profiling)
     {
@@ -487,10 +547,10 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
         return fail(ctx, PDH_EDEVICE, "hipEventCreate failed");
       PDH_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
-  PDH_HIP(ctx, fn(ctx->LB, 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
+  PDH_HIP(ctx, fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(e1, ctx->stream));
-  PDH_HIP(ctx, fn(ctx->LB, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
+  PDH_HIP(ctx, fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(e2, ctx->stream));
   return PDH_OK;

@@ -1,0 +1,62 @@
+"""Worker of tests/test_distributed_cpu.py: one rank of a gloo group (CPU).  Each rank builds the same
+global problem with the product host mirror, takes its row range, runs the host-side validation/packing
+of pdh_set_problem_local (pdh_check_problem: no GPU needed) and the ranks cross-check that their pieces
+tile the global problem exactly."""
+import ctypes as C
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import polydeal_amd as pa  # noqa: E402
+from polydeal_amd.partition import row_range  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    grid = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 3)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_block_agglomerates(2)
+    fe = pa.FE_AggloDGP(3, 2)
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(fe)
+    flat = ah.flatten(pa.SipVariant.diffusion_reaction(fe), True, True)
+    n = fe.n_dofs_per_cell
+    lib = pa.load_library()
+    r0, r1 = row_range(ah.n_agglomerates, n, rank, world)
+    st = (C.c_int64 * 8)()
+    rc = lib.pdh_check_problem(C.byref(flat.c), r0, r1, st)
+    assert rc == 0, lib.pdh_last_error(None)
+    gl = (C.c_int64 * 8)()
+    assert lib.pdh_check_problem(C.byref(flat.c), 0, flat.c.n_rows, gl) == 0
+    mine = torch.tensor(list(st)[:5], dtype=torch.int64)
+    tot = mine.clone()
+    dist.all_reduce(tot)
+    expect = torch.tensor(list(gl)[:5], dtype=torch.int64)
+    # owned polytopes, volume points, own-side face points and values tile the global problem exactly;
+    # coupling items: one per interior face, faces cut by the partition are computed on both ranks
+    # (each writes only its own rows), so the sum exceeds the global count by the number of cut faces
+    keep = [0, 2, 3, 4]
+    assert torch.equal(tot[keep], expect[keep]), (tot, expect)
+    assert int(tot[1]) > int(expect[1]) if world > 1 else int(tot[1]) == int(expect[1])
+    ranges = [None] * world
+    dist.all_gather_object(ranges, (r0, r1))
+    assert ranges[0][0] == 0 and ranges[-1][1] == flat.c.n_rows
+    for a, b in zip(ranges[:-1], ranges[1:]):
+        assert a[1] == b[0]
+    rp = flat.arrays()["rowptr"]
+    assert int(st[4]) == int(rp[r1] - rp[r0])
+    # a misaligned range must be rejected
+    assert lib.pdh_check_problem(C.byref(flat.c), r0 + 1, r1, st) != 0
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK world=%d" % world)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
