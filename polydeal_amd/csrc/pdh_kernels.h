@@ -99,36 +99,57 @@ __device__ __forceinline__ double mfma4(double a, double b, double c)
 }
 
 // Rotation of the four 4-lane blocks of every 16-lane row: result block bb = input block (bb+R)&3.
-// Both cross-lane paths are used so that neither pipe limits the MFMA rate: R = 1 goes through DPP
-// (VALU, row_ror), R = 2, 3 through ds_bpermute_b32 (LDS crossbar, ~8 LDS-pipe cycles each, measured).
+// R = 1, 2 go through DPP row_ror (VALU), R = 3 - needed only by the non-symmetric coupling schedule -
+// through ds_bpermute_b32 (LDS crossbar).  Measured alternatives on MI355X (profiles/README.md): all three
+// through DPP made the kernels VALU-issue bound (every VALU instruction, DPP moves included, takes issue
+// time from the f64 MFMA of its SIMD even across waves - tools/probes/coissue_probe.hip); all through
+// ds_bpermute made them LDS-pipe bound; a write/read round trip through LDS scratch exposed its latency.
 struct Rotator
 {
-  int addr[2]; // 4 * source lane for R = 2, 3
-  __device__ __forceinline__ void init(int lane)
-  {
-    for (int r = 2; r < 4; ++r)
-      addr[r - 2] = ((lane & ~15) | ((lane + 4 * r) & 15)) * 4;
-  }
+  int addr3; // 4 * source lane for R = 3
+  __device__ __forceinline__ void init(int lane) { addr3 = ((lane & ~15) | ((lane + 12) & 15)) * 4; }
   template <int R>
   __device__ __forceinline__ double rot(double x) const
   {
     if constexpr (R == 0)
       return x;
-    else if constexpr (R == 1)
+    else if constexpr (R == 1 || R == 2)
       {
-        // row_ror:12 gives lane m the value of lane (m+4) mod 16 of its row (tools/probes/dpp_probe.hip)
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x120 + 12, 0xf, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x120 + 12, 0xf, 0xf, false);
+        // row_ror:K gives lane m the value of lane (m-K) mod 16 of its row (tools/probes/dpp_probe.hip);
+        // mov_dpp (undefined old value): every lane is written, so no zero-initialising v_mov is needed
+        constexpr int K = 16 - 4 * R;
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x120 + K, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x120 + K, 0xf, 0xf, true);
         return __hiloint2double(hi, lo);
       }
     else
       {
-        const int lo = __builtin_amdgcn_ds_bpermute(addr[R - 2], __double2loint(x));
-        const int hi = __builtin_amdgcn_ds_bpermute(addr[R - 2], __double2hiint(x));
+        const int lo = __builtin_amdgcn_ds_bpermute(addr3, __double2loint(x));
+        const int hi = __builtin_amdgcn_ds_bpermute(addr3, __double2hiint(x));
         return __hiloint2double(hi, lo);
       }
   }
 };
+
+// The rotated copies of one set of NT fragments: v[s][f] = rot_s(fragment f).
+template <int NT>
+struct RotSet
+{
+  double v[4][NT];
+};
+
+// SMASK: bit s set = rot_s is needed (bit 0 is implied).
+template <int NT, int SMASK>
+__device__ __forceinline__ void make_rot(const double *X, const Rotator &rt, RotSet<NT> &out)
+{
+  static_for<0, NT>([&](auto f_) {
+    constexpr int f = f_;
+    out.v[0][f] = X[f];
+    out.v[1][f] = ((SMASK >> 1) & 1) ? rt.template rot<1>(X[f]) : 0.0;
+    out.v[2][f] = ((SMASK >> 2) & 1) ? rt.template rot<2>(X[f]) : 0.0;
+    out.v[3][f] = ((SMASK >> 3) & 1) ? rt.template rot<3>(X[f]) : 0.0;
+  });
+}
 
 // Compile-time product schedule.  NT fragments of 16 basis functions; the last fragment has LB live
 // 4-function blocks.  If LB is 1 or 2 the last fragment is stored replicated ([F,F,F,F] / [F0,F1,F0,F1])
@@ -263,27 +284,42 @@ __device__ __forceinline__ void eval_point_record(const PdhBasisTab &tab, const 
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-// sqrt(w) phi and sqrt(w) d_c phi of fragment a's function at the lane's point.
+// Raw table entries (value, derivative) per direction of one fragment's function at the lane's point.
+template <int DIM>
+struct FragRaw
+{
+  d2_t t[DIM];
+  __device__ __forceinline__ void load(const char *rec_bytes, const int *off)
+  {
+    for (int c = 0; c < DIM; ++c)
+      t[c] = *reinterpret_cast<const d2_t *>(rec_bytes + off[c]);
+  }
+  // sqrt(w) phi and sqrt(w) d_c phi
+  __device__ __forceinline__ void eval(double &phi, double *dphi) const
+  {
+    if constexpr (DIM == 2)
+      {
+        phi = t[0].x * t[1].x;
+        dphi[0] = t[0].y * t[1].x;
+        dphi[1] = t[0].x * t[1].y;
+      }
+    else
+      {
+        const double v12 = t[1].x * t[2].x, v01 = t[0].x * t[1].x;
+        phi = t[0].x * v12;
+        dphi[0] = t[0].y * v12;
+        dphi[1] = (t[0].x * t[2].x) * t[1].y;
+        dphi[2] = v01 * t[2].y;
+      }
+  }
+};
+
 template <int DIM>
 __device__ __forceinline__ void frag_eval(const char *rec_bytes, const int *off, double &phi, double *dphi)
 {
-  d2_t t[DIM];
-  for (int c = 0; c < DIM; ++c)
-    t[c] = *reinterpret_cast<const d2_t *>(rec_bytes + off[c]);
-  if constexpr (DIM == 2)
-    {
-      phi = t[0].x * t[1].x;
-      dphi[0] = t[0].y * t[1].x;
-      dphi[1] = t[0].x * t[1].y;
-    }
-  else
-    {
-      const double v12 = t[1].x * t[2].x, v01 = t[0].x * t[1].x;
-      phi = t[0].x * v12;
-      dphi[0] = t[0].y * v12;
-      dphi[1] = (t[0].x * t[2].x) * t[1].y;
-      dphi[2] = v01 * t[2].y;
-    }
+  FragRaw<DIM> r;
+  r.load(rec_bytes, off);
+  r.eval(phi, dphi);
 }
 
 template <int NT>
@@ -293,58 +329,93 @@ __device__ __forceinline__ constexpr int acc_idx(int a, int b, int r)
 }
 
 // acc[a,b,r] += rot_sa(A[a]) (x) rot_sb(B[b]) for the symmetric (a<=b) or the full schedule.
+// Needs A rotations {0} (+{1} if SYM) and B rotations {0,1,2} (+{3} if !SYM).
 template <int NT, int LB, bool SYM>
-__device__ __forceinline__ void product(double *acc, const double *A, const double *B, const Rotator &rt)
+__device__ __forceinline__ void product(double *acc, const RotSet<NT> &A, const RotSet<NT> &B)
 {
   using S = Sched<NT, LB>;
-  double A1[NT]; // rot_1(A[a]), only used by the symmetric schedule (r = 3)
-  static_for<0, NT>([&](auto a_) {
-    constexpr int a = a_;
-    if constexpr (S::needs_rot_a(a, 1, SYM))
-      A1[a] = rt.template rot<1>(A[a]);
-    else
-      A1[a] = 0.0;
-  });
   static_for<0, NT>([&](auto b_) {
     constexpr int b = b_;
-    const double R0 = B[b];
-    double R1 = 0.0, R2 = 0.0, R3 = 0.0;
-    if constexpr (S::needs_rot_b(b, 1, SYM))
-      R1 = rt.template rot<1>(R0);
-    if constexpr (S::needs_rot_b(b, 2, SYM))
-      R2 = rt.template rot<2>(R0);
-    if constexpr (S::needs_rot_b(b, 3, SYM))
-      R3 = rt.template rot<3>(R0);
     static_for<0, NT>([&](auto a_) {
       constexpr int a = a_;
       static_for<0, 4>([&](auto r_) {
         constexpr int r = r_;
         constexpr unsigned msk = SYM ? S::sym_mask(a, b, r) : S::full_mask(a, b, r);
         if constexpr (msk != 0u)
+          acc[acc_idx<NT>(a, b, r)] =
+            mfma4(A.v[S::sa(r, SYM)][a], B.v[S::sb(r, SYM)][b], acc[acc_idx<NT>(a, b, r)]);
+      });
+    });
+  });
+}
+// Full (non-symmetric) schedule with the B rotations formed per fragment right before use: keeps only three
+// rotated copies live at a time (the coupling kernel has 64 accumulators and no registers to spare).
+template <int NT, int LB>
+__device__ __forceinline__ void product_full(double *acc, const double *A, const double *B, const Rotator &rt)
+{
+  using S = Sched<NT, LB>;
+  static_for<0, NT>([&](auto b_) {
+    constexpr int b = b_;
+    const double R0 = B[b];
+    const double R1 = rt.template rot<1>(R0), R2 = rt.template rot<2>(R0), R3 = rt.template rot<3>(R0);
+    static_for<0, NT>([&](auto a_) {
+      constexpr int a = a_;
+      static_for<0, 4>([&](auto r_) {
+        constexpr int r = r_;
+        if constexpr (S::full_mask(a, b, r) != 0u)
           {
-            constexpr int sb = S::sb(r, SYM);
-            const double Rr = (sb == 0) ? R0 : (sb == 1) ? R1 : (sb == 2) ? R2 : R3;
-            const double Aa = (S::sa(r, SYM) == 0) ? A[a] : A1[a];
-            acc[acc_idx<NT>(a, b, r)] = mfma4(Aa, Rr, acc[acc_idx<NT>(a, b, r)]);
+            const double Rr = (r == 0) ? R0 : (r == 1) ? R1 : (r == 2) ? R2 : R3;
+            acc[acc_idx<NT>(a, b, r)] = mfma4(A[a], Rr, acc[acc_idx<NT>(a, b, r)]);
           }
       });
     });
   });
 }
+constexpr int ROT_SYM = 0x7;  // rotations 0,1,2: enough for both operands of the symmetric schedule
+constexpr int ROT_FULL = 0xf; // B operand of the full schedule
+constexpr int ROT_NONE = 0x1; // A operand of the full schedule
+
+// Epilogue helper.  Per-lane constants of the D layout (lane = 16 i + 4 bb + j) so that scattering one
+// accumulator into the LDS strip costs a couple of integer instructions: for a fragment with `rep`
+// distinct blocks and operand rotation s the lane's local tile is (bb+s) & (rep-1).
+template <int NT, int LB>
+struct StripMap
+{
+  using S = Sched<NT, LB>;
+  int i, bb, j;
+  __device__ __forceinline__ void init(int lane)
+  {
+    i = lane >> 4;
+    bb = (lane >> 2) & 3;
+    j = lane & 3;
+  }
+  // row / column of the computed block held by this lane for product (a,b,r)
+  template <int A, int R, bool SYM>
+  __device__ __forceinline__ int row() const
+  {
+    constexpr int rp = S::rep(A);
+    return 16 * A + 4 * ((bb + S::sa(R, SYM)) & (rp - 1)) + i;
+  }
+  template <int B, int R, bool SYM>
+  __device__ __forceinline__ int col() const
+  {
+    constexpr int rp = S::rep(B);
+    return 16 * B + 4 * ((bb + S::sb(R, SYM)) & (rp - 1)) + j;
+  }
+};
 
 // Scatter the accumulators' entries that fall into row strip STRIP (rows 16*STRIP.. of the block) into the
 // LDS strip [16][ncol_pad]; SYM additionally mirrors (i,j) -> (j,i); TRANSPOSE scatters the transposed
 // block instead.
 template <int NT, int LB, bool SYM, bool TRANSPOSE, int STRIP>
-__device__ __forceinline__ void fill_strip(const double *acc, double *strip, int ncol_pad, int lane, int n)
+__device__ __forceinline__ void fill_strip(const double *acc, double *strip, int ncol_pad, const StripMap<NT, LB> &sm, int n)
 {
   using S = Sched<NT, LB>;
-  const int i = lane >> 4, bb = (lane >> 2) & 3, j = lane & 3;
   static_for<0, NT>([&](auto a_) {
     constexpr int a = a_;
     static_for<0, NT>([&](auto b_) {
       constexpr int b = b_;
-      // rows 4*tile(a,.)+i lie in row strip a and columns 4*tile(b,.)+j in column strip b, so only the
+      // rows of fragment a lie in row strip a and columns of fragment b in column strip b, so only the
       // accumulators of fragment row STRIP (direct) / fragment column STRIP (mirror or transpose) contribute
       constexpr bool do_direct = !TRANSPOSE && (a == STRIP);
       constexpr bool do_swap = (TRANSPOSE || SYM) && (b == STRIP);
@@ -354,24 +425,51 @@ __device__ __forceinline__ void fill_strip(const double *acc, double *strip, int
           constexpr unsigned msk = SYM ? S::sym_mask(a, b, r) : S::full_mask(a, b, r);
           if constexpr (msk != 0u)
             {
-              if ((msk >> bb) & 1u)
+              const int R = sm.template row<a, r, SYM>(), C = sm.template col<b, r, SYM>();
+              const double v = acc[acc_idx<NT>(a, b, r)];
+              bool ok = (R < n) && (C < n);
+              if constexpr (msk != 0xfu)
+                ok = ok && (((msk >> sm.bb) & 1u) != 0u);
+              if (ok)
                 {
-                  const int ti = S::ti(a, r, bb, SYM), tj = S::tj(b, r, bb, SYM);
-                  const int R = 4 * ti + i, C = 4 * tj + j; // entry (R,C) of the computed block
-                  const double v = acc[acc_idx<NT>(a, b, r)];
-                  if (R < n && C < n)
-                    {
-                      if constexpr (do_direct)
-                        strip[(R & 15) * ncol_pad + C] = v;
-                      if constexpr (do_swap)
-                        if (TRANSPOSE || ti != tj)
-                          strip[(C & 15) * ncol_pad + R] = v;
-                    }
+                  if constexpr (do_direct)
+                    strip[(R & 15) * ncol_pad + C] = v;
+                  if constexpr (do_swap)
+                    if (TRANSPOSE || (R >> 2) != (C >> 2))
+                      strip[(C & 15) * ncol_pad + R] = v;
                 }
             }
         });
     });
   });
+}
+
+// Write rows [16*STRIP, 16*STRIP+rows) of a block from the LDS strip to their CSR positions: row R of the
+// block goes to values[base + R*row_len + pos(R,c)], one contiguous segment per row (n <= 64 = one wave store).
+// DIAG: own block in deal.II diagonal-first layout (diagonal entry at position 0, columns before it shifted).
+template <bool DIAG>
+__device__ __forceinline__ void store_strip(double *values, int64_t base, int row_len, int pos0, int diag_first,
+                                            const double *strip, int ncol_pad, int strip_idx, int n, int lane)
+{
+  const int rows = (n - 16 * strip_idx < 16) ? (n - 16 * strip_idx) : 16;
+  if (lane < n)
+    {
+      double *dst = values + base + (int64_t)(16 * strip_idx) * row_len;
+      const double *src = strip + lane;
+      for (int rr = 0; rr < rows; ++rr)
+        {
+          int pos = pos0 + lane;
+          if constexpr (DIAG)
+            if (diag_first)
+              {
+                const int R = 16 * strip_idx + rr;
+                pos = (lane == R) ? 0 : (pos0 + lane + (lane < R ? 1 : 0));
+              }
+          dst[pos] = src[0];
+          dst += row_len;
+          src += ncol_pad;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -387,8 +485,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   if (slot >= n_owned)
     return;
   const int agg = P.own_agg[slot];
-  double *rec = lds;                      // [64][RC::LEN]
-  double *aux = lds + PDH_WAVE * RC::LEN; // [64][2+DIM]: (unused), sigma/2, normal
+  // 32-point chunks: 8.4 KB of LDS per wave (the output strip) instead of 15.9 KB, so that LDS does not cap
+  // the CU below 3 waves per SIMD; lanes 32-63 idle during the (short) point phase.
+  constexpr int CH = 32;
+  double *rec = lds;                // [CH][RC::LEN]
+  double *aux = lds + CH * RC::LEN; // [CH][2+DIM]: (unused), sigma/2, -normal/2
   constexpr int AUXN = 2 + DIM;
 
   double lo[DIM], h[DIM];
@@ -412,9 +513,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   // ---- volume term ---------------------------------------------------------------------------
   {
     const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
-    for (int64_t base = qb; base < qe; base += PDH_WAVE)
+    for (int64_t base = qb; base < qe; base += CH)
       {
-        const int cnt = (int)((qe - base < PDH_WAVE) ? (qe - base) : PDH_WAVE);
+        const int cnt = (int)((qe - base < CH) ? (qe - base) : CH);
         __syncthreads();
         {
           double x[DIM], w = 0.0;
@@ -427,19 +528,30 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
           else
             for (int c = 0; c < DIM; ++c)
               x[c] = lo[c];
-          eval_point_record<DIM, N1D>(P.tab, lo, h, x, sqrt(w), rec + lane * RC::LEN);
+          if (lane < CH)
+            eval_point_record<DIM, N1D>(P.tab, lo, h, x, sqrt(w), rec + lane * RC::LEN);
         }
         __syncthreads();
         const int nsteps = (cnt + 3) >> 2;
+        FragRaw<DIM> raw[NT]; // table entries of the step being computed, loaded one step ahead
+        {
+          const char *rb = reinterpret_cast<const char *>(rec + kq * RC::LEN);
+          static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
+        }
         for (int step = 0; step < nsteps; ++step)
           {
-            const int pt = 4 * step + kq;
-            const char *rb = reinterpret_cast<const char *>(rec + pt * RC::LEN);
             double phi[NT], dphi[NT][DIM];
             static_for<0, NT>([&](auto a_) {
               constexpr int a = a_;
-              frag_eval<DIM>(rb, lb.off[a], phi[a], dphi[a]);
+              raw[a].eval(phi[a], dphi[a]);
             });
+            {
+              // prefetch the next step (the last iteration re-reads its own point: always a valid record)
+              const int ptn = 4 * ((step + 1 < nsteps) ? step + 1 : step) + kq;
+              const char *rb = reinterpret_cast<const char *>(rec + ptn * RC::LEN);
+              static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
+            }
+            RotSet<NT> RG[DIM];
             static_for<0, DIM>([&](auto c_) {
               constexpr int c = c_;
               double G[NT];
@@ -447,16 +559,22 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
                 constexpr int a = a_;
                 G[a] = dphi[a][c];
               });
-              product<NT, LB, true>(acc, G, G, rt); // sum_q (sqrt(w) d_c phi_i)(sqrt(w) d_c phi_j)
+              make_rot<NT, ROT_SYM>(G, rt, RG[c]);
+            });
+            static_for<0, DIM>([&](auto c_) {
+              constexpr int c = c_;
+              product<NT, LB, true>(acc, RG[c], RG[c]); // sum_q (sqrt(w) d_c phi_i)(sqrt(w) d_c phi_j)
             });
             if constexpr (REACT) // compile-time: a run-time branch here makes hipcc double the accumulators
               {
-                double A[NT];
+                RotSet<NT> RP, RA;
+                make_rot<NT, ROT_SYM>(phi, rt, RP);
                 static_for<0, NT>([&](auto a_) {
                   constexpr int a = a_;
-                  A[a] = P.reaction_c * phi[a];
+                  RA.v[0][a] = P.reaction_c * RP.v[0][a];
+                  RA.v[1][a] = P.reaction_c * RP.v[1][a];
                 });
-                product<NT, LB, true>(acc, A, phi, rt);
+                product<NT, LB, true>(acc, RA, RP);
               }
           }
       }
@@ -465,9 +583,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   // ---- own-side face terms (all faces of the polytope, boundary included) ----------------------
   {
     const int64_t pb = P.ap_ptr[slot], pe = P.ap_ptr[slot + 1];
-    for (int64_t base = pb; base < pe; base += PDH_WAVE)
+    for (int64_t base = pb; base < pe; base += CH)
       {
-        const int cnt = (int)((pe - base < PDH_WAVE) ? (pe - base) : PDH_WAVE);
+        const int cnt = (int)((pe - base < CH) ? (pe - base) : CH);
         __syncthreads();
         {
           double x[DIM], nr[DIM], w = 0.0, sg = 0.0;
@@ -487,34 +605,51 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
                 x[c] = lo[c];
                 nr[c] = 0.0;
               }
-          eval_point_record<DIM, N1D>(P.tab, lo, h, x, sqrt(w), rec + lane * RC::LEN);
-          aux[lane * AUXN + 1] = 0.5 * sg;
-          for (int c = 0; c < DIM; ++c)
-            aux[lane * AUXN + 2 + c] = -0.5 * nr[c];
+          if (lane < CH)
+            {
+              eval_point_record<DIM, N1D>(P.tab, lo, h, x, sqrt(w), rec + lane * RC::LEN);
+              aux[lane * AUXN + 1] = 0.5 * sg;
+              for (int c = 0; c < DIM; ++c)
+                aux[lane * AUXN + 2 + c] = -0.5 * nr[c];
+            }
         }
         __syncthreads();
         const int nsteps = (cnt + 3) >> 2;
+        FragRaw<DIM> raw[NT];
+        double hs, nh[DIM]; // sigma/2, -n/2 of the step being computed
+        {
+          const char *rb = reinterpret_cast<const char *>(rec + kq * RC::LEN);
+          static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
+          hs = aux[kq * AUXN + 1];
+          for (int c = 0; c < DIM; ++c)
+            nh[c] = aux[kq * AUXN + 2 + c];
+        }
         for (int step = 0; step < nsteps; ++step)
           {
-            const int pt = 4 * step + kq;
-            const char *rb = reinterpret_cast<const char *>(rec + pt * RC::LEN);
-            const double hs = aux[pt * AUXN + 1];
-            double nh[DIM]; // -n/2
-            for (int c = 0; c < DIM; ++c)
-              nh[c] = aux[pt * AUXN + 2 + c];
             double Phi[NT], U[NT];
             static_for<0, NT>([&](auto a_) {
               constexpr int a = a_;
               double ph, dp[DIM];
-              frag_eval<DIM>(rb, lb.off[a], ph, dp);
+              raw[a].eval(ph, dp);
               double u = hs * ph;
               for (int c = 0; c < DIM; ++c)
                 u += nh[c] * dp[c];
               Phi[a] = ph; // sqrt(w) phi
               U[a] = u;    // sqrt(w) (-1/2 grad phi . n + sigma/2 phi)
             });
-            product<NT, LB, true>(acc, U, Phi, rt);
-            product<NT, LB, true>(acc, Phi, U, rt);
+            {
+              const int ptn = 4 * ((step + 1 < nsteps) ? step + 1 : step) + kq;
+              const char *rb = reinterpret_cast<const char *>(rec + ptn * RC::LEN);
+              static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
+              hs = aux[ptn * AUXN + 1];
+              for (int c = 0; c < DIM; ++c)
+                nh[c] = aux[ptn * AUXN + 2 + c];
+            }
+            RotSet<NT> RU, RPhi;
+            make_rot<NT, ROT_SYM>(U, rt, RU);
+            make_rot<NT, ROT_SYM>(Phi, rt, RPhi);
+            product<NT, LB, true>(acc, RU, RPhi);
+            product<NT, LB, true>(acc, RPhi, RU);
           }
       }
   }
@@ -526,23 +661,14 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   const int64_t rbase = P.row_base[slot];
   const int rlen = P.row_len[slot];
   const int L = P.diag_L[slot];
+  StripMap<NT, LB> sm;
+  sm.init(lane);
   static_for<0, NT>([&](auto s_) {
     constexpr int s = s_;
     __syncthreads();
-    fill_strip<NT, LB, true, false, s>(acc, strip, ncol_pad, lane, n);
+    fill_strip<NT, LB, true, false, s>(acc, strip, ncol_pad, sm, n);
     __syncthreads();
-    const int rows = (n - 16 * s < 16) ? (n - 16 * s) : 16;
-    for (int idx = lane; idx < rows * n; idx += PDH_WAVE)
-      {
-        const int rr = idx / n, c = idx - rr * n;
-        const int R = 16 * s + rr;
-        int pos;
-        if (P.diag_first)
-          pos = (c == R) ? 0 : (L + c + (c < R ? 1 : 0));
-        else
-          pos = L + c;
-        P.values[rbase + (int64_t)R * rlen + pos] = strip[rr * ncol_pad + c];
-      }
+    store_strip<true>(P.values, rbase, rlen, L, P.diag_first, strip, ncol_pad, s, n, lane);
   });
 }
 
@@ -647,14 +773,16 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
             B1[a] = ph; // sqrt(w) phi^Q
             B2[a] = g;  // sqrt(w) (-1/2 grad phi^Q . n_P)
           });
-          product<NT, LB, false>(acc, A1, B1, rt);
-          product<NT, LB, false>(acc, A2, B2, rt);
+          product_full<NT, LB>(acc, A1, B1, rt);
+          product_full<NT, LB>(acc, A2, B2, rt);
         }
     }
 
   const int n = P.n;
   const int ncol_pad = 16 * NT + 2;
   double *strip = lds;
+  StripMap<NT, LB> sm;
+  sm.init(lane);
   {
     const int64_t rbase = P.row_base[slot];
     const int rlen = P.row_len[slot];
@@ -662,15 +790,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
     static_for<0, NT>([&](auto s_) {
       constexpr int s = s_;
       __syncthreads();
-      fill_strip<NT, LB, false, false, s>(acc, strip, ncol_pad, lane, n);
+      fill_strip<NT, LB, false, false, s>(acc, strip, ncol_pad, sm, n);
       __syncthreads();
-      const int rows = (n - 16 * s < 16) ? (n - 16 * s) : 16;
-      for (int idx = lane; idx < rows * n; idx += PDH_WAVE)
-        {
-          const int rr = idx / n, c = idx - rr * n;
-          const int R = 16 * s + rr;
-          P.values[rbase + (int64_t)R * rlen + pos0 + c] = strip[rr * ncol_pad + c];
-        }
+      store_strip<false>(P.values, rbase, rlen, pos0, 0, strip, ncol_pad, s, n, lane);
     });
   }
   // A[Q,P] = A[P,Q]^T, written into Q's rows when this context owns them
@@ -683,15 +805,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
       static_for<0, NT>([&](auto s_) {
         constexpr int s = s_;
         __syncthreads();
-        fill_strip<NT, LB, false, true, s>(acc, strip, ncol_pad, lane, n);
+        fill_strip<NT, LB, false, true, s>(acc, strip, ncol_pad, sm, n);
         __syncthreads();
-        const int rows = (n - 16 * s < 16) ? (n - 16 * s) : 16;
-        for (int idx = lane; idx < rows * n; idx += PDH_WAVE)
-          {
-            const int rr = idx / n, c = idx - rr * n;
-            const int R = 16 * s + rr;
-            P.values[qbase + (int64_t)R * qlen + post + c] = strip[rr * ncol_pad + c];
-          }
+        store_strip<false>(P.values, qbase, qlen, post, 0, strip, ncol_pad, s, n, lane);
       });
     }
 }
@@ -699,7 +815,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
 // LDS bytes needed by the two kernels (host side helper).
 inline size_t lds_bytes_diag(int dim, int n1d, int nt)
 {
-  const size_t recs = (size_t)PDH_WAVE * (dim * n1d * 2 + 2 + 2 + dim) * sizeof(double);
+  const size_t recs = (size_t)32 * (dim * n1d * 2 + 2 + 2 + dim) * sizeof(double); // 32-point chunks
   const size_t strip = (size_t)16 * (16 * nt + 2) * sizeof(double);
   return recs > strip ? recs : strip;
 }
