@@ -485,9 +485,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   if (slot >= n_owned)
     return;
   const int agg = P.own_agg[slot];
-  // 32-point chunks: 8.4 KB of LDS per wave (the output strip) instead of 15.9 KB, so that LDS does not cap
-  // the CU below 3 waves per SIMD; lanes 32-63 idle during the (short) point phase.
-  constexpr int CH = 32;
+  // Points per chunk.  Large blocks (NT >= 3) run at 2 waves per SIMD (register-limited): 64-point chunks
+  // (one point per lane in the point phase, 15.9 KB of LDS per wave at n1d = 4, DIM = 3 = 10 waves per CU).
+  // Small blocks reach 4-5 waves per SIMD, where LDS would be the cap: 32-point chunks (measured faster).
+  constexpr int CH = (NT >= 3) ? PDH_WAVE : 32;
   double *rec = lds;                // [CH][RC::LEN]
   double *aux = lds + CH * RC::LEN; // [CH][2+DIM]: (unused), sigma/2, -normal/2
   constexpr int AUXN = 2 + DIM;
@@ -815,7 +816,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
 // LDS bytes needed by the two kernels (host side helper).
 inline size_t lds_bytes_diag(int dim, int n1d, int nt)
 {
-  const size_t recs = (size_t)32 * (dim * n1d * 2 + 2 + 2 + dim) * sizeof(double); // 32-point chunks
+  const size_t recs = (size_t)(nt >= 3 ? PDH_WAVE : 32) * (dim * n1d * 2 + 2 + 2 + dim) * sizeof(double); // CH-point chunks
   const size_t strip = (size_t)16 * (16 * nt + 2) * sizeof(double);
   return recs > strip ? recs : strip;
 }

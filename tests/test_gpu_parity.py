@@ -152,3 +152,17 @@ def test_cpp_examples_run():
     out = subprocess.run([os.path.join(root, "examples", "poisson")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Assembled DoF/s" in out.stdout
+
+
+def test_poisson_output_L2_error_with_gpu_matrix():
+    """test/polydeal/poisson.output ('L2 error:0.00647702', printed by the reference itself): same pipeline
+    as tests/test_oracle_golden.py::test_poisson_output_L2_error but with the matrix assembled by the HIP path."""
+    from test_oracle_golden import _poisson_test_setup, poisson_l2_error
+
+    grid, ah, var = _poisson_test_setup()
+    kw = flatten(ah, var, diag_first=False)
+    vals = gpu_values(kw)
+    _, _, ref = po.assemble_csr(ah, var, diag_first=False)
+    assert np.max(np.abs(vals - ref)) <= TOL * np.max(np.abs(ref))
+    err = poisson_l2_error(grid, ah, kw["rowptr"], kw["colind"], vals)
+    assert "L2 error:" + gc.fmt(err) == gc.golden_lines("poisson.output")[0]

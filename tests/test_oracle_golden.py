@@ -209,3 +209,50 @@ def test_exact_solution_reproduced_on_distorted_grid(fe_cls, p):
         err += np.sum((fv["val"] @ u[ah.dof_indices(P)] - u_ex(fv["x"])) ** 2 * fv["JxW"])
     assert np.sqrt(err) < 1e-12
     assert np.max(np.abs(A - A.T)) < 1e-11 * np.max(np.abs(A))
+
+
+def _poisson_test_setup():
+    """test/polydeal/poisson.cc:122-241: [-1,1]^2, refine_global(6), 7 two-cell agglomerates + singletons,
+    FE_DGQ(1), QGauss(3), penalty 20, hf = edge length of the master cell (:321), index()<index()."""
+    grid = po.hyper_cube_refined(2, -1.0, 1.0, 6)
+    ah = po.AgglomerationHandler(grid)
+    gc.define_with_singletons(ah, grid.n_cells, gc.GROUPS_POLY_ITER)
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(po.FE_DGQ(2, 1))
+    hf = 2.0 / 64
+    var = po.SipVariant("test/poisson.cc", 20.0 / hf, "index", "one")
+    return grid, ah, var
+
+
+def poisson_l2_error(grid, ah, rowptr, colind, values):
+    """RHS (poisson.cc:286-303), direct solve (:492-497), interpolate_to_fine_grid + integrate_difference with
+    QGauss(1) (:505-523): the number the reference prints as 'L2 error:0.00647702' (poisson.output)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    pi = np.pi
+    b = np.zeros(ah.n_dofs)
+    for P in range(ah.n_agglomerates):
+        fv = ah.reinit(P)
+        f = 8 * pi * pi * np.sin(2 * pi * fv["x"][:, 0]) * np.sin(2 * pi * fv["x"][:, 1])
+        b[ah.dof_indices(P)] += np.einsum("qi,q->i", fv["val"], f * fv["JxW"])
+    A = sp.csr_matrix((values, colind, rowptr), shape=(ah.n_dofs, ah.n_dofs))
+    u = spla.spsolve(A.tocsc(), b)
+    err2 = 0.0
+    for P in range(ah.n_agglomerates):
+        coef = u[ah.dof_indices(P)]
+        for cell in ah.get_agglomerate(P):
+            V = grid.vertices[cell]  # 4 vertices: nodal interpolation onto FE_DGQ(1) of the fine cell
+            val, _ = ah.fe.shape(ah.real_to_unit(P, V))
+            uh_mid = np.mean(val @ coef)  # bilinear interpolant at the midpoint (QGauss(1))
+            mid = V.mean(axis=0)
+            h2 = (V[1, 0] - V[0, 0]) * (V[2, 1] - V[0, 1])
+            err2 += h2 * (uh_mid - np.sin(2 * pi * mid[0]) * np.sin(2 * pi * mid[1])) ** 2
+    return np.sqrt(err2)
+
+
+def test_poisson_output_L2_error():
+    """End-to-end known answer produced by the reference itself: test/polydeal/poisson.output."""
+    grid, ah, var = _poisson_test_setup()
+    rp, ci, va = po.assemble_csr(ah, var, diag_first=False)
+    err = poisson_l2_error(grid, ah, rp, ci, va)
+    assert "L2 error:" + gc.fmt(err) == gc.golden_lines("poisson.output")[0]
