@@ -112,12 +112,36 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
                 t_setup=t_setup, nnz=flat.nnz, checksum=chk)
 
 
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box gives a
+    1-GPU job a share of the host's cores; os.cpu_count() reports all of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(pa, args, basis):
     """Reference-shaped C restatement (oracle/sip_ref.c) timed on the host cores on a bounded sample:
     same FE / rules / variant / block size, fewer polytopes (cost per polytope is size-independent).
     A 1-core calibration run sizes the two samples to about args.cpu_seconds of CPU wall time each."""
     from oracle import sip_ref
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     nthreads = max(1, min(cores, sip_ref.max_threads()))
 
     def run(nb, thr):

@@ -45,7 +45,7 @@ constexpr int invalid_index = -1;
 // ---------------------------------------------------------------------------------------------------
 // 1-D Gauss-Legendre rule on [0,1]  (QGauss<1>(n))  [deal.II]
 // ---------------------------------------------------------------------------------------------------
-inline void qgauss_1d(int n, std::vector<double> &x, std::vector<double> &w)
+inline void qgauss_1d_compute(int n, std::vector<double> &x, std::vector<double> &w)
 {
   x.assign(n, 0.0);
   w.assign(n, 0.0);
@@ -83,6 +83,21 @@ inline void qgauss_1d(int n, std::vector<double> &x, std::vector<double> &w)
       x[i] = (double)(0.5L * (t + 1.0L));
       w[i] = (double)(1.0L / ((1 - t * t) * dp * dp)); // = 2/((1-t^2)P'^2) / 2
     }
+}
+
+// cached per thread: the rule is requested once per sub-cell by the quadrature helpers below
+inline void qgauss_1d(int n, std::vector<double> &x, std::vector<double> &w)
+{
+  thread_local std::map<int, std::pair<std::vector<double>, std::vector<double>>> cache;
+  auto it = cache.find(n);
+  if (it == cache.end())
+    {
+      std::vector<double> cx, cw;
+      qgauss_1d_compute(n, cx, cw);
+      it = cache.emplace(n, std::make_pair(cx, cw)).first;
+    }
+  x = it->second.first;
+  w = it->second.second;
 }
 
 // ---------------------------------------------------------------------------------------------------

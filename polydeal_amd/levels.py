@@ -1,0 +1,30 @@
+"""Per-level SIP assembly for agglomerated multigrid hierarchies.
+
+The reference builds one AgglomerationHandler per R-tree level and assembles the level operator with the same
+hot path (examples/simplex_agglomerated_multigrid.cc:378-390 calls PolyUtils::assemble_dg_matrix once per
+level; include/poly_utils.h:1761-1862 builds the level handlers).  On structured grids the R-tree levels are
+exactly blocks of 2^k cells per direction (test/polydeal/rtree_mesh.output, 3DRtree.output), which is what
+`block_hierarchy` produces; each level is assembled by the same HIP kernels."""
+from __future__ import annotations
+
+from .handler import AgglomerationHandler, BackgroundGrid, FiniteElement, SipVariant, assemble_dg_matrix
+
+
+def block_hierarchy(grid: BackgroundGrid, fe: FiniteElement, blocks, n_q_points_1d=None):
+    """One handler per level; `blocks` = cells per direction of a polytope on each level, coarse to fine
+    (e.g. [8, 4, 2] on a 64^3 grid gives 8^3, 16^3, 32^3 polytopes)."""
+    nq = n_q_points_1d or fe.degree + 1
+    levels = []
+    for b in blocks:
+        ah = AgglomerationHandler(grid)
+        ah.define_block_agglomerates(b)
+        ah.initialize_fe_values(nq, nq)
+        ah.distribute_agglomerated_dofs(fe)
+        levels.append(ah)
+    return levels
+
+
+def assemble_levels(levels, fe: FiniteElement, variant: SipVariant | None = None, diag_first=True, device=0):
+    """[(rowptr, colind, values)] - the 'V-cycle assembly' of BASELINE.json configs[4]: one
+    assemble_dg_matrix per level."""
+    return [assemble_dg_matrix(fe, ah, variant, diag_first, device) for ah in levels]

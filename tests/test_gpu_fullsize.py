@@ -1,0 +1,104 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent identities (the oracle cannot assemble these
+sizes in seconds): for a globally continuous v the jump terms vanish, so with Nitsche boundary terms on the
+unit cube [0,1]^d and uniform penalty sigma
+    v = 1   : A v = 0 on rows of interior polytopes,  v^T A v = sigma * |dOmega| = 2 d sigma
+    v = x_0 : v^T A v = int |grad x|^2 - 2 int_dO x d_n x + sigma int_dO x^2 = -1 + sigma (1 + (2d-2)/3)
+These touch every kernel output (diagonal blocks, both coupling blocks of every face, CSR placement incl. the
+deal.II diagonal-first layout).  The same identities are what test/polydeal/poisson_sanity_check_01..03 print
+(there with boundary terms dropped)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import polydeal_amd as pa
+
+pytestmark = pytest.mark.gpu
+
+
+def coefficient_vectors(ah, fe):
+    """Coefficients of v=1 and v=x_0 in every polytope's basis on its bounding box."""
+    n = fe.n_dofs_per_cell
+    nA = ah.n_agglomerates
+    one = np.zeros((nA, n))
+    x0 = np.zeros((nA, n))
+    lo = np.zeros(nA)
+    hi = np.zeros(nA)
+    off = np.zeros(nA, dtype=np.int64)
+    for P in range(nA):
+        l, h = ah.bbox(P)
+        lo[P], hi[P] = l[0], h[0]
+        off[P] = ah.dof_indices(P)[0]
+    if fe.basis == pa.PDH_BASIS_DGQ:
+        p = fe.degree
+        from oracle.polydeal_oracle import gauss_lobatto_nodes  # node positions only (test infrastructure)
+        nodes = gauss_lobatto_nodes(p)
+        i0 = np.arange(n) % (p + 1)  # x index, lexicographic x fastest
+        one[:] = 1.0
+        x0[:] = lo[:, None] + nodes[i0][None, :] * (hi - lo)[:, None]
+    else:
+        # Legendre: phi_0 = 1; the function with multi-index e_0 is index 1: sqrt(3)(2 xhat - 1)
+        one[:, 0] = 1.0
+        x0[:, 0] = 0.5 * (lo + hi)
+        x0[:, 1] = (hi - lo) / (2.0 * np.sqrt(3.0))
+    v1 = np.zeros(ah.n_dofs)
+    vx = np.zeros(ah.n_dofs)
+    idx = off[:, None] + np.arange(n)[None, :]
+    v1[idx] = one
+    vx[idx] = x0
+    return v1, vx, off
+
+
+def run_identities(dim, cells, block, fe, nq):
+    lg = cells.bit_length() - 1
+    grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, lg)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_block_agglomerates(block)
+    ah.initialize_fe_values(nq, nq)
+    ah.distribute_agglomerated_dofs(fe)
+    var = pa.SipVariant.poisson_example(fe)
+    rp, ci, vals = pa.assemble_dg_matrix(fe, ah, var, diag_first=True)
+    assert np.all(np.isfinite(vals))
+    A = sp.csr_matrix((vals, ci, rp), shape=(ah.n_dofs, ah.n_dofs))
+    sigma = var.penalty_constant / ah.diameter(0)
+    v1, vx, off = coefficient_vectors(ah, fe)
+    y1 = A @ v1
+    scale = float(np.max(np.abs(vals)))
+    # interior polytopes: all bbox faces strictly inside the domain
+    nb = cells // block
+    n = fe.n_dofs_per_cell
+    interior = np.ones(ah.n_agglomerates, dtype=bool)
+    for P in range(ah.n_agglomerates):
+        l, h = ah.bbox(P)
+        if np.min(l) < 1e-12 or np.max(h) > 1 - 1e-12:
+            interior[P] = False
+    rows = (off[interior][:, None] + np.arange(n)[None, :]).ravel()
+    assert interior.sum() == (nb - 2) ** dim
+    assert np.max(np.abs(y1[rows])) <= 1e-12 * scale * n
+    q1 = float(v1 @ y1)
+    qx = float(vx @ (A @ vx))
+    assert abs(q1 - 2 * dim * sigma) <= 1e-11 * 2 * dim * sigma
+    exact_x = -1.0 + sigma * (1.0 + (2 * dim - 2) / 3.0)
+    assert abs(qx - exact_x) <= 1e-11 * abs(exact_x)
+    # symmetry on a sample of rows (full transpose is too heavy at this size)
+    sample = np.unique(np.linspace(0, ah.n_dofs - 1, 400).astype(np.int64))
+    S = A[sample][:, sample]
+    assert abs(S - S.T).max() <= 1e-12 * scale
+    return ah.n_dofs, len(vals)
+
+
+def test_config2_2d_p2_4096_polytopes():
+    """BASELINE.json configs[1]: 2-D unit square, 128^2 cells, 4096 polytopes of 2x2, p=2 (both bases)."""
+    assert run_identities(2, 128, 2, pa.FE_AggloDGP(2, 2), 3)[0] == 24576
+    assert run_identities(2, 128, 2, pa.FE_DGQ(2, 2), 3)[0] == 36864
+
+
+def test_config3_3d_p3_32768_polytopes_dgp():
+    """BASELINE.json configs[2] with FE_AggloDGP(3) (what examples/poisson.cc instantiates): 655 360 dofs."""
+    n_dofs, nnz = run_identities(3, 64, 2, pa.FE_AggloDGP(3, 3), 4)
+    assert n_dofs == 655360 and nnz == 89292800
+
+
+def test_config3_3d_p3_32768_polytopes_dgq():
+    """BASELINE.json configs[2] with FE_DGQ(3), (p+1)^3 = 64 dofs per polytope: the bench workload itself."""
+    n_dofs, nnz = run_identities(3, 64, 2, pa.FE_DGQ(3, 3), 4)
+    assert n_dofs == 2097152 and nnz == 914358272

@@ -166,3 +166,28 @@ def test_poisson_output_L2_error_with_gpu_matrix():
     assert np.max(np.abs(vals - ref)) <= TOL * np.max(np.abs(ref))
     err = poisson_l2_error(grid, ah, kw["rowptr"], kw["colind"], vals)
     assert "L2 error:" + gc.fmt(err) == gc.golden_lines("poisson.output")[0]
+
+
+def test_multilevel_block_hierarchy():
+    """configs[4] stand-in (meshes/piston_3.inp is not in the reference snapshot): R-tree-like block levels
+    of a jittered 16^3 grid, one assemble_dg_matrix per level, each checked against the oracle."""
+    import polydeal_amd as pa
+    from polydeal_amd.levels import assemble_levels, block_hierarchy
+
+    grid = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 3).distort(0.2, seed=7)
+    fe = pa.FE_DGQ(3, 1)
+    levels = block_hierarchy(grid, fe, [4, 2, 1])
+    mats = assemble_levels(levels, fe)
+    assert [ah.n_agglomerates for ah in levels] == [8, 64, 512]
+    og = po.hyper_cube_refined(3, 0.0, 1.0, 3)
+    for c in range(og.n_cells):
+        og.vertices[c] = grid.cell_vertices(c)
+    for b, (rp, ci, vals) in zip([4, 2, 1], mats):
+        oah = po.AgglomerationHandler(og)
+        for g in po.block_agglomerates(og, b):
+            oah.define_agglomerate(g)
+        oah.initialize_fe_values(2, 2)
+        oah.distribute_agglomerated_dofs(po.FE_DGQ(3, 1))
+        orp, oci, ref = po.assemble_csr(oah, po.variant_assemble_dg_matrix())
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+        assert np.max(np.abs(vals - ref)) <= TOL * np.max(np.abs(ref))
