@@ -102,6 +102,15 @@ int pdh_assemble_sip(pdh_ctx *ctx, const pdh_problem *problem, double *values);
 int pdh_assemble_sip_local(pdh_ctx *ctx, const pdh_problem *problem, int32_t row_begin, int32_t row_end,
                            double *values);
 
+/* Right-hand side of the SIP Poisson problem for the resident problem, i.e. what the
+ * callers assemble in the same loops as the matrix (examples/poisson.cc:745-759, 788-828):
+ *   rhs_i(P) = sum_q phi_i f(x_q) JxW  +  sum_{q on boundary faces} (sigma g phi_i - grad phi_i . n g) JxW
+ * f_vol : [Nq_tot]  f sampled at the volume quadrature points, in the order of vq_x; NULL = no volume term
+ * g_bdry: [Nqf_tot] Dirichlet datum sampled at the face quadrature points, in the order of fq_x (only the
+ *         entries of boundary faces are read); NULL = homogeneous
+ * rhs   : [row_end-row_begin] host output for the owned rows, overwritten.  Rows are in dof order.      */
+int pdh_assemble_rhs(pdh_ctx *ctx, const double *f_vol, const double *g_bdry, double *rhs);
+
 /* Access to device-resident results and synchronisation. */
 int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values);
 int pdh_synchronize(pdh_ctx *ctx);

@@ -750,6 +750,25 @@ def assemble_csr(ah: AgglomerationHandler, var: SipVariant, diag_first: bool = T
     return rowptr, colind, values
 
 
+def assemble_rhs(ah: AgglomerationHandler, var: SipVariant, f=None, g=None):
+    """Right-hand side as the callers assemble it next to the matrix (examples/poisson.cc:745-759, 788-828):
+    volume sum_q phi_i f JxW and Nitsche boundary sum_q (sigma g phi_i - grad phi_i . n g) JxW."""
+    b = np.zeros(ah.n_dofs)
+    for P in range(ah.n_agglomerates):
+        idx = ah.dof_indices(P)
+        if f is not None:
+            fv = ah.reinit(P)
+            b[idx] += np.einsum("qi,q->i", fv["val"], f(fv["x"]) * fv["JxW"])
+        if g is not None and var.boundary != "zero":
+            for fc in range(ah.n_faces[P]):
+                if ah.at_boundary(P, fc):
+                    ff = ah.reinit_face(P, fc)
+                    sig = face_sigma(ah, var, P)
+                    gn = np.einsum("qic,qc->qi", ff["grad"], ff["normal"])
+                    b[idx] += np.einsum("qi,q->i", sig * ff["val"] - gn, g(ff["x"]) * ff["JxW"])
+    return b
+
+
 def csr_to_dense(rowptr, colind, values, n):
     A = np.zeros((n, n))
     for r in range(n):

@@ -43,7 +43,7 @@ EXPORTS = [
     "pdh_create", "pdh_destroy", "pdh_last_error", "pdh_set_problem", "pdh_set_problem_local",
     "pdh_assemble_device", "pdh_assemble", "pdh_assemble_sip", "pdh_assemble_sip_local",
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
-    "pdh_problem_stats", "pdh_check_problem", "pdh_version",
+    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs",
 ]
 
 _lib = None
@@ -71,6 +71,7 @@ def load_library():
     lib.pdh_assemble.argtypes = [C.c_void_p, C.c_void_p]
     lib.pdh_assemble_sip.argtypes = [C.c_void_p, P(pdh_problem), C.c_void_p]
     lib.pdh_assemble_sip_local.argtypes = [C.c_void_p, P(pdh_problem), C.c_int32, C.c_int32, C.c_void_p]
+    lib.pdh_assemble_rhs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
     lib.pdh_stream.argtypes = [C.c_void_p]
@@ -153,6 +154,16 @@ class Context:
     def assemble(self):
         out = np.empty(self.n_values, dtype=np.float64)
         self._chk(self.lib.pdh_assemble(self.h, out.ctypes.data))
+        return out
+
+    def assemble_rhs(self, f_vol=None, g_bdry=None):
+        """rhs of the owned rows; f_vol / g_bdry sampled at the caller's volume / face quadrature points."""
+        n_rows = self.stats()["n_owned_agg"] * self.stats()["dofs_per_cell"]
+        out = np.empty(n_rows, dtype=np.float64)
+        fv = None if f_vol is None else np.ascontiguousarray(f_vol, dtype=np.float64)
+        gb = None if g_bdry is None else np.ascontiguousarray(g_bdry, dtype=np.float64)
+        self._chk(self.lib.pdh_assemble_rhs(self.h, None if fv is None else fv.ctypes.data,
+                                            None if gb is None else gb.ctypes.data, out.ctypes.data))
         return out
 
     def device_values(self):

@@ -27,6 +27,9 @@ PDH_DECL(0) PDH_DECL(1) PDH_DECL(2) PDH_DECL(3) PDH_DECL(4) PDH_DECL(5) PDH_DECL
 #undef PDH_DECL
 }
 
+extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int count, const double *f_vol,
+                                     const double *g_face, double *rhs, hipStream_t stream);
+
 static pdh_launch_fn g_launch[PDH_N_GROUPS] = {pdh_launch_g0, pdh_launch_g1, pdh_launch_g2, pdh_launch_g3,
                                                pdh_launch_g4, pdh_launch_g5, pdh_launch_g6, pdh_launch_g7};
 
@@ -52,6 +55,11 @@ struct pdh_ctx
   int n_owned = 0, n_items = 0, NT = 0, LB = 0, group = -1;
   size_t lds_diag = 0, lds_off = 0;
   int64_t n_values = 0, n_vq = 0, n_ap = 0;
+  // host-side maps from the caller's quadrature arrays to the packed device layout (for pdh_assemble_rhs)
+  std::vector<int64_t> vq_src;                       // per owned slot: first volume point in the caller's arrays
+  struct FaceRun { int64_t ap_begin, fq_begin; int32_t count; int32_t boundary; };
+  std::vector<FaceRun> face_runs;
+  int64_t n_rows_owned = 0;
   bool profiling = false;
   std::vector<hipEvent_t> events; // 3 per profiled launch: before k_diag, between, after k_offdiag
   size_t ev_used = 0;
@@ -161,9 +169,11 @@ struct Packed
   int n = 0, n1d = 0, NT = 0, LB = 0;
   std::vector<int32_t> midx;
   PdhBasisTab tab;
-  std::vector<int32_t> own_agg, row_len, diag_L, it_own, it_nbr, it_pcnt, it_pos, it_nbr_slot, it_pos_t;
+  std::vector<int32_t> own_agg, own_row, row_len, diag_L, it_own, it_nbr, it_pcnt, it_pos, it_nbr_slot, it_pos_t;
   std::vector<int64_t> row_base, vq_ptr, ap_ptr, it_pbeg;
   std::vector<double> vq_x, vq_w, ap_x, ap_n, ap_wself, ap_wcross, ap_sig;
+  std::vector<int64_t> vq_src, run_ap, run_fq;
+  std::vector<int32_t> run_cnt, run_bdry;
   int64_t n_values = 0;
 };
 
@@ -270,6 +280,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
         continue;
       const int slot = (int)K.own_agg.size();
       K.own_agg.push_back(a);
+      K.own_row.push_back(off - row_begin);
       // coupled blocks, ascending by dof offset (reference :954-975)
       blocks.clear();
       blocks.emplace_back(off, a);
@@ -313,6 +324,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
               }
         }
       // volume points
+      K.vq_src.push_back(p->vq_ptr[a]);
       for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q)
         K.vq_w.push_back(p->vq_w[q]);
       K.vq_ptr.push_back((int64_t)K.vq_w.size());
@@ -324,6 +336,10 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           const int other = side0 ? p->face_out[f] : p->face_in[f];
           const int64_t qb = p->fq_ptr[f], qe = p->fq_ptr[f + 1];
           const double sig = p->face_sigma[f];
+          K.run_ap.push_back((int64_t)K.ap_wself.size());
+          K.run_fq.push_back(qb);
+          K.run_cnt.push_back((int32_t)(qe - qb));
+          K.run_bdry.push_back(other < 0 ? 1 : 0);
           if (other >= 0)
             {
               const int ooff = p->dof_offset[other];
@@ -484,6 +500,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   PDH_UP(K.ap_wcross, ap_wcross)
   PDH_UP(K.ap_sig, ap_sig)
   PDH_UP(K.own_agg, own_agg)
+  PDH_UP(K.own_row, own_row)
   PDH_UP(K.row_base, row_base)
   PDH_UP(K.row_len, row_len)
   PDH_UP(K.diag_L, diag_L)
@@ -516,6 +533,11 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   ctx->group = combo_group(p->dim, K.n1d, K.NT, K.LB);
   ctx->lds_diag = pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
   ctx->lds_off = pdh::lds_bytes_offdiag(p->dim, K.n1d, K.NT);
+  ctx->vq_src = K.vq_src;
+  ctx->face_runs.clear();
+  for (size_t r = 0; r < K.run_ap.size(); ++r)
+    ctx->face_runs.push_back({K.run_ap[r], K.run_fq[r], K.run_cnt[r], K.run_bdry[r]});
+  ctx->n_rows_owned = (int64_t)K.own_agg.size() * K.n;
   ctx->has_problem = true;
   ctx->ev_used = 0;
   return PDH_OK;
@@ -592,6 +614,66 @@ extern "C" int pdh_assemble_sip(pdh_ctx *ctx, const pdh_problem *p, double *valu
   if (!p)
     return fail(ctx, PDH_EINVAL, "problem is NULL");
   return pdh_assemble_sip_local(ctx, p, 0, p->n_rows, values);
+}
+
+extern "C" int pdh_assemble_rhs(pdh_ctx *ctx, const double *f_vol, const double *g_bdry, double *rhs)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (!ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "pdh_assemble_rhs called before pdh_set_problem");
+  if (!rhs)
+    return fail(ctx, PDH_EINVAL, "rhs is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  // repack the caller's samples into the device point order
+  std::vector<double> fv, gf;
+  double *d_f = nullptr, *d_g = nullptr, *d_rhs = nullptr;
+  auto cleanup = [&]() {
+    if (d_f)
+      (void)hipFree(d_f);
+    if (d_g)
+      (void)hipFree(d_g);
+    if (d_rhs)
+      (void)hipFree(d_rhs);
+  };
+  if (f_vol)
+    {
+      fv.resize((size_t)std::max<int64_t>(ctx->n_vq, 1));
+      std::vector<int64_t> vptr((size_t)ctx->n_owned + 1);
+      PDH_HIP(ctx, hipMemcpy(vptr.data(), ctx->dev.vq_ptr, vptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+      for (int sl = 0; sl < ctx->n_owned; ++sl)
+        for (int64_t q = vptr[sl]; q < vptr[sl + 1]; ++q)
+          fv[q] = f_vol[ctx->vq_src[sl] + (q - vptr[sl])];
+      PDH_HIP(ctx, hipMalloc((void **)&d_f, fv.size() * sizeof(double)));
+      PDH_HIP(ctx, hipMemcpy(d_f, fv.data(), fv.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+  if (g_bdry)
+    {
+      gf.assign((size_t)std::max<int64_t>(ctx->n_ap, 1), 0.0);
+      for (const auto &run : ctx->face_runs)
+        if (run.boundary)
+          for (int32_t t = 0; t < run.count; ++t)
+            gf[run.ap_begin + t] = g_bdry[run.fq_begin + t];
+      hipError_t e = hipMalloc((void **)&d_g, gf.size() * sizeof(double));
+      if (e == hipSuccess)
+        e = hipMemcpy(d_g, gf.data(), gf.size() * sizeof(double), hipMemcpyHostToDevice);
+      if (e != hipSuccess)
+        {
+          cleanup();
+          return fail(ctx, PDH_EDEVICE, std::string("rhs upload: ") + hipGetErrorString(e));
+        }
+    }
+  hipError_t e = hipMalloc((void **)&d_rhs, std::max<int64_t>(ctx->n_rows_owned, 1) * sizeof(double));
+  if (e == hipSuccess)
+    e = pdh_launch_rhs(ctx->dev.dim, ctx->dev.n1d, &ctx->dev, ctx->n_owned, d_f, d_g, d_rhs, ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(rhs, d_rhs, ctx->n_rows_owned * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess)
+    return fail(ctx, PDH_EDEVICE, std::string("pdh_assemble_rhs: ") + hipGetErrorString(e));
+  return PDH_OK;
 }
 
 extern "C" int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values)

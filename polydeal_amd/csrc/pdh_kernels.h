@@ -69,6 +69,7 @@ struct PdhDev
   const int64_t *row_base; // [n_owned] value offset of the polytope's first row
   const int32_t *row_len;  // [n_owned] entries per row
   const int32_t *diag_L;   // [n_owned] ascending column position of the own block inside the row
+  const int32_t *own_row;  // [n_owned] first dof row of the polytope, relative to the owned row range
   // coupling-block items: one per interior face with at least one owned side
   const int32_t *it_own;  // owned slot of P (the side whose packed points are used)
   const int32_t *it_nbr;  // neighbour polytope id Q

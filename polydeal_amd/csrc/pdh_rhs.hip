@@ -1,0 +1,144 @@
+// pdh_rhs.hip — right-hand-side kernel of the SIP path.
+//
+//   rhs_i(P) = sum_q phi_i f(x_q) JxW                                          reference examples/poisson.cc:745-759
+//            + sum_{q on boundary faces of P} (sigma g phi_i - grad phi_i . n g) JxW          examples/poisson.cc:788-828
+//
+// One wavefront per owned polytope, lanes = basis functions (n <= 64).  Per chunk of 64 quadrature points each
+// lane first evaluates the 1-D basis records of one POINT into LDS (same records as the matrix kernels, without
+// the sqrt(w) scaling), then every lane runs over the chunk's points and accumulates ITS function's value
+// (and normal derivative) - all lanes read the same record, different entries.  HBM-bound and tiny next to the
+// matrix kernels (2 Nq n flops per polytope).
+#include "pdh_kernels.h"
+
+namespace pdh
+{
+template <int DIM, int N1D>
+__global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_owned, const double *__restrict__ f_vol,
+                                                  const double *__restrict__ g_face, double *__restrict__ rhs)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  using RC = Rec<DIM, N1D>;
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x;
+  if (slot >= n_owned)
+    return;
+  const int agg = P.own_agg[slot];
+  double *rec = lds;                      // [64][RC::LEN]
+  double *aux = lds + PDH_WAVE * RC::LEN; // [64][1+DIM]
+  constexpr int AUXN = 1 + DIM;
+  double lo[DIM], h[DIM];
+  for (int c = 0; c < DIM; ++c)
+    {
+      lo[c] = P.bbox[(int64_t)agg * 2 * DIM + c];
+      h[c] = P.bbox[(int64_t)agg * 2 * DIM + DIM + c] - lo[c];
+    }
+  // this lane's basis function
+  const bool live = lane < P.n;
+  int off[DIM];
+  {
+    const uint32_t packed = live ? (uint32_t)P.midx[lane] : 0u;
+    for (int c = 0; c < DIM; ++c)
+      off[c] = live ? (c * N1D + (int)((packed >> (8 * c)) & 0xff)) * 2 : RC::ZERO_OFF / 8;
+  }
+  double acc = 0.0;
+
+  // volume: sum_q phi_i f JxW
+  if (f_vol)
+    {
+      const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
+      for (int64_t base = qb; base < qe; base += PDH_WAVE)
+        {
+          const int cnt = (int)((qe - base < PDH_WAVE) ? (qe - base) : PDH_WAVE);
+          __syncthreads();
+          if (lane < cnt)
+            {
+              double x[DIM];
+              for (int c = 0; c < DIM; ++c)
+                x[c] = P.vq_x[c * P.vq_stride + base + lane];
+              eval_point_record<DIM, N1D>(P.tab, lo, h, x, 1.0, rec + lane * RC::LEN);
+              aux[lane * AUXN] = f_vol[base + lane] * P.vq_w[base + lane];
+            }
+          __syncthreads();
+          for (int q = 0; q < cnt; ++q)
+            {
+              const double *r = rec + q * RC::LEN;
+              double phi = r[off[0]];
+              for (int c = 1; c < DIM; ++c)
+                phi *= r[off[c]];
+              acc += phi * aux[q * AUXN];
+            }
+        }
+    }
+
+  // Nitsche boundary terms; points of interior faces carry g = 0 (set by the host)
+  if (g_face)
+    {
+      const int64_t pb = P.ap_ptr[slot], pe = P.ap_ptr[slot + 1];
+      for (int64_t base = pb; base < pe; base += PDH_WAVE)
+        {
+          const int cnt = (int)((pe - base < PDH_WAVE) ? (pe - base) : PDH_WAVE);
+          __syncthreads();
+          if (lane < cnt)
+            {
+              double x[DIM];
+              for (int c = 0; c < DIM; ++c)
+                x[c] = P.ap_x[c * P.ap_stride + base + lane];
+              eval_point_record<DIM, N1D>(P.tab, lo, h, x, 1.0, rec + lane * RC::LEN);
+              // packed boundary points carry w = 2 JxW and sigma/2:  2w (sigma/2 g phi - 1/2 g grad phi.n)
+              const double gw = g_face[base + lane] * P.ap_wself[base + lane];
+              aux[lane * AUXN] = gw * P.ap_sig[base + lane];
+              for (int c = 0; c < DIM; ++c)
+                aux[lane * AUXN + 1 + c] = -0.5 * gw * P.ap_n[c * P.ap_stride + base + lane];
+            }
+          __syncthreads();
+          for (int q = 0; q < cnt; ++q)
+            {
+              const double *r = rec + q * RC::LEN;
+              const double *a = aux + q * AUXN;
+              double v[DIM], d[DIM];
+              for (int c = 0; c < DIM; ++c)
+                {
+                  v[c] = r[off[c]];
+                  d[c] = r[off[c] + 1];
+                }
+              double phi = v[0];
+              for (int c = 1; c < DIM; ++c)
+                phi *= v[c];
+              double s = a[0] * phi;
+              for (int g = 0; g < DIM; ++g)
+                {
+                  double t = d[g];
+                  for (int c = 0; c < DIM; ++c)
+                    if (c != g)
+                      t *= v[c];
+                  s += a[1 + g] * t;
+                }
+              acc += s;
+            }
+        }
+    }
+  if (live)
+    rhs[(int64_t)P.own_row[slot] + lane] = acc;
+}
+} // namespace pdh
+
+extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int count, const double *f_vol,
+                                     const double *g_face, double *rhs, hipStream_t stream)
+{
+  if (count <= 0)
+    return hipSuccess;
+  const dim3 grid((unsigned)count), block(PDH_WAVE);
+#define PDH_RHS_CASE(D, N)                                                                                 \
+  if (dim == D && n1d == N)                                                                                \
+    {                                                                                                      \
+      const size_t lds = (size_t)PDH_WAVE * (pdh::Rec<D, N>::LEN + 1 + D) * sizeof(double);                \
+      hipLaunchKernelGGL((pdh::k_rhs<D, N>), grid, block, lds, stream, *P, count, f_vol, g_face, rhs);      \
+      return hipGetLastError();                                                                            \
+    }
+  PDH_RHS_CASE(2, 1) PDH_RHS_CASE(2, 2) PDH_RHS_CASE(2, 3) PDH_RHS_CASE(2, 4)
+  PDH_RHS_CASE(2, 5) PDH_RHS_CASE(2, 6) PDH_RHS_CASE(2, 7) PDH_RHS_CASE(2, 8)
+  PDH_RHS_CASE(3, 1) PDH_RHS_CASE(3, 2) PDH_RHS_CASE(3, 3) PDH_RHS_CASE(3, 4)
+  PDH_RHS_CASE(3, 5) PDH_RHS_CASE(3, 6)
+#undef PDH_RHS_CASE
+  return hipErrorInvalidValue;
+}

@@ -191,3 +191,67 @@ def test_multilevel_block_hierarchy():
         orp, oci, ref = po.assemble_csr(oah, po.variant_assemble_dg_matrix())
         assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
         assert np.max(np.abs(vals - ref)) <= TOL * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("dim,lg,b,fe_cls,p,dist", [
+    (2, 3, 2, po.FE_DGQ, 1, 0.0),
+    (2, 3, 2, po.FE_AggloDGP, 3, 0.2),
+    (3, 2, 2, po.FE_DGQ, 3, 0.0),
+    (3, 2, 2, po.FE_AggloDGP, 2, 0.15),
+])
+def test_rhs_parity(dim, lg, b, fe_cls, p, dist):
+    """pdh_assemble_rhs vs the oracle: volume source + Nitsche boundary datum (examples/poisson.cc:745-759,
+    788-828), 1e-12 relative."""
+    import polydeal_amd as pa
+
+    fe = fe_cls(dim, p)
+    ah = build(dim, lg, b, fe, p + 1, distort=dist)
+    var = po.variant_poisson_example(fe)
+    f = lambda x: np.sin(2.0 * x[:, 0]) + x[:, 1] ** 2 + (x[:, -1] if dim == 3 else 0.0)
+    g = lambda x: 1.0 + x[:, 0] * x[:, 1] - 0.5 * x[:, -1]
+    kw = flatten(ah, var)
+    nq = kw["vq_x"].shape[1]
+    f_vol = f(kw["vq_x"].T)
+    g_b = g(kw["fq_x"].T)
+    prob = pa.Problem(**kw)
+    ctx = pa.Context(0)
+    ctx.set_problem(prob)
+    got = ctx.assemble_rhs(f_vol, g_b)
+    got_f = ctx.assemble_rhs(f_vol, None)
+    ctx.close()
+    ref = po.assemble_rhs(ah, var, f, g)
+    ref_f = po.assemble_rhs(ah, var, f, None)
+    assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
+    assert np.max(np.abs(got_f - ref_f)) <= TOL * np.max(np.abs(ref_f))
+
+
+def test_poisson_output_L2_error_all_on_gpu():
+    """The reference's printed 'L2 error:0.00647702' (test/polydeal/poisson.output) with BOTH the matrix and
+    the right-hand side assembled by the HIP path (solve + error evaluation on the host)."""
+    import polydeal_amd as pa
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from test_oracle_golden import _poisson_test_setup
+
+    grid, ah, var = _poisson_test_setup()
+    kw = flatten(ah, var, diag_first=False)
+    prob = pa.Problem(**kw)
+    ctx = pa.Context(0)
+    ctx.set_problem(prob)
+    vals = ctx.assemble()
+    pi = np.pi
+    xq = kw["vq_x"]
+    b = ctx.assemble_rhs(8 * pi * pi * np.sin(2 * pi * xq[0]) * np.sin(2 * pi * xq[1]), None)
+    ctx.close()
+    A = sp.csr_matrix((vals, kw["colind"], kw["rowptr"]), shape=(ah.n_dofs, ah.n_dofs))
+    u = spla.spsolve(A.tocsc(), b)
+    err2 = 0.0
+    for P in range(ah.n_agglomerates):
+        coef = u[ah.dof_indices(P)]
+        for cell in ah.get_agglomerate(P):
+            V = grid.vertices[cell]
+            val, _ = ah.fe.shape(ah.real_to_unit(P, V))
+            mid = V.mean(axis=0)
+            h2 = (V[1, 0] - V[0, 0]) * (V[2, 1] - V[0, 1])
+            err2 += h2 * (np.mean(val @ coef) - np.sin(2 * pi * mid[0]) * np.sin(2 * pi * mid[1])) ** 2
+    assert "L2 error:" + gc.fmt(np.sqrt(err2)) == gc.golden_lines("poisson.output")[0]
