@@ -125,6 +125,11 @@ int pdh_kernel_times_ms(pdh_ctx *ctx, float *ms /* [PDH_N_KERNELS] average per l
 int pdh_problem_stats(pdh_ctx *ctx, int64_t *stats /* [8]: n_owned_agg, n_offdiag_items, n_vq_points,
                         n_face_side_points, n_values, dofs_per_cell, lds_bytes_diag, lds_bytes_offdiag */);
 
+/* Executed work of one pdh_assemble_device launch: v_mfma_f64_4x4x4_4b_f64 instructions issued by k_diag and
+ * k_offdiag (512 flop each).  Smaller than the algorithmic count of SURVEY.md 8(d): only the upper tile
+ * pairs of the symmetric diagonal blocks are computed and A[Q,P] is written as A[P,Q]^T.             */
+int pdh_kernel_work(pdh_ctx *ctx, int64_t *mfma_instr /* [PDH_N_KERNELS] */);
+
 /* Host-only validation of a problem description: runs every check of pdh_set_problem_local without
  * touching a GPU (usable on a build machine).  stats as in pdh_problem_stats, may be NULL.          */
 int pdh_check_problem(const pdh_problem *problem, int32_t row_begin, int32_t row_end, int64_t *stats);

@@ -43,7 +43,7 @@ EXPORTS = [
     "pdh_create", "pdh_destroy", "pdh_last_error", "pdh_set_problem", "pdh_set_problem_local",
     "pdh_assemble_device", "pdh_assemble", "pdh_assemble_sip", "pdh_assemble_sip_local",
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
-    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs",
+    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work",
 ]
 
 _lib = None
@@ -79,6 +79,7 @@ def load_library():
     lib.pdh_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_kernel_times_ms.argtypes = [C.c_void_p, P(C.c_float), P(C.c_int)]
     lib.pdh_problem_stats.argtypes = [C.c_void_p, P(C.c_int64)]
+    lib.pdh_kernel_work.argtypes = [C.c_void_p, P(C.c_int64)]
     lib.pdh_check_problem.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, P(C.c_int64)]
     lib.pdh_version.restype = C.c_char_p
     _lib = lib
@@ -179,6 +180,12 @@ class Context:
         n = C.c_int()
         self._chk(self.lib.pdh_kernel_times_ms(self.h, ms, C.byref(n)))
         return [float(ms[0]), float(ms[1])], int(n.value)
+
+    def kernel_work(self):
+        """MFMA instructions (512 flop each) issued per launch by [k_diag, k_offdiag]."""
+        w = (C.c_int64 * 2)()
+        self._chk(self.lib.pdh_kernel_work(self.h, w))
+        return [int(w[0]), int(w[1])]
 
     def stats(self):
         st = (C.c_int64 * 8)()

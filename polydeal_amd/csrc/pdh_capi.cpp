@@ -33,6 +33,32 @@ extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int coun
 static pdh_launch_fn g_launch[PDH_N_GROUPS] = {pdh_launch_g0, pdh_launch_g1, pdh_launch_g2, pdh_launch_g3,
                                                pdh_launch_g4, pdh_launch_g5, pdh_launch_g6, pdh_launch_g7};
 
+// number of MFMA instructions one 4-point step of a product issues, from the kernels' own schedule
+template <int NT, int LB>
+static constexpr int sched_instr(bool sym)
+{
+  int c = 0;
+  for (int a = 0; a < NT; ++a)
+    for (int b = 0; b < NT; ++b)
+      for (int r = 0; r < 4; ++r)
+        if ((sym ? pdh::Sched<NT, LB>::sym_mask(a, b, r) : pdh::Sched<NT, LB>::full_mask(a, b, r)) != 0u)
+          ++c;
+  return c;
+}
+static int sched_instr_rt(int nt, int lb, bool sym)
+{
+  switch (nt * 4 + (lb - 1))
+    {
+#define PDH_C(NT, LB)                                                                              \
+  case NT * 4 + (LB - 1):                                                                          \
+    return sched_instr<NT, LB>(sym);
+      PDH_C(1, 1) PDH_C(1, 2) PDH_C(1, 3) PDH_C(1, 4) PDH_C(2, 1) PDH_C(2, 2) PDH_C(2, 3) PDH_C(2, 4)
+      PDH_C(3, 1) PDH_C(3, 2) PDH_C(3, 3) PDH_C(3, 4) PDH_C(4, 1) PDH_C(4, 2) PDH_C(4, 3) PDH_C(4, 4)
+#undef PDH_C
+    }
+  return 0;
+}
+
 // translation-unit group holding the kernels of a combo, or -1 if that combo is not instantiated
 static int combo_group(int dim, int n1d, int nt, int lb)
 {
@@ -60,6 +86,7 @@ struct pdh_ctx
   struct FaceRun { int64_t ap_begin, fq_begin; int32_t count; int32_t boundary; };
   std::vector<FaceRun> face_runs;
   int64_t n_rows_owned = 0;
+  int64_t mfma_diag = 0, mfma_offdiag = 0; // MFMA instructions per launch
   bool profiling = false;
   std::vector<hipEvent_t> events; // 3 per profiled launch: before k_diag, between, after k_offdiag
   size_t ev_used = 0;
@@ -538,6 +565,26 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   for (size_t r = 0; r < K.run_ap.size(); ++r)
     ctx->face_runs.push_back({K.run_ap[r], K.run_fq[r], K.run_cnt[r], K.run_bdry[r]});
   ctx->n_rows_owned = (int64_t)K.own_agg.size() * K.n;
+  {
+    // executed work: k-steps of 4 points per chunk (64 points in k_diag for NT >= 3, else 32; 32 in k_offdiag)
+    const int64_t i_sym = sched_instr_rt(K.NT, K.LB, true), i_full = sched_instr_rt(K.NT, K.LB, false);
+    const int ch_d = (K.NT >= 3) ? 64 : 32, ch_o = 32;
+    auto ksteps = [](int64_t npts, int ch) {
+      int64_t s = (npts / ch) * (ch / 4);
+      const int64_t rem = npts % ch;
+      return s + (rem + 3) / 4;
+    };
+    int64_t kv = 0, kf = 0, ko = 0;
+    for (size_t sl = 0; sl < K.own_agg.size(); ++sl)
+      {
+        kv += ksteps(K.vq_ptr[sl + 1] - K.vq_ptr[sl], ch_d);
+        kf += ksteps(K.ap_ptr[sl + 1] - K.ap_ptr[sl], ch_d);
+      }
+    for (size_t it = 0; it < K.it_pcnt.size(); ++it)
+      ko += ksteps(K.it_pcnt[it], ch_o);
+    ctx->mfma_diag = kv * (p->dim + (p->reaction_c != 0.0 ? 1 : 0)) * i_sym + kf * 2 * i_sym;
+    ctx->mfma_offdiag = ko * 2 * i_full;
+  }
   ctx->has_problem = true;
   ctx->ev_used = 0;
   return PDH_OK;
@@ -719,6 +766,15 @@ extern "C" int pdh_kernel_times_ms(pdh_ctx *ctx, float *ms, int *n_launches)
     ms[k] = (float)(sum[k] / (double)nl);
   if (n_launches)
     *n_launches = (int)nl;
+  return PDH_OK;
+}
+
+extern "C" int pdh_kernel_work(pdh_ctx *ctx, int64_t *mfma_instr)
+{
+  if (!ctx || !ctx->has_problem || !mfma_instr)
+    return fail(ctx, PDH_ESTATE, "no problem resident");
+  mfma_instr[0] = ctx->mfma_diag;
+  mfma_instr[1] = ctx->mfma_offdiag;
   return PDH_OK;
 }
 

@@ -255,3 +255,21 @@ def test_poisson_output_L2_error_all_on_gpu():
             h2 = (V[1, 0] - V[0, 0]) * (V[2, 1] - V[0, 1])
             err2 += h2 * (np.mean(val @ coef) - np.sin(2 * pi * mid[0]) * np.sin(2 * pi * mid[1])) ** 2
     assert "L2 error:" + gc.fmt(np.sqrt(err2)) == gc.golden_lines("poisson.output")[0]
+
+
+ALL_COMBOS = [(2, po.FE_DGQ, p) for p in range(0, 8)] + [(2, po.FE_AggloDGP, p) for p in range(1, 8)] + \
+             [(3, po.FE_DGQ, p) for p in range(0, 4)] + [(3, po.FE_AggloDGP, p) for p in range(1, 6)]
+
+
+@pytest.mark.parametrize("dim,fe_cls,p", ALL_COMBOS, ids=lambda v: getattr(v, "name", str(v)))
+def test_every_instantiated_combo(dim, fe_cls, p):
+    """Every (dim, basis, degree) the library instantiates kernels for (pdh_combos.h), on a small distorted
+    mesh with the reaction term switched on for odd p (exercises both k_diag variants)."""
+    fe = fe_cls(dim, p)
+    ah = build(dim, 2, 2, fe, p + 1, distort=0.1)
+    var = po.variant_diffusion_reaction(fe) if p % 2 else po.variant_assemble_dg_matrix()
+    if p == 0:
+        var = po.SipVariant("p0", 10.0, "id", "diameter_in")
+    _, _, ref = po.assemble_csr(ah, var)
+    got = gpu_values(flatten(ah, var))
+    assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
