@@ -49,6 +49,14 @@ def algorithmic_work(flat, n):
     return dict(flops=[fl_diag, fl_off], bytes=[by_diag, by_off])
 
 
+def make_variant(pa, name, fe):
+    if name == "diffusion_reaction":
+        return pa.SipVariant.diffusion_reaction(fe)
+    if name == "assemble_dg_matrix":
+        return pa.SipVariant.assemble_dg_matrix()
+    return pa.SipVariant.poisson_example(fe)
+
+
 def build_handler(pa, dim, cells, block, basis, degree, nq):
     lg = cells.bit_length() - 1
     if (1 << lg) == cells:
@@ -66,7 +74,7 @@ def build_handler(pa, dim, cells, block, basis, degree, nq):
 def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup):
     t0 = time.time()
     grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1)
-    var = pa.SipVariant.poisson_example(fe)
+    var = make_variant(pa, args.variant, fe)
     flat = ah.flatten(var, diag_first=True, with_colind=False)
     n = fe.n_dofs_per_cell
     n_agg = ah.n_agglomerates
@@ -148,7 +156,7 @@ def cpu_baseline(pa, args, basis):
     def run(nb, thr):
         cells = nb * args.block
         grid, ah, fe = build_handler(pa, args.dim, cells, args.block, basis, args.degree, args.degree + 1)
-        flat = ah.flatten(pa.SipVariant.poisson_example(fe), diag_first=True, with_colind=True)
+        flat = ah.flatten(make_variant(pa, args.variant, fe), diag_first=True, with_colind=True)
         kw = flat.arrays()
         c = flat.c
         kw.update(dim=c.dim, degree=c.degree, basis=c.basis, n_agg=c.n_agg, n_faces=c.n_faces, n_rows=c.n_rows,
@@ -174,6 +182,8 @@ def main():
     ap.add_argument("--block", type=int, default=2, help="cells per direction in one polytope")
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--fe", choices=["dgq", "dgp"], default="dgq")
+    ap.add_argument("--variant", choices=["poisson", "diffusion_reaction", "assemble_dg_matrix"], default="poisson",
+                    help="caller variant (penalty / face ownership / reaction term), SURVEY.md 8(a)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary FE measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -248,10 +258,12 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dD SIP Poisson, unit cube, %d^%d hex cells, %d polytopes of %d^%d cells, %s(%d) n=%d, "
-                                   "QGauss(%d), variant examples/poisson.cc; %d dofs, %d nnz"
+                                   "QGauss(%d), variant %s; %d dofs, %d nnz"
                                    % (args.dim, args.cells, args.dim, r["n_agg"], args.block, args.dim,
                                       "FE_DGQ" if args.fe == "dgq" else "FE_AggloDGP", args.degree, r["n"],
-                                      args.degree + 1, r["n_dofs"], r["nnz"]),
+                                      args.degree + 1, {"poisson": "examples/poisson.cc", "diffusion_reaction": "examples/diffusion_reaction.cc",
+                                                        "assemble_dg_matrix": "PolyUtils::assemble_dg_matrix"}[args.variant],
+                                      r["n_dofs"], r["nnz"]),
                        "parallelism": "rows(polytopes) split in %d contiguous ranges, owner-computes-rows, no collective" % world},
             "roofline": {"bound": "mfma", "kernel": "k_diag", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,

@@ -251,10 +251,12 @@ struct LaneBasis
 };
 
 // Evaluate the 1-D basis of one point (this lane's) in the frame of a bounding box and store its record.
-// sw = sqrt(weight) is folded into direction 0.
-template <int DIM, int N1D>
+// sw = sqrt(weight) is folded into direction 0.  dscale[c] (face points only) additionally scales the
+// derivative entries of direction c by a per-point factor - the face kernels fold -n_c/2 (or +n_c/2) in, so
+// that grad(phi).n-type combinations cost no extra multiplies per basis function.
+template <int DIM, int N1D, bool DSCALE>
 __device__ __forceinline__ void eval_point_record(const PdhBasisTab &tab, const double *lo, const double *h,
-                                                  const double *x, double sw, double *rec)
+                                                  const double *x, double sw, const double *dscale, double *rec)
 {
   constexpr int p = N1D - 1;
   static_for<0, DIM>([&](auto c_) {
@@ -267,6 +269,8 @@ __device__ __forceinline__ void eval_point_record(const PdhBasisTab &tab, const 
         sv = sw;
         ih *= sw;
       }
+    if constexpr (DSCALE)
+      ih *= dscale[c];
     static_for<0, N1D>([&](auto k_) {
       constexpr int k = k_;
       double val = tab.coef[k][p], der = 0.0;
@@ -294,6 +298,21 @@ struct FragRaw
   {
     for (int c = 0; c < DIM; ++c)
       t[c] = *reinterpret_cast<const d2_t *>(rec_bytes + off[c]);
+  }
+  // With derivative entries pre-scaled by s_c (face records):  phi  and  u = m phi + sum_c s_c d_c phi
+  __device__ __forceinline__ void eval_u(double m, double &phi, double &u) const
+  {
+    if constexpr (DIM == 2)
+      {
+        phi = t[0].x * t[1].x;
+        u = t[1].x * (m * t[0].x + t[0].y) + t[0].x * t[1].y;
+      }
+    else
+      {
+        const double v12 = t[1].x * t[2].x;
+        phi = t[0].x * v12;
+        u = v12 * (m * t[0].x + t[0].y) + t[0].x * (t[1].y * t[2].x + t[1].x * t[2].y);
+      }
   }
   // sqrt(w) phi and sqrt(w) d_c phi
   __device__ __forceinline__ void eval(double &phi, double *dphi) const
@@ -531,7 +550,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
             for (int c = 0; c < DIM; ++c)
               x[c] = lo[c];
           if (lane < CH)
-            eval_point_record<DIM, N1D>(P.tab, lo, h, x, sqrt(w), rec + lane * RC::LEN);
+            eval_point_record<DIM, N1D, false>(P.tab, lo, h, x, sqrt(w), nullptr, rec + lane * RC::LEN);
         }
         __syncthreads();
         const int nsteps = (cnt + 3) >> 2;
@@ -609,43 +628,35 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
               }
           if (lane < CH)
             {
-              eval_point_record<DIM, N1D>(P.tab, lo, h, x, sqrt(w), rec + lane * RC::LEN);
-              aux[lane * AUXN + 1] = 0.5 * sg;
+              double ds[DIM]; // -n_c / 2 folded into the derivative entries
               for (int c = 0; c < DIM; ++c)
-                aux[lane * AUXN + 2 + c] = -0.5 * nr[c];
+                ds[c] = -0.5 * nr[c];
+              eval_point_record<DIM, N1D, true>(P.tab, lo, h, x, sqrt(w), ds, rec + lane * RC::LEN);
+              aux[lane * AUXN + 1] = 0.5 * sg;
             }
         }
         __syncthreads();
         const int nsteps = (cnt + 3) >> 2;
         FragRaw<DIM> raw[NT];
-        double hs, nh[DIM]; // sigma/2, -n/2 of the step being computed
+        double hs; // sigma/2 of the step being computed
         {
           const char *rb = reinterpret_cast<const char *>(rec + kq * RC::LEN);
           static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
           hs = aux[kq * AUXN + 1];
-          for (int c = 0; c < DIM; ++c)
-            nh[c] = aux[kq * AUXN + 2 + c];
         }
         for (int step = 0; step < nsteps; ++step)
           {
             double Phi[NT], U[NT];
             static_for<0, NT>([&](auto a_) {
               constexpr int a = a_;
-              double ph, dp[DIM];
-              raw[a].eval(ph, dp);
-              double u = hs * ph;
-              for (int c = 0; c < DIM; ++c)
-                u += nh[c] * dp[c];
-              Phi[a] = ph; // sqrt(w) phi
-              U[a] = u;    // sqrt(w) (-1/2 grad phi . n + sigma/2 phi)
+              // Phi = sqrt(w) phi,  U = sqrt(w) (-1/2 grad phi . n + sigma/2 phi)
+              raw[a].eval_u(hs, Phi[a], U[a]);
             });
             {
               const int ptn = 4 * ((step + 1 < nsteps) ? step + 1 : step) + kq;
               const char *rb = reinterpret_cast<const char *>(rec + ptn * RC::LEN);
               static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
               hs = aux[ptn * AUXN + 1];
-              for (int c = 0; c < DIM; ++c)
-                nh[c] = aux[ptn * AUXN + 2 + c];
             }
             RotSet<NT> RU, RPhi;
             make_rot<NT, ROT_SYM>(U, rt, RU);
@@ -739,13 +750,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
               x[c] = lo[c]; // any point with finite basis values; its weight is zero
               nr[c] = 0.0;
             }
-        eval_point_record<DIM, N1D>(P.tab, lo, h, x, sqrt(w), (half ? recQ : recP) + pl * RC::LEN);
+        double ds[DIM]; // P frame: +n_c/2, Q frame: -n_c/2 folded into the derivative entries
+        for (int c = 0; c < DIM; ++c)
+          ds[c] = (half ? -0.5 : 0.5) * nr[c];
+        eval_point_record<DIM, N1D, true>(P.tab, lo, h, x, sqrt(w), ds, (half ? recQ : recP) + pl * RC::LEN);
         if (half == 0)
-          {
-            aux[pl * AUXN + 1] = -sg;
-            for (int c = 0; c < DIM; ++c)
-              aux[pl * AUXN + 2 + c] = 0.5 * nr[c];
-          }
+          aux[pl * AUXN + 1] = -sg;
       }
       __syncthreads();
       const int nsteps = (cnt + 3) >> 2;
@@ -755,25 +765,16 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
           const char *rbP = reinterpret_cast<const char *>(recP + pt * RC::LEN);
           const char *rbQ = reinterpret_cast<const char *>(recQ + pt * RC::LEN);
           const double msg = aux[pt * AUXN + 1]; // -sigma
-          double nh[DIM];                         // n_P / 2
-          for (int c = 0; c < DIM; ++c)
-            nh[c] = aux[pt * AUXN + 2 + c];
           double A1[NT], A2[NT], B1[NT], B2[NT];
           static_for<0, NT>([&](auto a_) {
             constexpr int a = a_;
-            double ph, dp[DIM];
-            frag_eval<DIM>(rbP, lb.off[a], ph, dp);
-            double u = msg * ph;
-            for (int c = 0; c < DIM; ++c)
-              u += nh[c] * dp[c];
-            A1[a] = u;  // sqrt(w) (1/2 grad phi^P . n_P - sigma phi^P)
-            A2[a] = ph; // sqrt(w) phi^P
-            frag_eval<DIM>(rbQ, lb.off[a], ph, dp);
-            double g = -nh[0] * dp[0];
-            for (int c = 1; c < DIM; ++c)
-              g -= nh[c] * dp[c];
-            B1[a] = ph; // sqrt(w) phi^Q
-            B2[a] = g;  // sqrt(w) (-1/2 grad phi^Q . n_P)
+            FragRaw<DIM> r;
+            r.load(rbP, lb.off[a]);
+            // A2 = sqrt(w) phi^P,  A1 = sqrt(w) (1/2 grad phi^P . n_P - sigma phi^P)
+            r.eval_u(msg, A2[a], A1[a]);
+            r.load(rbQ, lb.off[a]);
+            // B1 = sqrt(w) phi^Q,  B2 = sqrt(w) (-1/2 grad phi^Q . n_P)
+            r.eval_u(0.0, B1[a], B2[a]);
           });
           product_full<NT, LB>(acc, A1, B1, rt);
           product_full<NT, LB>(acc, A2, B2, rt);

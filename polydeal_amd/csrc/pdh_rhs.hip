@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
               double x[DIM];
               for (int c = 0; c < DIM; ++c)
                 x[c] = P.vq_x[c * P.vq_stride + base + lane];
-              eval_point_record<DIM, N1D>(P.tab, lo, h, x, 1.0, rec + lane * RC::LEN);
+              eval_point_record<DIM, N1D, false>(P.tab, lo, h, x, 1.0, nullptr, rec + lane * RC::LEN);
               aux[lane * AUXN] = f_vol[base + lane] * P.vq_w[base + lane];
             }
           __syncthreads();
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
               double x[DIM];
               for (int c = 0; c < DIM; ++c)
                 x[c] = P.ap_x[c * P.ap_stride + base + lane];
-              eval_point_record<DIM, N1D>(P.tab, lo, h, x, 1.0, rec + lane * RC::LEN);
+              eval_point_record<DIM, N1D, false>(P.tab, lo, h, x, 1.0, nullptr, rec + lane * RC::LEN);
               // packed boundary points carry w = 2 JxW and sigma/2:  2w (sigma/2 g phi - 1/2 g grad phi.n)
               const double gw = g_face[base + lane] * P.ap_wself[base + lane];
               aux[lane * AUXN] = gw * P.ap_sig[base + lane];

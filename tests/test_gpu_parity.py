@@ -273,3 +273,69 @@ def test_every_instantiated_combo(dim, fe_cls, p):
     _, _, ref = po.assemble_csr(ah, var)
     got = gpu_values(flatten(ah, var))
     assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
+
+
+def random_agglomeration(grid, n_seeds, rng, allow_disconnected=False):
+    """Random polytopes: grow n_seeds regions over the cell adjacency graph (round-robin BFS with random
+    frontier picks); optionally glue two random regions into one disconnected agglomerate
+    (test/polydeal/disconnected_exact_solution.cc exercises such agglomerates)."""
+    n = grid.n_cells
+    owner = -np.ones(n, dtype=np.int64)
+    seeds = rng.choice(n, size=n_seeds, replace=False)
+    frontiers = []
+    for k, s in enumerate(seeds):
+        owner[s] = k
+        frontiers.append([int(s)])
+    remaining = n - n_seeds
+    while remaining:
+        progressed = False
+        for k in rng.permutation(n_seeds):
+            fr = frontiers[k]
+            while fr:
+                c = fr[rng.integers(len(fr))]
+                nbrs = [grid.neighbor(c, f) for f in range(2 * grid.dim)]
+                free = [x for x in nbrs if x != po.INVALID and owner[x] < 0]
+                if not free:
+                    fr.remove(c)
+                    continue
+                x = free[rng.integers(len(free))]
+                owner[x] = k
+                fr.append(int(x))
+                remaining -= 1
+                progressed = True
+                break
+        assert progressed or remaining == 0
+    groups = [sorted(np.nonzero(owner == k)[0].tolist()) for k in range(n_seeds)]
+    if allow_disconnected and n_seeds > 3:
+        a, b = 0, n_seeds - 1
+        groups[a] = sorted(groups[a] + groups[b])
+        del groups[b]
+    return groups
+
+
+@pytest.mark.parametrize("dim,lg,n_seeds,fe_cls,p,seed,disc", [
+    (2, 4, 23, po.FE_AggloDGP, 2, 11, False),
+    (2, 4, 9, po.FE_DGQ, 1, 12, True),
+    (2, 3, 7, po.FE_DGQ, 3, 13, False),
+    (3, 2, 5, po.FE_AggloDGP, 3, 14, False),
+    (3, 2, 9, po.FE_DGQ, 2, 15, True),
+    (3, 3, 40, po.FE_AggloDGP, 1, 16, False),
+])
+def test_random_irregular_agglomerates(dim, lg, n_seeds, fe_cls, p, seed, disc):
+    """Irregular polytopes (varying sub-cell counts, many faces per polytope, non-convex and disconnected
+    shapes, un-sorted definition order) on a distorted mesh - the general input the face tables must handle."""
+    rng = np.random.default_rng(seed)
+    grid = po.hyper_cube_refined(dim, -1.0, 1.0, lg).distort(0.2, seed=seed)
+    groups = random_agglomeration(grid, n_seeds, rng, disc)
+    order = rng.permutation(len(groups))  # polytope index order != master cell order
+    ah = po.AgglomerationHandler(grid)
+    for k in order:
+        ah.define_agglomerate(groups[k])
+    fe = fe_cls(dim, p)
+    ah.initialize_fe_values(p + 1, p + 1)
+    ah.distribute_agglomerated_dofs(fe)
+    assert max(ah.n_faces) > 2 * dim or n_seeds < 8
+    for var in (po.variant_poisson_example(fe), po.variant_assemble_dg_matrix()):
+        _, _, ref = po.assemble_csr(ah, var)
+        got = gpu_values(flatten(ah, var))
+        assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
