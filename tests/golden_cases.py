@@ -150,6 +150,24 @@ def render_neighbors_03(ah):
     return out
 
 
+def render_reinit_cell_face_02(ah):
+    # test/polydeal/reinit_cell_face_02.cc:121-157
+    out = []
+    for P in range(ah.n_agglomerates):
+        nf = ah.n_faces_of(P)
+        out.append("Cell with index %d has %d faces" % (ah.master_index(P), nf))
+        for f in range(nf):
+            if not ah.at_boundary(P, f):
+                Q = ah.neighbor(P, f)
+                out.append("Neighbor index= %d" % ah.master_index(Q))
+                out.append("Neighbor of neighbor(%d) = %d" % (f, ah.master_index(Q)))
+                assert ah.neighbor(Q, ah.neighbor_of_agglomerated_neighbor(P, f)) == P
+            else:
+                out.append("Face with idx: %d is a boundary face." % f)
+        out.append("")
+    return out
+
+
 def render_sparsity(ah):
     # DynamicSparsityPattern::print: "[row,col,col,...]" ascending (sparsity_agglomerated_tria.cc)
     return ["[" + ",".join(str(int(c)) for c in [r] + list(cols)) + "]" for r, cols in enumerate(ah.sparsity_rows())]
@@ -183,6 +201,7 @@ def render_polytope_iterator_forward(ah, n_first):
 # ---- agglomerate lists hard-coded in the reference tests ---------------------------------------
 GROUPS_QUAD_PTS = [[3, 6, 9], [36, 37], [25, 19]]  # reinit_cell_face_quad_pts.cc:60-78
 GROUPS_FOUR = [[3, 6, 9, 12, 13], [15, 36, 37], [57, 60, 54], [25, 19, 22]]  # reinit_cell_face_01.cc:52-80
+GROUPS_RCF02 = [[3, 6, 9], [15, 36, 37], [57, 60, 54], [25, 19, 22]]  # reinit_cell_face_02.cc:68-95
 GROUPS_2X2 = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
 GROUPS_HALVES = [[0, 1, 2, 3, 4, 5, 6, 7], [8, 9, 10, 11, 12, 13, 14, 15]]  # continuous_face_01.cc:161-170
 GROUPS_CF02 = [

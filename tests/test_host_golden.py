@@ -156,3 +156,11 @@ def test_errors_are_reported():
         pa.BackgroundGrid(2, 6, morton=True)  # Morton needs a power of two
     with pytest.raises(pa.HostError):
         ah.define_agglomerate([])
+
+
+def test_reinit_cell_face_02_and_agglomerated_neighbors_01():
+    """Two more face-enumeration goldens on irregular agglomerates of the 8x8 grid (540 + 928 lines)."""
+    _, ah = make(2, 3, gc.GROUPS_RCF02)
+    assert gc.render_reinit_cell_face_02(ah) == gc.golden_lines("reinit_cell_face_02.output")[:-1]
+    _, ah = make(2, 3, gc.GROUPS_FOUR)
+    assert gc.render_neighbors_02(ah) == gc.golden_lines("agglomerated_neighbors_01.output")[:-1]

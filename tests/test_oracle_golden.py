@@ -256,3 +256,11 @@ def test_poisson_output_L2_error():
     rp, ci, va = po.assemble_csr(ah, var, diag_first=False)
     err = poisson_l2_error(grid, ah, rp, ci, va)
     assert "L2 error:" + gc.fmt(err) == gc.golden_lines("poisson.output")[0]
+
+
+def test_reinit_cell_face_02_and_agglomerated_neighbors_01():
+    """Two more face-enumeration goldens on irregular agglomerates of the 8x8 grid (540 + 928 lines)."""
+    _, ah = make(2, 3, gc.GROUPS_RCF02)
+    assert gc.render_reinit_cell_face_02(ah) == gc.golden_lines("reinit_cell_face_02.output")[:-1]
+    _, ah = make(2, 3, gc.GROUPS_FOUR)
+    assert gc.render_neighbors_02(ah) == gc.golden_lines("agglomerated_neighbors_01.output")[:-1]
