@@ -153,7 +153,7 @@ def cpu_baseline(pa, args, basis):
     cores = effective_cpus()
     nthreads = max(1, min(cores, sip_ref.max_threads()))
 
-    def run(nb, thr):
+    def run(nb, thr, fast=False):
         cells = nb * args.block
         grid, ah, fe = build_handler(pa, args.dim, cells, args.block, basis, args.degree, args.degree + 1)
         flat = ah.flatten(make_variant(pa, args.variant, fe), diag_first=True, with_colind=True)
@@ -161,15 +161,18 @@ def cpu_baseline(pa, args, basis):
         c = flat.c
         kw.update(dim=c.dim, degree=c.degree, basis=c.basis, n_agg=c.n_agg, n_faces=c.n_faces, n_rows=c.n_rows,
                   diag_first=c.diag_first, reaction_c=c.reaction_c)
-        _, secs = sip_ref.assemble(kw, nthreads=thr)
+        _, secs = sip_ref.assemble(kw, nthreads=thr, fast=fast)
         return dict(dofs=ah.n_dofs, secs=secs, threads=thr, n_agg=ah.n_agglomerates, nb=nb)
 
-    cal = run(3, 1)
-    per_poly = cal["secs"] / cal["n_agg"]
-    root = 1.0 / args.dim
-    nb_one = int(max(3, min(args.cpu_max_blocks, round((args.cpu_seconds / per_poly) ** root))))
-    nb_all = int(max(3, min(args.cpu_max_blocks, round((args.cpu_seconds * nthreads / per_poly) ** root))))
-    return dict(all=run(nb_all, nthreads), one=run(nb_one, 1)), cores
+    def sized(fast):
+        cal = run(3, 1, fast)
+        per_poly = max(cal["secs"] / cal["n_agg"], 1e-7)
+        root = 1.0 / args.dim
+        nb_one = int(max(3, min(args.cpu_max_blocks, round((args.cpu_seconds / per_poly) ** root))))
+        nb_all = int(max(3, min(args.cpu_max_blocks, round((args.cpu_seconds * nthreads / per_poly) ** root))))
+        return dict(all=run(nb_all, nthreads, fast), one=run(nb_one, 1, fast))
+
+    return dict(port=sized(False), fast=sized(True)), cores
 
 
 def main():
@@ -228,12 +231,20 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res, cores = cpu_baseline(pa, args, args.fe)
-        a, o = res["all"], res["one"]
+        a, o = res["port"]["all"], res["port"]["one"]
+        fa, fo = res["fast"]["all"], res["fast"]["one"]
         cpu = {"value": a["dofs"] / a["secs"], "unit": "DoF/s", "cores": a["threads"], "kind": "port",
                "sample": "oracle/sip_ref.c (reference-shaped C restatement, gcc -O2, OpenMP over polytopes) on %d^%d=%d polytopes "
                          "of the same workload (%d dofs) in %.1f s on %d threads; 1 core: %d polytopes in %.1f s"
                          % (a["nb"], args.dim, a["n_agg"], a["dofs"], a["secs"], a["threads"], o["n_agg"], o["secs"]),
-               "value_1core": o["dofs"] / o["secs"], "host_cores": cores}
+               "value_1core": o["dofs"] / o["secs"], "host_cores": cores,
+               "best_effort_cpu": {
+                   "note": "same algorithm content, hoisted basis evaluation + vectorised inner loops "
+                           "(sipref_assemble_fast, gcc -O3 -march=native): reported so that GPU/CPU is not quoted "
+                           "against the reference-shaped port only",
+                   "value": fa["dofs"] / fa["secs"], "cores": fa["threads"], "value_1core": fo["dofs"] / fo["secs"],
+                   "sample": "%d polytopes in %.1f s on %d threads; 1 core: %d polytopes in %.1f s"
+                             % (fa["n_agg"], fa["secs"], fa["threads"], fo["n_agg"], fo["secs"])}}
 
     if rank == 0:
         r = main_res

@@ -371,11 +371,251 @@ static void assemble_polytope(const sipref_problem *P, const fe_t *fe, int a, co
   free(M11);
 }
 
+/* ------------------------------------------------------------------------------------------------------
+ * "Honest best-effort" CPU variant: same algorithmic content as the reference
+ * (volume block + Nitsche block per polytope, four n x n blocks per owned interior face, no symmetry or
+ * transpose shortcuts), but implemented the way a performance-minded CPU author would: basis values and
+ * normal derivatives evaluated once per point into contiguous arrays, j-contiguous inner loops that the
+ * compiler vectorises (build this file with -O3 -march=native), scratch reused across polytopes, and block
+ * scatter by one column search per row.  Reported next to the reference-shaped port so that GPU/CPU
+ * ratios are not quoted against a strawman only.
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct
+{
+  double *val, *grad, *gn, *val1, *gn1, *blk; /* scratch */
+  size_t cap_q;
+} fast_scratch;
+
+static void fast_eval(const fe_t *fe, const double *bbox, const double *x, int64_t stride, int64_t q0, int nq,
+                      double *val /*[q][n]*/, double *grad /*[c][q][n]*/)
+{
+  const int dim = fe->dim, n = fe->n;
+  double inv_h[3];
+  for (int c = 0; c < dim; ++c)
+    inv_h[c] = 1.0 / (bbox[dim + c] - bbox[c]);
+  for (int q = 0; q < nq; ++q)
+    {
+      double v1[3][MAXN1D], d1[3][MAXN1D];
+      for (int c = 0; c < dim; ++c)
+        {
+          const double xh = (x[c * stride + q0 + q] - bbox[c]) / (bbox[dim + c] - bbox[c]);
+          if (fe->basis == 0)
+            eval_lagrange(fe->p, fe->nodes, xh, v1[c], d1[c]);
+          else
+            eval_legendre(fe->p, xh, v1[c], d1[c]);
+          for (int k = 0; k <= fe->p; ++k)
+            d1[c][k] *= inv_h[c];
+        }
+      for (int i = 0; i < n; ++i)
+        {
+          const int *m = fe->mi[i];
+          if (dim == 2)
+            {
+              val[(size_t)q * n + i] = v1[0][m[0]] * v1[1][m[1]];
+              grad[((size_t)0 * nq + q) * n + i] = d1[0][m[0]] * v1[1][m[1]];
+              grad[((size_t)1 * nq + q) * n + i] = v1[0][m[0]] * d1[1][m[1]];
+            }
+          else
+            {
+              const double a = v1[0][m[0]], b = v1[1][m[1]], cc = v1[2][m[2]];
+              val[(size_t)q * n + i] = a * b * cc;
+              grad[((size_t)0 * nq + q) * n + i] = d1[0][m[0]] * b * cc;
+              grad[((size_t)1 * nq + q) * n + i] = a * d1[1][m[1]] * cc;
+              grad[((size_t)2 * nq + q) * n + i] = a * b * d1[2][m[2]];
+            }
+        }
+    }
+}
+
+/* block scatter: one column search per row (columns of a block are contiguous in the DG pattern) */
+static void scatter_block(const sipref_problem *P, double *values, const double *M, int n, int row0, int col0, int atomic)
+{
+  for (int i = 0; i < n; ++i)
+    {
+      const int r = row0 + i;
+      const int64_t b = P->rowptr[r], e = P->rowptr[r + 1];
+      int64_t lo = b + (P->diag_first ? 1 : 0), hi = e;
+      while (lo < hi)
+        {
+          const int64_t mid = (lo + hi) >> 1;
+          if (P->colind[mid] < col0)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+      /* lo = position of the first column >= col0 among the ascending part */
+      for (int j = 0; j < n; ++j)
+        {
+          const int c = col0 + j;
+          int64_t pos;
+          if (P->diag_first && c == r)
+            pos = b;
+          else if (P->diag_first && row0 == col0 && c > r)
+            pos = lo + j - 1; /* the diagonal entry was moved to the front of the row */
+          else
+            pos = lo + j;
+          if (atomic)
+            {
+#pragma omp atomic
+              values[pos] += M[(size_t)i * n + j];
+            }
+          else
+            values[pos] += M[(size_t)i * n + j];
+        }
+    }
+}
+
+static void assemble_polytope_fast(const sipref_problem *P, const fe_t *fe, int a, const int64_t *face_begin,
+                                   double *values, int atomic, fast_scratch *S)
+{
+  const int dim = P->dim, n = fe->n;
+  const int64_t nq_tot = P->vq_ptr[P->n_agg];
+  const int64_t nqf_tot = P->n_faces ? P->fq_ptr[P->n_faces] : 0;
+  const double *bbP = P->bbox + (size_t)a * 2 * dim;
+  size_t need = (size_t)(P->vq_ptr[a + 1] - P->vq_ptr[a]);
+  for (int64_t f = face_begin[a]; f < face_begin[a + 1]; ++f)
+    if ((size_t)(P->fq_ptr[f + 1] - P->fq_ptr[f]) > need)
+      need = (size_t)(P->fq_ptr[f + 1] - P->fq_ptr[f]);
+  if (need > S->cap_q)
+    {
+      free(S->val);
+      free(S->grad);
+      free(S->gn);
+      free(S->val1);
+      free(S->gn1);
+      S->cap_q = need;
+      S->val = (double *)malloc(sizeof(double) * need * n);
+      S->grad = (double *)malloc(sizeof(double) * need * n * 3);
+      S->gn = (double *)malloc(sizeof(double) * need * n);
+      S->val1 = (double *)malloc(sizeof(double) * need * n);
+      S->gn1 = (double *)malloc(sizeof(double) * need * n);
+    }
+  if (!S->blk)
+    S->blk = (double *)malloc(sizeof(double) * 5 * (size_t)n * n);
+  double *restrict cell = S->blk, *restrict M11 = cell + (size_t)n * n, *restrict M12 = M11 + (size_t)n * n,
+                   *restrict M21 = M12 + (size_t)n * n, *restrict M22 = M21 + (size_t)n * n;
+  memset(cell, 0, sizeof(double) * (size_t)n * n);
+  {
+    const int64_t q0 = P->vq_ptr[a];
+    const int nq = (int)(P->vq_ptr[a + 1] - q0);
+    fast_eval(fe, bbP, P->vq_x, nq_tot, q0, nq, S->val, S->grad);
+    for (int c = 0; c < dim; ++c)
+      for (int q = 0; q < nq; ++q)
+        {
+          const double w = P->vq_w[q0 + q];
+          const double *restrict g = S->grad + ((size_t)c * nq + q) * n;
+          for (int i = 0; i < n; ++i)
+            {
+              const double gi = g[i] * w;
+              double *restrict row = cell + (size_t)i * n;
+              for (int j = 0; j < n; ++j)
+                row[j] += gi * g[j];
+            }
+        }
+    if (P->reaction_c != 0.0)
+      for (int q = 0; q < nq; ++q)
+        {
+          const double w = P->reaction_c * P->vq_w[q0 + q];
+          const double *restrict v = S->val + (size_t)q * n;
+          for (int i = 0; i < n; ++i)
+            {
+              const double vi = v[i] * w;
+              double *restrict row = cell + (size_t)i * n;
+              for (int j = 0; j < n; ++j)
+                row[j] += vi * v[j];
+            }
+        }
+  }
+  for (int64_t f = face_begin[a]; f < face_begin[a + 1]; ++f)
+    {
+      const int out = P->face_out[f];
+      const int64_t q0 = P->fq_ptr[f];
+      const int nq = (int)(P->fq_ptr[f + 1] - q0);
+      const double sigma = P->face_sigma[f];
+      fast_eval(fe, bbP, P->fq_x, nqf_tot, q0, nq, S->val, S->grad);
+      for (int q = 0; q < nq; ++q)
+        for (int i = 0; i < n; ++i)
+          {
+            double s = 0.0;
+            for (int c = 0; c < dim; ++c)
+              s += S->grad[((size_t)c * nq + q) * n + i] * P->fq_n[c * nqf_tot + q0 + q];
+            S->gn[(size_t)q * n + i] = s;
+          }
+      if (out < 0)
+        {
+          for (int q = 0; q < nq; ++q)
+            {
+              const double w = P->fq_w[q0 + q];
+              const double *restrict v = S->val + (size_t)q * n, *restrict g = S->gn + (size_t)q * n;
+              for (int i = 0; i < n; ++i)
+                {
+                  const double vi = v[i] * w, gi = g[i] * w;
+                  double *restrict row = cell + (size_t)i * n;
+                  for (int j = 0; j < n; ++j)
+                    row[j] += -vi * g[j] - gi * v[j] + sigma * vi * v[j];
+                }
+            }
+        }
+      else
+        {
+          fast_eval(fe, P->bbox + (size_t)out * 2 * dim, P->fq_x, nqf_tot, q0, nq, S->val1, S->grad);
+          for (int q = 0; q < nq; ++q)
+            for (int i = 0; i < n; ++i)
+              {
+                double s = 0.0;
+                for (int c = 0; c < dim; ++c)
+                  s += S->grad[((size_t)c * nq + q) * n + i] * P->fq_n[c * nqf_tot + q0 + q];
+                S->gn1[(size_t)q * n + i] = s;
+              }
+          memset(M11, 0, sizeof(double) * 4 * (size_t)n * n);
+          for (int q = 0; q < nq; ++q)
+            {
+              const double w0 = P->fq_w[q0 + q];
+              const double w1 = P->fq_w_out ? P->fq_w_out[q0 + q] : w0;
+              const double *restrict v0 = S->val + (size_t)q * n, *restrict g0 = S->gn + (size_t)q * n;
+              const double *restrict v1 = S->val1 + (size_t)q * n, *restrict g1 = S->gn1 + (size_t)q * n;
+              for (int i = 0; i < n; ++i)
+                {
+                  const double v0i = v0[i], g0i = g0[i], v1i = v1[i], g1i = g1[i];
+                  double *restrict r11 = M11 + (size_t)i * n, *restrict r12 = M12 + (size_t)i * n;
+                  double *restrict r21 = M21 + (size_t)i * n, *restrict r22 = M22 + (size_t)i * n;
+                  for (int j = 0; j < n; ++j)
+                    {
+                      r11[j] += (-0.5 * g0i * v0[j] - 0.5 * g0[j] * v0i + sigma * v0i * v0[j]) * w0;
+                      r12[j] += (0.5 * g0i * v1[j] - 0.5 * g1[j] * v0i - sigma * v0i * v1[j]) * w1;
+                      r21[j] += (-0.5 * g1i * v0[j] + 0.5 * g0[j] * v1i - sigma * v1i * v0[j]) * w1;
+                      r22[j] += (0.5 * g1i * v1[j] + 0.5 * g1[j] * v1i + sigma * v1i * v1[j]) * w1;
+                    }
+                }
+            }
+          const int ra = P->dof_offset[a], rb = P->dof_offset[out];
+          scatter_block(P, values, M11, n, ra, ra, atomic);
+          scatter_block(P, values, M12, n, ra, rb, atomic);
+          scatter_block(P, values, M21, n, rb, ra, atomic);
+          scatter_block(P, values, M22, n, rb, rb, atomic);
+        }
+    }
+  scatter_block(P, values, cell, n, P->dof_offset[a], P->dof_offset[a], atomic);
+}
+
 /* Assemble polytopes [a_begin, a_end) (all: 0..n_agg).  values must be zero-initialised by the caller
  * and have nnz entries; colind is required.  nthreads <= 1: serial, in polytope order (the reference's
  * per-rank behaviour); > 1: OpenMP over polytopes with atomic scatter (stand-in for mpirun -np N).
  * Returns 0, or <0 on bad input. */
+static int sipref_assemble_mode(const sipref_problem *P, double *values, int a_begin, int a_end, int nthreads, int fast);
+
 int sipref_assemble(const sipref_problem *P, double *values, int a_begin, int a_end, int nthreads)
+{
+  return sipref_assemble_mode(P, values, a_begin, a_end, nthreads, 0);
+}
+
+/* hoisted / vectorisable variant (see "Honest best-effort" above) */
+int sipref_assemble_fast(const sipref_problem *P, double *values, int a_begin, int a_end, int nthreads)
+{
+  return sipref_assemble_mode(P, values, a_begin, a_end, nthreads, 1);
+}
+
+static int sipref_assemble_mode(const sipref_problem *P, double *values, int a_begin, int a_end, int nthreads, int fast)
 {
   if (!P || !values || !P->colind)
     return -1;
@@ -395,6 +635,29 @@ int sipref_assemble(const sipref_problem *P, double *values, int a_begin, int a_
     }
   for (int a = 0; a < P->n_agg; ++a)
     face_begin[a + 1] += face_begin[a];
+  if (fast)
+    {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads > 1 ? nthreads : 1)
+#endif
+      {
+        fast_scratch S;
+        memset(&S, 0, sizeof(S));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (int a = a_begin; a < a_end; ++a)
+          assemble_polytope_fast(P, &fe, a, face_begin, values, nthreads > 1, &S);
+        free(S.val);
+        free(S.grad);
+        free(S.gn);
+        free(S.val1);
+        free(S.gn1);
+        free(S.blk);
+      }
+      free(face_begin);
+      return 0;
+    }
 #ifdef _OPENMP
   if (nthreads > 1)
     {

@@ -32,3 +32,7 @@ def test_c_restatement_matches_numpy_oracle(dim, lg, b, fe_cls, p, nq, var, dist
     assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref))
     got2, _ = sip_ref.assemble(kw, nthreads=2)
     assert np.max(np.abs(got2 - ref)) <= 1e-13 * np.max(np.abs(ref))
+    # hoisted / vectorised CPU variant (second CPU baseline of bench.py)
+    for thr in (1, 2):
+        got3, _ = sip_ref.assemble(kw, nthreads=thr, fast=True)
+        assert np.max(np.abs(got3 - ref)) <= 1e-13 * np.max(np.abs(ref))
