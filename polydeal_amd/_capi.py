@@ -49,16 +49,7 @@ EXPORTS = [
 _lib = None
 
 
-def load_library():
-    """Loads libpolydeal_hip.so; raises if the HIP extension has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(
-            "polydeal_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C polydeal_amd/csrc`; there is no CPU fallback" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+def _bind(lib):
     P = C.POINTER
     lib.pdh_create.argtypes = [P(C.c_void_p), C.c_int]
     lib.pdh_destroy.argtypes = [C.c_void_p]
@@ -82,8 +73,23 @@ def load_library():
     lib.pdh_kernel_work.argtypes = [C.c_void_p, P(C.c_int64)]
     lib.pdh_check_problem.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, P(C.c_int64)]
     lib.pdh_version.restype = C.c_char_p
-    _lib = lib
     return lib
+
+
+def load_library(path=None):
+    """Loads libpolydeal_hip.so; raises if the HIP extension has not been built.  `path` loads another build
+    of the library next to the default one (tools/ab_bench.py compares two builds in one process)."""
+    global _lib
+    if path is not None:
+        return _bind(C.CDLL(path))
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "polydeal_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C polydeal_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
 
 
 _DTYPES = {
@@ -127,8 +133,8 @@ class Problem:
 class Context:
     """pdh_ctx wrapper (one per device and host thread)."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, lib_path=None):
+        self.lib = load_library(lib_path)
         h = C.c_void_p()
         rc = self.lib.pdh_create(C.byref(h), device)
         if rc != PDH_OK:
