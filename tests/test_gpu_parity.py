@@ -152,6 +152,12 @@ def test_cpp_examples_run():
     out = subprocess.run([os.path.join(root, "examples", "poisson")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Assembled DoF/s" in out.stdout
+    # the reference's test minimal_SIP_Poisson.cc re-written against the C++ host mirror: its stdout must be the
+    # reference's expected output file
+    out = subprocess.run([os.path.join(root, "examples", "minimal_SIP_Poisson_test")], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout == open(os.path.join(root, "tests", "golden", "minimal_SIP_Poisson.output")).read()
 
 
 def test_poisson_output_L2_error_with_gpu_matrix():
