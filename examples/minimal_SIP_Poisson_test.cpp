@@ -73,6 +73,13 @@ bool test()
 
 int main()
 {
+  // descriptor sanity of the templated FE classes (dofs per cell: (p+1)^dim and C(p+dim,dim), fe_agglodgp.cc:89-101)
+  if (FE_DGQ<3>(3).n_dofs_per_cell() != 64 || FE_DGQ<2>(2).n_dofs_per_cell() != 9 || FE_AggloDGP<3>(3).n_dofs_per_cell() != 20 ||
+      FE_AggloDGP<2>(2).n_dofs_per_cell() != 6 || FE_AggloDGP<3>(3).get_name() != "FE_AggloDGP<3>(3)")
+    {
+      std::printf("FE descriptors are wrong\n");
+      return 3;
+    }
   try
     {
       if (!test<2>() || !test<3>())

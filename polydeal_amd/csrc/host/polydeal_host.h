@@ -113,22 +113,23 @@ struct FiniteElement
            std::to_string(degree) + ")";
   }
 };
-template <int dim>
+// (the template parameter must not be called `dim`: inside the class that name finds the base-class member)
+template <int spacedim>
 struct FE_DGQ : FiniteElement
 {
   explicit FE_DGQ(unsigned int p)
   {
-    this->dim = dim;
+    dim = spacedim;
     degree = (int)p;
     basis = PDH_BASIS_DGQ;
   }
 };
-template <int dim>
+template <int spacedim>
 struct FE_AggloDGP : FiniteElement // reference include/fe_agglodgp.h:317
 {
   explicit FE_AggloDGP(unsigned int p)
   {
-    this->dim = dim;
+    dim = spacedim;
     degree = (int)p;
     basis = PDH_BASIS_AGGLODGP;
   }
