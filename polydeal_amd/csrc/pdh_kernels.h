@@ -342,6 +342,80 @@ __device__ __forceinline__ void frag_eval(const char *rec_bytes, const int *off,
   r.eval(phi, dphi);
 }
 
+// Table entries of ONE 4-point step for all NT fragments of this lane, loaded one step ahead of their use.
+// Generic form: DIM (value, derivative) pairs per fragment.  Tensor form (3-D FE_DGQ(3): n1d^2 = 16, i.e. a
+// fragment is exactly one z-layer, function 16a+m = (m&3, m>>2, a)): the x and y entries are shared by the
+// four fragments and the z entries are lane-uniform, so a step needs 6 instead of 12 LDS reads and 15
+// instead of 24 multiplies for the gradients (16 instead of 28 operations for the face operands).
+template <int DIM, int N1D, int NT, int LB>
+struct StepRaw
+{
+  // Measured on MI355X (tools/ab_bench.py): k_diag +2.6 %, k_offdiag -1 % with the tensor form, so it is
+  // switched off; the code is kept because the operation count argument may hold on other parts.
+  static constexpr bool TENS = false && (DIM == 3 && N1D == 4 && NT == 4 && LB == 4);
+  FragRaw<DIM> r[TENS ? 1 : NT];
+  d2_t z[TENS ? 4 : 1];
+
+  __device__ __forceinline__ void load(const char *rb, const LaneBasis<DIM, N1D, NT, LB> &lb)
+  {
+    if constexpr (TENS)
+      {
+        r[0].t[0] = *reinterpret_cast<const d2_t *>(rb + lb.off[0][0]);
+        r[0].t[1] = *reinterpret_cast<const d2_t *>(rb + lb.off[0][1]);
+        static_for<0, 4>([&](auto a_) {
+          constexpr int a = a_;
+          z[a] = *reinterpret_cast<const d2_t *>(rb + (2 * N1D + a) * 16);
+        });
+      }
+    else
+      static_for<0, NT>([&](auto a_) { r[a_].load(rb, lb.off[a_]); });
+  }
+  // sqrt(w) d_c phi of every fragment (phi only if WANT_PHI)
+  template <bool WANT_PHI>
+  __device__ __forceinline__ void eval_grad(double *phi, double (*dphi)[DIM]) const
+  {
+    if constexpr (TENS)
+      {
+        const double tx = r[0].t[0].y * r[0].t[1].x, ty = r[0].t[0].x * r[0].t[1].y, tz = r[0].t[0].x * r[0].t[1].x;
+        static_for<0, 4>([&](auto a_) {
+          constexpr int a = a_;
+          dphi[a][0] = tx * z[a].x;
+          dphi[a][1] = ty * z[a].x;
+          dphi[a][2] = tz * z[a].y;
+          if constexpr (WANT_PHI)
+            phi[a] = tz * z[a].x;
+        });
+      }
+    else
+      static_for<0, NT>([&](auto a_) {
+        constexpr int a = a_;
+        double ph;
+        r[a].eval(ph, dphi[a]);
+        if constexpr (WANT_PHI)
+          phi[a] = ph;
+      });
+  }
+  // face records (derivatives pre-scaled by s_c): phi and u = m phi + sum_c s_c d_c phi of every fragment
+  __device__ __forceinline__ void eval_u(double m, double *phi, double *u) const
+  {
+    if constexpr (TENS)
+      {
+        const double c_ = r[0].t[0].x * r[0].t[1].x;
+        const double a_ = r[0].t[1].x * (m * r[0].t[0].x + r[0].t[0].y) + r[0].t[0].x * r[0].t[1].y;
+        static_for<0, 4>([&](auto f_) {
+          constexpr int f = f_;
+          phi[f] = c_ * z[f].x;
+          u[f] = a_ * z[f].x + c_ * z[f].y;
+        });
+      }
+    else
+      static_for<0, NT>([&](auto a_) {
+        constexpr int a = a_;
+        r[a].eval_u(m, phi[a], u[a]);
+      });
+  }
+};
+
 template <int NT>
 __device__ __forceinline__ constexpr int acc_idx(int a, int b, int r)
 {
@@ -395,19 +469,31 @@ constexpr int ROT_SYM = 0x7;  // rotations 0,1,2: enough for both operands of th
 constexpr int ROT_FULL = 0xf; // B operand of the full schedule
 constexpr int ROT_NONE = 0x1; // A operand of the full schedule
 
-// Epilogue helper.  Per-lane constants of the D layout (lane = 16 i + 4 bb + j) so that scattering one
-// accumulator into the LDS strip costs a couple of integer instructions: for a fragment with `rep`
-// distinct blocks and operand rotation s the lane's local tile is (bb+s) & (rep-1).
+// Epilogue helper.  Per-lane constants of the D layout (lane = 16 i + 4 bb + j): for a fragment with `rep`
+// distinct blocks and operand rotation s the lane's local tile is (bb+s) & (rep-1).  For full fragments
+// (rep = 4) the LDS offsets of an accumulator's entry depend on (sa, sb) only and are precomputed, so that
+// scattering an accumulator into the strip is one ds_write with an immediate offset.
 template <int NT, int LB>
 struct StripMap
 {
   using S = Sched<NT, LB>;
   int i, bb, j;
-  __device__ __forceinline__ void init(int lane)
+  int dir4[2][4]; // (row & 15) * ncol_pad + (col - 16 b)   for rotations (sa, sb) of full fragments
+  int swp4[2][4]; // (col & 15) * ncol_pad + (row - 16 a)
+  __device__ __forceinline__ void init(int lane, int ncol_pad)
   {
     i = lane >> 4;
     bb = (lane >> 2) & 3;
     j = lane & 3;
+    // static indices only: a run-time indexed member array would move the whole object to scratch memory
+    static_for<0, 2>([&](auto sa_) {
+      static_for<0, 4>([&](auto sb_) {
+        constexpr int sa = sa_, sb = sb_;
+        const int r = 4 * ((bb + sa) & 3) + i, c = 4 * ((bb + sb) & 3) + j;
+        dir4[sa][sb] = r * ncol_pad + c;
+        swp4[sa][sb] = c * ncol_pad + r;
+      });
+    });
   }
   // row / column of the computed block held by this lane for product (a,b,r)
   template <int A, int R, bool SYM>
@@ -426,8 +512,8 @@ struct StripMap
 
 // Scatter the accumulators' entries that fall into row strip STRIP (rows 16*STRIP.. of the block) into the
 // LDS strip [16][ncol_pad]; SYM additionally mirrors (i,j) -> (j,i); TRANSPOSE scatters the transposed
-// block instead.
-template <int NT, int LB, bool SYM, bool TRANSPOSE, int STRIP>
+// block instead.  FULL: n == 16 NT, every tile of every fragment is live - no bounds checks, precomputed offsets.
+template <int NT, int LB, bool SYM, bool TRANSPOSE, int STRIP, bool FULL>
 __device__ __forceinline__ void fill_strip(const double *acc, double *strip, int ncol_pad, const StripMap<NT, LB> &sm, int n)
 {
   using S = Sched<NT, LB>;
@@ -445,18 +531,39 @@ __device__ __forceinline__ void fill_strip(const double *acc, double *strip, int
           constexpr unsigned msk = SYM ? S::sym_mask(a, b, r) : S::full_mask(a, b, r);
           if constexpr (msk != 0u)
             {
-              const int R = sm.template row<a, r, SYM>(), C = sm.template col<b, r, SYM>();
               const double v = acc[acc_idx<NT>(a, b, r)];
-              bool ok = (R < n) && (C < n);
-              if constexpr (msk != 0xfu)
-                ok = ok && (((msk >> sm.bb) & 1u) != 0u);
-              if (ok)
+              constexpr int sa = S::sa(r, SYM), sb = S::sb(r, SYM);
+              if constexpr (FULL && LB == 4)
                 {
-                  if constexpr (do_direct)
-                    strip[(R & 15) * ncol_pad + C] = v;
-                  if constexpr (do_swap)
-                    if (TRANSPOSE || (R >> 2) != (C >> 2))
-                      strip[(C & 15) * ncol_pad + R] = v;
+                  bool ok = true;
+                  if constexpr (msk != 0xfu)
+                    ok = ((msk >> sm.bb) & 1u) != 0u;
+                  if (ok)
+                    {
+                      if constexpr (do_direct)
+                        strip[sm.dir4[sa][sb] + 16 * b] = v;
+                      if constexpr (do_swap)
+                        {
+                          // mirror only strictly off-diagonal tiles (a == b: tile (bb+sa) vs (bb+sb), i.e. r != 0)
+                          if constexpr (TRANSPOSE || a != b || r != 0)
+                            strip[sm.swp4[sa][sb] + 16 * a] = v;
+                        }
+                    }
+                }
+              else
+                {
+                  const int R = sm.template row<a, r, SYM>(), C = sm.template col<b, r, SYM>();
+                  bool ok = (R < n) && (C < n);
+                  if constexpr (msk != 0xfu)
+                    ok = ok && (((msk >> sm.bb) & 1u) != 0u);
+                  if (ok)
+                    {
+                      if constexpr (do_direct)
+                        strip[(R & 15) * ncol_pad + C] = v;
+                      if constexpr (do_swap)
+                        if (TRANSPOSE || (R >> 2) != (C >> 2))
+                          strip[(C & 15) * ncol_pad + R] = v;
+                    }
                 }
             }
         });
@@ -554,23 +661,16 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
         }
         __syncthreads();
         const int nsteps = (cnt + 3) >> 2;
-        FragRaw<DIM> raw[NT]; // table entries of the step being computed, loaded one step ahead
-        {
-          const char *rb = reinterpret_cast<const char *>(rec + kq * RC::LEN);
-          static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
-        }
+        StepRaw<DIM, N1D, NT, LB> raw; // table entries of the step being computed, loaded one step ahead
+        raw.load(reinterpret_cast<const char *>(rec + kq * RC::LEN), lb);
         for (int step = 0; step < nsteps; ++step)
           {
             double phi[NT], dphi[NT][DIM];
-            static_for<0, NT>([&](auto a_) {
-              constexpr int a = a_;
-              raw[a].eval(phi[a], dphi[a]);
-            });
+            raw.template eval_grad<REACT>(phi, dphi);
             {
               // prefetch the next step (the last iteration re-reads its own point: always a valid record)
               const int ptn = 4 * ((step + 1 < nsteps) ? step + 1 : step) + kq;
-              const char *rb = reinterpret_cast<const char *>(rec + ptn * RC::LEN);
-              static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
+              raw.load(reinterpret_cast<const char *>(rec + ptn * RC::LEN), lb);
             }
             RotSet<NT> RG[DIM];
             static_for<0, DIM>([&](auto c_) {
@@ -637,25 +737,18 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
         }
         __syncthreads();
         const int nsteps = (cnt + 3) >> 2;
-        FragRaw<DIM> raw[NT];
+        StepRaw<DIM, N1D, NT, LB> raw;
         double hs; // sigma/2 of the step being computed
-        {
-          const char *rb = reinterpret_cast<const char *>(rec + kq * RC::LEN);
-          static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
-          hs = aux[kq * AUXN + 1];
-        }
+        raw.load(reinterpret_cast<const char *>(rec + kq * RC::LEN), lb);
+        hs = aux[kq * AUXN + 1];
         for (int step = 0; step < nsteps; ++step)
           {
             double Phi[NT], U[NT];
-            static_for<0, NT>([&](auto a_) {
-              constexpr int a = a_;
-              // Phi = sqrt(w) phi,  U = sqrt(w) (-1/2 grad phi . n + sigma/2 phi)
-              raw[a].eval_u(hs, Phi[a], U[a]);
-            });
+            // Phi = sqrt(w) phi,  U = sqrt(w) (-1/2 grad phi . n + sigma/2 phi)
+            raw.eval_u(hs, Phi, U);
             {
               const int ptn = 4 * ((step + 1 < nsteps) ? step + 1 : step) + kq;
-              const char *rb = reinterpret_cast<const char *>(rec + ptn * RC::LEN);
-              static_for<0, NT>([&](auto a_) { raw[a_].load(rb, lb.off[a_]); });
+              raw.load(reinterpret_cast<const char *>(rec + ptn * RC::LEN), lb);
               hs = aux[ptn * AUXN + 1];
             }
             RotSet<NT> RU, RPhi;
@@ -675,11 +768,20 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   const int rlen = P.row_len[slot];
   const int L = P.diag_L[slot];
   StripMap<NT, LB> sm;
-  sm.init(lane);
+  sm.init(lane, ncol_pad);
+  const bool full = (n == 16 * NT);
   static_for<0, NT>([&](auto s_) {
     constexpr int s = s_;
     __syncthreads();
-    fill_strip<NT, LB, true, false, s>(acc, strip, ncol_pad, sm, n);
+    if constexpr (LB == 4) // the unchecked variant exists for completely filled blocks only
+      {
+        if (full)
+          fill_strip<NT, LB, true, false, s, true>(acc, strip, ncol_pad, sm, n);
+        else
+          fill_strip<NT, LB, true, false, s, false>(acc, strip, ncol_pad, sm, n);
+      }
+    else
+      fill_strip<NT, LB, true, false, s, false>(acc, strip, ncol_pad, sm, n);
     __syncthreads();
     store_strip<true>(P.values, rbase, rlen, L, P.diag_first, strip, ncol_pad, s, n, lane);
   });
@@ -785,7 +887,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
   const int ncol_pad = 16 * NT + 2;
   double *strip = lds;
   StripMap<NT, LB> sm;
-  sm.init(lane);
+  sm.init(lane, ncol_pad);
+  const bool full = (n == 16 * NT);
   {
     const int64_t rbase = P.row_base[slot];
     const int rlen = P.row_len[slot];
@@ -793,7 +896,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
     static_for<0, NT>([&](auto s_) {
       constexpr int s = s_;
       __syncthreads();
-      fill_strip<NT, LB, false, false, s>(acc, strip, ncol_pad, sm, n);
+      if constexpr (LB == 4)
+        {
+          if (full)
+            fill_strip<NT, LB, false, false, s, true>(acc, strip, ncol_pad, sm, n);
+          else
+            fill_strip<NT, LB, false, false, s, false>(acc, strip, ncol_pad, sm, n);
+        }
+      else
+        fill_strip<NT, LB, false, false, s, false>(acc, strip, ncol_pad, sm, n);
       __syncthreads();
       store_strip<false>(P.values, rbase, rlen, pos0, 0, strip, ncol_pad, s, n, lane);
     });
@@ -808,7 +919,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
       static_for<0, NT>([&](auto s_) {
         constexpr int s = s_;
         __syncthreads();
-        fill_strip<NT, LB, false, true, s>(acc, strip, ncol_pad, sm, n);
+        if constexpr (LB == 4)
+          {
+            if (full)
+              fill_strip<NT, LB, false, true, s, true>(acc, strip, ncol_pad, sm, n);
+            else
+              fill_strip<NT, LB, false, true, s, false>(acc, strip, ncol_pad, sm, n);
+          }
+        else
+          fill_strip<NT, LB, false, true, s, false>(acc, strip, ncol_pad, sm, n);
         __syncthreads();
         store_strip<false>(P.values, qbase, qlen, post, 0, strip, ncol_pad, s, n, lane);
       });
