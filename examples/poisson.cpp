@@ -54,6 +54,28 @@ int main(int argc, char **argv)
   for (double x : values)
     sum += x;
   std::printf("sum of entries (constants are in the kernel of the interior operator; Nitsche rows remain): %.12g\n", sum);
+  // PolyUtils::compute_global_error (reference include/poly_utils.h:1647-1750) on the device evaluation path, with
+  // u_h = 0 and u = prod_c sin(2 pi x_c): the norms of u itself, (1/2)^(dim/2) and 2 pi sqrt(dim) (1/2)^(dim/2)
+  const double two_pi = 2.0 * M_PI;
+  const auto err = PolyUtilsHIP::compute_global_error(
+    ctx, F, std::vector<double>(ah.n_dofs(), 0.0),
+    [&](const double *x) {
+      double u = 1;
+      for (int c = 0; c < dim; ++c)
+        u *= std::sin(two_pi * x[c]);
+      return u;
+    },
+    [&](const double *x, double *g) {
+      for (int d = 0; d < dim; ++d)
+        {
+          g[d] = two_pi * std::cos(two_pi * x[d]);
+          for (int c = 0; c < dim; ++c)
+            if (c != d)
+              g[d] *= std::sin(two_pi * x[c]);
+        }
+    });
+  std::printf("compute_global_error(u_h=0): L2 %.10f (exact %.10f)  H1-semi %.10f (exact %.10f)\n", err[0],
+              std::pow(0.5, 0.5 * dim), err[1], two_pi * std::sqrt((double)dim) * std::pow(0.5, 0.5 * dim));
   pdh_destroy(ctx);
   return 0;
 }

@@ -111,6 +111,14 @@ int pdh_assemble_sip_local(pdh_ctx *ctx, const pdh_problem *problem, int32_t row
  * rhs   : [row_end-row_begin] host output for the owned rows, overwritten.  Rows are in dof order.      */
 int pdh_assemble_rhs(pdh_ctx *ctx, const double *f_vol, const double *g_bdry, double *rhs);
 
+/* Evaluation of a polytopal DG function at caller-given points: the device part of
+ * PolyUtils::interpolate_to_fine_grid (include/poly_utils.h:1145-1274: points = support points of the sub-cells)
+ * and PolyUtils::compute_global_error (:1686-1731: points = quadrature points; the JxW-weighted sums stay with the
+ * caller).  solution: coefficients of the owned rows [row_end-row_begin]; pt_ptr [n_agg+1]: CSR offsets of the
+ * points of every polytope; pts [dim][N] real coordinates; u [N] (required) and grad [dim][N] (may be NULL) receive
+ * u_h and grad u_h at the points of the polytopes owned by this context (others are left untouched).        */
+int pdh_evaluate(pdh_ctx *ctx, const double *solution, const int64_t *pt_ptr, const double *pts, double *u, double *grad);
+
 /* Access to device-resident results and synchronisation. */
 int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values);
 int pdh_synchronize(pdh_ctx *ctx);

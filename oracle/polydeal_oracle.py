@@ -817,3 +817,31 @@ def interpolate_nodal(ah: AgglomerationHandler, func):
         x = lo + nodes * (hi - lo)
         u[ah.dof_indices(P)] = func(x)
     return u
+
+
+# ===================================================================================================
+# Post-processing
+# ===================================================================================================
+def evaluate_at(ah: AgglomerationHandler, u, P: int, x):
+    """u_h and grad u_h of polytope P at real points x [N, dim]: basis on the bounding box, values through
+    BoundingBox::real_to_unit, gradients scaled by the inverse box extents.
+    include/poly_utils.h:1196-1233 (interpolate_to_fine_grid) and :1699-1711 (compute_global_error)."""
+    lo, hi = ah.bboxes[P]
+    val, ugrad = ah.fe.shape(ah.real_to_unit(P, np.atleast_2d(x)))
+    coef = np.asarray(u)[ah.dof_indices(P)]
+    return val @ coef, np.einsum("qic,i->qc", ugrad * (1.0 / (hi - lo)), coef)
+
+
+def compute_global_error(ah: AgglomerationHandler, u, exact, exact_grad=None):
+    """L2 error and H1-seminorm error over the polytopes' own quadrature:
+    include/poly_utils.h:1647-1750 (sum_q (u-u_h)^2 JxW, sum_q |grad u - grad u_h|^2 JxW, sqrt of the sums)."""
+    l2 = h1 = 0.0
+    for P in range(ah.n_agglomerates):
+        fv = ah.reinit(P)
+        coef = np.asarray(u)[ah.dof_indices(P)]
+        uh = fv["val"] @ coef
+        l2 += float(np.sum((exact(fv["x"]) - uh) ** 2 * fv["JxW"]))
+        if exact_grad is not None:
+            gh = np.einsum("qic,i->qc", fv["grad"], coef)
+            h1 += float(np.sum(np.sum((exact_grad(fv["x"]) - gh) ** 2, axis=1) * fv["JxW"]))
+    return np.sqrt(l2), (np.sqrt(h1) if exact_grad is not None else None)

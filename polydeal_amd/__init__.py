@@ -8,4 +8,6 @@ from ._capi import Context, PdhError, Problem, load_library, PDH_BASIS_AGGLODGP,
 from .handler import (AgglomerationHandler, BackgroundGrid, FE_AggloDGP, FE_DGQ, FiniteElement, HostError,  # noqa: F401
                       SipVariant, assemble_dg_matrix)
 
+from .postprocess import compute_global_error, interpolate_to_points  # noqa: F401
+
 __version__ = "0.1"

@@ -43,7 +43,7 @@ EXPORTS = [
     "pdh_create", "pdh_destroy", "pdh_last_error", "pdh_set_problem", "pdh_set_problem_local",
     "pdh_assemble_device", "pdh_assemble", "pdh_assemble_sip", "pdh_assemble_sip_local",
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
-    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work",
+    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate",
 ]
 
 _lib = None
@@ -63,6 +63,7 @@ def _bind(lib):
     lib.pdh_assemble_sip.argtypes = [C.c_void_p, P(pdh_problem), C.c_void_p]
     lib.pdh_assemble_sip_local.argtypes = [C.c_void_p, P(pdh_problem), C.c_int32, C.c_int32, C.c_void_p]
     lib.pdh_assemble_rhs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pdh_evaluate.argtypes = [C.c_void_p] * 6
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
     lib.pdh_stream.argtypes = [C.c_void_p]
@@ -151,6 +152,13 @@ class Context:
         row_end = prob.c.n_rows if row_end is None else row_end
         self._chk(self.lib.pdh_set_problem_local(self.h, C.byref(prob.c), row_begin, row_end))
         self.n_values = self.stats()["n_values"]
+        off = np.array((C.c_int32 * prob.c.n_agg).from_address(int(prob.c.dof_offset)), dtype=np.int64)
+        self._owned = (off >= row_begin) & (off < row_end)  # polytopes whose rows live here
+
+    def owned_point_mask(self, pt_ptr):
+        """Boolean mask over per-polytope CSR points: True for the points of polytopes owned by this context."""
+        ptr = np.asarray(pt_ptr, dtype=np.int64)
+        return np.repeat(self._owned, np.diff(ptr))
 
     def assemble_device(self):
         self._chk(self.lib.pdh_assemble_device(self.h))
@@ -172,6 +180,18 @@ class Context:
         self._chk(self.lib.pdh_assemble_rhs(self.h, None if fv is None else fv.ctypes.data,
                                             None if gb is None else gb.ctypes.data, out.ctypes.data))
         return out
+
+    def evaluate(self, solution, pt_ptr, pts, want_grad=False):
+        """u_h (and grad u_h) at caller-given real points; pt_ptr [n_agg+1], pts [dim][N]."""
+        sol = np.ascontiguousarray(solution, dtype=np.float64)
+        ptr = np.ascontiguousarray(pt_ptr, dtype=np.int64)
+        p = np.ascontiguousarray(pts, dtype=np.float64)
+        n = int(ptr[-1])
+        u = np.zeros(n)
+        g = np.zeros((p.shape[0], n)) if want_grad else None
+        self._chk(self.lib.pdh_evaluate(self.h, sol.ctypes.data, ptr.ctypes.data, p.ctypes.data, u.ctypes.data,
+                                        None if g is None else g.ctypes.data))
+        return (u, g) if want_grad else u
 
     def device_values(self):
         p, n = C.c_void_p(), C.c_int64()

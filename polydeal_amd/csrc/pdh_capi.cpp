@@ -30,6 +30,10 @@ PDH_DECL(0) PDH_DECL(1) PDH_DECL(2) PDH_DECL(3) PDH_DECL(4) PDH_DECL(5) PDH_DECL
 extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int count, const double *f_vol,
                                      const double *g_face, double *rhs, hipStream_t stream);
 
+extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *P, int count, const double *coef,
+                                      const int64_t *pt_ptr, const double *pts, int64_t pts_stride, double *out_u,
+                                      double *out_g, hipStream_t stream);
+
 static pdh_launch_fn g_launch[PDH_N_GROUPS] = {pdh_launch_g0, pdh_launch_g1, pdh_launch_g2, pdh_launch_g3,
                                                pdh_launch_g4, pdh_launch_g5, pdh_launch_g6, pdh_launch_g7};
 
@@ -86,6 +90,7 @@ struct pdh_ctx
   struct FaceRun { int64_t ap_begin, fq_begin; int32_t count; int32_t boundary; };
   std::vector<FaceRun> face_runs;
   int64_t n_rows_owned = 0;
+  int32_t n_agg_total = 0;
   int64_t mfma_diag = 0, mfma_offdiag = 0; // MFMA instructions per launch
   bool profiling = false;
   std::vector<hipEvent_t> events; // 3 per profiled launch: before k_diag, between, after k_offdiag
@@ -565,6 +570,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   for (size_t r = 0; r < K.run_ap.size(); ++r)
     ctx->face_runs.push_back({K.run_ap[r], K.run_fq[r], K.run_cnt[r], K.run_bdry[r]});
   ctx->n_rows_owned = (int64_t)K.own_agg.size() * K.n;
+  ctx->n_agg_total = p->n_agg;
   {
     // executed work: k-steps of 4 points per chunk (64 points in k_diag for NT >= 3, else 32; 32 in k_offdiag)
     const int64_t i_sym = sched_instr_rt(K.NT, K.LB, true), i_full = sched_instr_rt(K.NT, K.LB, false);
@@ -720,6 +726,84 @@ extern "C" int pdh_assemble_rhs(pdh_ctx *ctx, const double *f_vol, const double 
   cleanup();
   if (e != hipSuccess)
     return fail(ctx, PDH_EDEVICE, std::string("pdh_assemble_rhs: ") + hipGetErrorString(e));
+  return PDH_OK;
+}
+
+extern "C" int pdh_evaluate(pdh_ctx *ctx, const double *solution, const int64_t *pt_ptr, const double *pts, double *u,
+                            double *grad)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (!ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "pdh_evaluate called before pdh_set_problem");
+  if (!solution || !pt_ptr || !pts || !u)
+    return fail(ctx, PDH_EINVAL, "solution, pt_ptr, pts and u are required");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  // points of the owned polytopes, compacted in slot order
+  std::vector<int32_t> own((size_t)ctx->n_owned);
+  PDH_HIP(ctx, hipMemcpy(own.data(), ctx->dev.own_agg, own.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::vector<int64_t> lptr((size_t)ctx->n_owned + 1, 0);
+  for (int sl = 0; sl < ctx->n_owned; ++sl)
+    {
+      const int64_t c = pt_ptr[own[sl] + 1] - pt_ptr[own[sl]];
+      if (c < 0)
+        return fail(ctx, PDH_EINVAL, "pt_ptr must be non-decreasing");
+      lptr[sl + 1] = lptr[sl] + c;
+    }
+  const int dim = ctx->dev.dim;
+  const int64_t n_loc = lptr.back(), n_all = pt_ptr[ctx->n_agg_total];
+  std::vector<double> lp((size_t)std::max<int64_t>(n_loc, 1) * dim);
+  for (int sl = 0; sl < ctx->n_owned; ++sl)
+    for (int64_t q = 0; q < lptr[sl + 1] - lptr[sl]; ++q)
+      for (int c = 0; c < dim; ++c)
+        lp[(size_t)c * n_loc + lptr[sl] + q] = pts[(size_t)c * n_all + pt_ptr[own[sl]] + q];
+  double *d_sol = nullptr, *d_pts = nullptr, *d_u = nullptr, *d_g = nullptr;
+  int64_t *d_ptr = nullptr;
+  auto cleanup = [&]() {
+    for (void *p : {(void *)d_sol, (void *)d_pts, (void *)d_u, (void *)d_g, (void *)d_ptr})
+      if (p)
+        (void)hipFree(p);
+  };
+  hipError_t e = hipMalloc((void **)&d_sol, std::max<int64_t>(ctx->n_rows_owned, 1) * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMemcpy(d_sol, solution, ctx->n_rows_owned * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&d_pts, lp.size() * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMemcpy(d_pts, lp.data(), lp.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&d_ptr, lptr.size() * sizeof(int64_t));
+  if (e == hipSuccess)
+    e = hipMemcpy(d_ptr, lptr.data(), lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&d_u, std::max<int64_t>(n_loc, 1) * sizeof(double));
+  if (e == hipSuccess && grad)
+    e = hipMalloc((void **)&d_g, (size_t)std::max<int64_t>(n_loc, 1) * dim * sizeof(double));
+  if (e == hipSuccess)
+    e = pdh_launch_eval(dim, ctx->dev.n1d, grad ? 1 : 0, &ctx->dev, ctx->n_owned, d_sol, d_ptr, d_pts, n_loc, d_u, d_g,
+                        ctx->stream);
+  std::vector<double> hu((size_t)std::max<int64_t>(n_loc, 1)), hg;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(hu.data(), d_u, n_loc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && grad)
+    {
+      hg.resize((size_t)std::max<int64_t>(n_loc, 1) * dim);
+      e = hipMemcpyAsync(hg.data(), d_g, (size_t)n_loc * dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess)
+    return fail(ctx, PDH_EDEVICE, std::string("pdh_evaluate: ") + hipGetErrorString(e));
+  // scatter back into the caller's point order (points of polytopes not owned here are left untouched)
+  for (int sl = 0; sl < ctx->n_owned; ++sl)
+    for (int64_t q = 0; q < lptr[sl + 1] - lptr[sl]; ++q)
+      {
+        u[pt_ptr[own[sl]] + q] = hu[lptr[sl] + q];
+        if (grad)
+          for (int c = 0; c < dim; ++c)
+            grad[(size_t)c * n_all + pt_ptr[own[sl]] + q] = hg[(size_t)c * n_loc + lptr[sl] + q];
+      }
   return PDH_OK;
 }
 

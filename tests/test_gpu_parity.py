@@ -152,6 +152,9 @@ def test_cpp_examples_run():
     out = subprocess.run([os.path.join(root, "examples", "poisson")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Assembled DoF/s" in out.stdout
+    line = [l for l in out.stdout.split("\n") if l.startswith("compute_global_error")][0].replace("(", " ").replace(")", " ")
+    t = line.split()
+    assert abs(float(t[4]) - float(t[6])) < 1e-8 and abs(float(t[8]) - float(t[10])) < 1e-6, line
     # the reference's test minimal_SIP_Poisson.cc re-written against the C++ host mirror: its stdout must be the
     # reference's expected output file
     out = subprocess.run([os.path.join(root, "examples", "minimal_SIP_Poisson_test")], capture_output=True, text=True,
@@ -345,3 +348,88 @@ def test_random_irregular_agglomerates(dim, lg, n_seeds, fe_cls, p, seed, disc):
         _, _, ref = po.assemble_csr(ah, var)
         got = gpu_values(flatten(ah, var))
         assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("dim,lg,b,fe_cls,p,dist", [
+    (2, 3, 2, po.FE_DGQ, 2, 0.2),
+    (2, 3, 4, po.FE_AggloDGP, 4, 0.0),
+    (3, 2, 2, po.FE_DGQ, 3, 0.1),
+    (3, 2, 2, po.FE_AggloDGP, 3, 0.0),
+])
+def test_evaluate_and_global_error_parity(dim, lg, b, fe_cls, p, dist):
+    """pdh_evaluate vs the oracle (values and gradients at the volume quadrature points, 1e-12 relative) and
+    PolyUtils::compute_global_error (include/poly_utils.h:1647-1750) rebuilt on top of it; also on a row range."""
+    import polydeal_amd as pa
+    from polydeal_amd.partition import row_range
+
+    fe = fe_cls(dim, p)
+    ah = build(dim, lg, b, fe, p + 1, distort=dist)
+    var = po.variant_poisson_example(fe)
+    kw = flatten(ah, var)
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(ah.n_dofs)
+    exact = lambda x: np.sin(1.3 * x[:, 0]) * np.cos(0.7 * x[:, 1]) + (x[:, -1] ** 2 if dim == 3 else 0.0)
+
+    def exact_grad(x):
+        g = np.zeros_like(x)
+        g[:, 0] = 1.3 * np.cos(1.3 * x[:, 0]) * np.cos(0.7 * x[:, 1])
+        g[:, 1] = -0.7 * np.sin(1.3 * x[:, 0]) * np.sin(0.7 * x[:, 1])
+        if dim == 3:
+            g[:, 2] = 2 * x[:, 2]
+        return g
+
+    prob = pa.Problem(**kw)
+    ctx = pa.Context(0)
+    ctx.set_problem(prob)
+    uh, gh = ctx.evaluate(u, kw["vq_ptr"], kw["vq_x"], want_grad=True)
+    uh_only = ctx.evaluate(u, kw["vq_ptr"], kw["vq_x"])
+    l2, h1 = pa.compute_global_error(ctx, kw["vq_ptr"], kw["vq_x"], kw["vq_w"], u, exact, exact_grad)
+    ref_u = np.concatenate([po.evaluate_at(ah, u, P, ah.reinit(P)["x"])[0] for P in range(ah.n_agglomerates)])
+    ref_g = np.concatenate([po.evaluate_at(ah, u, P, ah.reinit(P)["x"])[1] for P in range(ah.n_agglomerates)]).T
+    assert np.array_equal(uh, uh_only)
+    assert np.max(np.abs(uh - ref_u)) <= TOL * np.max(np.abs(ref_u))
+    assert np.max(np.abs(gh - ref_g)) <= TOL * np.max(np.abs(ref_g))
+    rl2, rh1 = po.compute_global_error(ah, u, exact, exact_grad)
+    assert abs(l2 - rl2) <= TOL * rl2 and abs(h1 - rh1) <= TOL * rh1
+
+    # two "ranks": squares of the partial errors add up (poly_utils.h:1736-1745)
+    s2 = np.zeros(2)
+    for r in range(2):
+        rb, re = row_range(ah.n_agglomerates, fe.n_dofs_per_cell, r, 2)
+        ctx.set_problem(prob, rb, re)
+        a, c = pa.compute_global_error(ctx, kw["vq_ptr"], kw["vq_x"], kw["vq_w"], u[rb:re], exact, exact_grad)
+        s2 += [a * a, c * c]
+    ctx.close()
+    assert abs(np.sqrt(s2[0]) - rl2) <= TOL * rl2 and abs(np.sqrt(s2[1]) - rh1) <= TOL * rh1
+
+
+def test_poisson_output_L2_error_evaluated_on_gpu():
+    """'L2 error:0.00647702' (test/polydeal/poisson.output) with matrix, right-hand side AND the
+    interpolate_to_fine_grid evaluation (u_h at the vertices of every sub-cell, include/poly_utils.h:1196-1233)
+    on the HIP path; only the sparse solve and the one-point integrate_difference sum stay on the host."""
+    import polydeal_amd as pa
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from test_oracle_golden import _poisson_test_setup
+
+    grid, ah, var = _poisson_test_setup()
+    kw = flatten(ah, var, diag_first=False)
+    prob = pa.Problem(**kw)
+    ctx = pa.Context(0)
+    ctx.set_problem(prob)
+    vals = ctx.assemble()
+    pi = np.pi
+    xq = kw["vq_x"]
+    b = ctx.assemble_rhs(8 * pi * pi * np.sin(2 * pi * xq[0]) * np.sin(2 * pi * xq[1]), None)
+    A = sp.csr_matrix((vals, kw["colind"], kw["rowptr"]), shape=(ah.n_dofs, ah.n_dofs))
+    u = spla.spsolve(A.tocsc(), b)
+    cells = [ah.get_agglomerate(P) for P in range(ah.n_agglomerates)]
+    pt_ptr = np.concatenate([[0], np.cumsum([4 * len(c) for c in cells])])
+    pts = np.concatenate([grid.vertices[c] for cs in cells for c in cs]).T  # [2][4*n_cells]
+    uv = pa.interpolate_to_points(ctx, u, pt_ptr, pts).reshape(-1, 4)
+    ctx.close()
+    V = np.stack([grid.vertices[c] for cs in cells for c in cs])  # [n_cells,4,2]
+    mid = V.mean(axis=1)
+    h2 = (V[:, 1, 0] - V[:, 0, 0]) * (V[:, 2, 1] - V[:, 0, 1])
+    err = np.sqrt(np.sum(h2 * (uv.mean(axis=1) - np.sin(2 * pi * mid[:, 0]) * np.sin(2 * pi * mid[:, 1])) ** 2))
+    assert "L2 error:" + gc.fmt(err) == gc.golden_lines("poisson.output")[0]

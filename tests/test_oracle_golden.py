@@ -264,3 +264,21 @@ def test_reinit_cell_face_02_and_agglomerated_neighbors_01():
     assert gc.render_reinit_cell_face_02(ah) == gc.golden_lines("reinit_cell_face_02.output")[:-1]
     _, ah = make(2, 3, gc.GROUPS_FOUR)
     assert gc.render_neighbors_02(ah) == gc.golden_lines("agglomerated_neighbors_01.output")[:-1]
+
+
+def test_compute_global_error_known_answers():
+    """oracle.compute_global_error (include/poly_utils.h:1647-1750): zero for a function in the polytopal space,
+    and the analytic value for u_h = 0 (||xy||_L2 = 1/3, |xy|_H1 = sqrt(2/3) on the unit square)."""
+    fe = po.FE_DGQ(2, 2)
+    grid = po.hyper_cube_refined(2, 0.0, 1.0, 3)
+    ah = po.AgglomerationHandler(grid)
+    for g in po.block_agglomerates(grid, 2):
+        ah.define_agglomerate(g)
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(fe)
+    f = lambda x: x[:, 0] * x[:, 1]
+    df = lambda x: np.stack([x[:, 1], x[:, 0]], axis=1)
+    l2, h1 = po.compute_global_error(ah, po.interpolate_nodal(ah, f), f, df)
+    assert l2 < 1e-14 and h1 < 1e-13
+    l2, h1 = po.compute_global_error(ah, np.zeros(ah.n_dofs), f, df)
+    assert abs(l2 - 1.0 / 3.0) < 1e-14 and abs(h1 - np.sqrt(2.0 / 3.0)) < 1e-14

@@ -3,3 +3,4 @@ struct PdhDev;
 #define S(g) extern "C" hipError_t pdh_launch_g##g(int,int,int,int,int,const PdhDev*,int,size_t,hipStream_t){return hipSuccess;}
 S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 extern "C" hipError_t pdh_launch_rhs(int,int,const PdhDev*,int,const double*,const double*,double*,hipStream_t){return hipSuccess;}
+extern "C" hipError_t pdh_launch_eval(int,int,int,const PdhDev*,int,const double*,const int64_t*,const double*,int64_t,double*,double*,hipStream_t){return hipSuccess;}
