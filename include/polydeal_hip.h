@@ -119,6 +119,14 @@ int pdh_assemble_rhs(pdh_ctx *ctx, const double *f_vol, const double *g_bdry, do
  * u_h and grad u_h at the points of the polytopes owned by this context (others are left untouched).        */
 int pdh_evaluate(pdh_ctx *ctx, const double *solution, const int64_t *pt_ptr, const double *pts, double *u, double *grad);
 
+/* Values of all basis functions of a set of bounding boxes at caller-given points - the local matrices of
+ * Utils::fill_injection_matrix (include/utils.h:219-229: local_matrix(i,j) = fe.shape_value(j,
+ * coarse_bbox.real_to_unit(real_qpoints[i]))); needs no resident problem.  bbox [n_boxes][2][dim] (lower corner,
+ * upper corner); pt_ptr [n_boxes+1] CSR offsets of the points of every box; pts [dim][N] real coordinates;
+ * values [N][n] row-major, n = dofs per cell of (dim, degree, basis).                                         */
+int pdh_shape_values(pdh_ctx *ctx, int dim, int degree, int basis, int n_boxes, const double *bbox,
+                     const int64_t *pt_ptr, const double *pts, double *values);
+
 /* Access to device-resident results and synchronisation. */
 int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values);
 int pdh_synchronize(pdh_ctx *ctx);

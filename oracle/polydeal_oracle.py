@@ -845,3 +845,23 @@ def compute_global_error(ah: AgglomerationHandler, u, exact, exact_grad=None):
             gh = np.einsum("qic,i->qc", fv["grad"], coef)
             h1 += float(np.sum(np.sum((exact_grad(fv["x"]) - gh) ** 2, axis=1) * fv["JxW"]))
     return np.sqrt(l2), (np.sqrt(h1) if exact_grad is not None else None)
+
+
+def fill_injection_matrix(coarse_ah: AgglomerationHandler, fine_ah: AgglomerationHandler):
+    """Dense injection matrix [n_fine_dofs, n_coarse_dofs] from the coarse polytopal space into the fine one:
+    include/utils.h:95-270.  Block (child F, parent C): local(i, j) = phi^C_j(coarse_bbox.real_to_unit(
+    fine_bbox.unit_to_real(unit support point i)))  (:212-229).  Children = fine polytopes nested in C
+    (the reference reads them from the R-tree hierarchy, :169, 203)."""
+    fe = coarse_ah.fe
+    assert isinstance(fe, FE_DGQ)
+    nodes = fe.nodes[fe.multi_index]  # unit support points [n, dim]
+    M = np.zeros((fine_ah.n_dofs, coarse_ah.n_dofs))
+    for F in range(fine_ah.n_agglomerates):
+        cells = fine_ah.get_agglomerate(F)
+        C = coarse_ah.polytope_of_cell(cells[0])
+        assert all(coarse_ah.polytope_of_cell(c) == C for c in cells), "not nested"
+        lo, hi = fine_ah.bboxes[F]
+        real = lo + nodes * (hi - lo)  # BoundingBox::unit_to_real
+        val, _ = fe.shape(coarse_ah.real_to_unit(C, real))
+        M[np.ix_(fine_ah.dof_indices(F), coarse_ah.dof_indices(C))] = val
+    return M

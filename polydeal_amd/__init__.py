@@ -6,7 +6,7 @@ There is no CPU compute path: without libpolydeal_hip.so / a HIP device the comp
 """
 from ._capi import Context, PdhError, Problem, load_library, PDH_BASIS_AGGLODGP, PDH_BASIS_DGQ  # noqa: F401
 from .handler import (AgglomerationHandler, BackgroundGrid, FE_AggloDGP, FE_DGQ, FiniteElement, HostError,  # noqa: F401
-                      SipVariant, assemble_dg_matrix)
+                      SipVariant, assemble_dg_matrix, fill_injection_matrix)
 
 from .postprocess import compute_global_error, interpolate_to_points  # noqa: F401
 

@@ -43,7 +43,7 @@ EXPORTS = [
     "pdh_create", "pdh_destroy", "pdh_last_error", "pdh_set_problem", "pdh_set_problem_local",
     "pdh_assemble_device", "pdh_assemble", "pdh_assemble_sip", "pdh_assemble_sip_local",
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
-    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate",
+    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values",
 ]
 
 _lib = None
@@ -64,6 +64,7 @@ def _bind(lib):
     lib.pdh_assemble_sip_local.argtypes = [C.c_void_p, P(pdh_problem), C.c_int32, C.c_int32, C.c_void_p]
     lib.pdh_assemble_rhs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pdh_evaluate.argtypes = [C.c_void_p] * 6
+    lib.pdh_shape_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
     lib.pdh_stream.argtypes = [C.c_void_p]
@@ -192,6 +193,18 @@ class Context:
         self._chk(self.lib.pdh_evaluate(self.h, sol.ctypes.data, ptr.ctypes.data, p.ctypes.data, u.ctypes.data,
                                         None if g is None else g.ctypes.data))
         return (u, g) if want_grad else u
+
+    def shape_values(self, dim, degree, basis, bbox, pt_ptr, pts):
+        """phi_j(x_q) of the box basis (dim, degree, basis) for every box's points: [N][n]."""
+        bb = np.ascontiguousarray(bbox, dtype=np.float64).reshape(-1, 2 * dim)
+        ptr = np.ascontiguousarray(pt_ptr, dtype=np.int64)
+        p = np.ascontiguousarray(pts, dtype=np.float64)
+        from .handler import FiniteElement
+        n = FiniteElement(dim, degree, basis).n_dofs_per_cell
+        out = np.zeros((int(ptr[-1]), n))
+        self._chk(self.lib.pdh_shape_values(self.h, dim, degree, basis, bb.shape[0], bb.ctypes.data, ptr.ctypes.data,
+                                            p.ctypes.data, out.ctypes.data))
+        return out
 
     def device_values(self):
         p, n = C.c_void_p(), C.c_int64()

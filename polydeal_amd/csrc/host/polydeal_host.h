@@ -917,4 +917,93 @@ inline std::array<double, 2> compute_global_error(pdh_ctx *ctx, const FlatProble
   return {std::sqrt(l2), std::sqrt(h1)};
 }
 } // namespace PolyUtilsHIP
+
+namespace Utils
+{
+// Utils::fill_injection_matrix (reference include/utils.h:95-270): the injection from the coarse polytopal
+// space into the fine one, row block of fine polytope F / column block of its parent C:
+//   local_matrix(i, j) = phi^C_j( coarse_bbox.real_to_unit( fine_bbox.unit_to_real(support point i) ) ).
+// The reference takes polytope->children() from the R-tree hierarchy; here the children of C are the fine
+// polytopes whose cells lie in C (the two handlers must be nested over the same grid, checked).  Needs support
+// points, i.e. FE_DGQ (FE_AggloDGP has none: reference include/fe_agglodgp.h:63).  The basis evaluation runs on
+// the device (pdh_shape_values); output is CSR over fine rows x coarse columns, n entries per row.
+inline void fill_injection_matrix(const AgglomerationHandler &coarse_ah, const AgglomerationHandler &fine_ah,
+                                  std::vector<int64_t> &rowptr, std::vector<int32_t> &colind, std::vector<double> &values,
+                                  int device = 0)
+{
+  const FiniteElement &fe = coarse_ah.get_fe();
+  if (fe.basis != PDH_BASIS_DGQ || fine_ah.get_fe().basis != fe.basis || fine_ah.get_fe().degree != fe.degree)
+    throw std::invalid_argument("fill_injection_matrix needs the same FE_DGQ space on both handlers");
+  if (&coarse_ah.get_triangulation() != &fine_ah.get_triangulation())
+    throw std::invalid_argument("both handlers must live on the same grid");
+  if (!(coarse_ah.n_dofs() < fine_ah.n_dofs()))
+    throw std::invalid_argument("the coarse space must be smaller than the fine one"); // utils.h:120
+  const int dim = fe.dim, n = fe.n_dofs_per_cell(), n1d = fe.degree + 1;
+  const int nC = (int)coarse_ah.n_agglomerates(), nF = (int)fine_ah.n_agglomerates();
+  // parent of every fine polytope; all its cells must share it
+  std::vector<int> parent(nF);
+  std::vector<std::vector<int>> children(nC);
+  for (int F = 0; F < nF; ++F)
+    {
+      parent[F] = coarse_ah.cell_to_polytope_index(fine_ah.master_index(F));
+      for (int cell : fine_ah.get_agglomerate(F))
+        if (coarse_ah.cell_to_polytope_index(cell) != parent[F])
+          throw std::invalid_argument("fine polytopes are not nested in the coarse ones");
+      children[parent[F]].push_back(F);
+    }
+  // unit support points: tensor Gauss-Lobatto nodes, lexicographic [deal.II FE_DGQ]
+  const auto nodes = pdh::gauss_lobatto_nodes(fe.degree);
+  const auto mi = pdh::multi_indices(dim, fe.degree, fe.basis);
+  // real support points of the children, grouped by parent (utils.h:212-217)
+  std::vector<int64_t> pt_ptr(nC + 1, 0);
+  for (int C = 0; C < nC; ++C)
+    pt_ptr[C + 1] = pt_ptr[C] + (int64_t)children[C].size() * n;
+  const int64_t N = pt_ptr[nC];
+  std::vector<double> pts((size_t)N * dim), bb((size_t)nC * 2 * dim);
+  std::vector<int> row_of_point((size_t)N);
+  for (int C = 0; C < nC; ++C)
+    {
+      for (int c = 0; c < dim; ++c)
+        {
+          bb[(size_t)C * 2 * dim + c] = coarse_ah.bbox(C)[c];
+          bb[(size_t)C * 2 * dim + dim + c] = coarse_ah.bbox(C)[3 + c];
+        }
+      int64_t q = pt_ptr[C];
+      for (int F : children[C])
+        for (int i = 0; i < n; ++i, ++q)
+          {
+            for (int c = 0; c < dim; ++c)
+              {
+                const double lo = fine_ah.bbox(F)[c], hi = fine_ah.bbox(F)[3 + c];
+                pts[(size_t)c * N + q] = lo + (double)nodes[(mi[i] >> (8 * c)) & 0xff] * (hi - lo); // unit_to_real
+              }
+            row_of_point[q] = fine_ah.dof_offset_of(F) + i;
+          }
+    }
+  (void)n1d;
+  std::vector<double> local((size_t)N * n);
+  pdh_ctx *ctx = nullptr;
+  if (pdh_create(&ctx, device) != PDH_OK)
+    throw std::runtime_error(std::string("pdh_create: ") + pdh_last_error(nullptr));
+  const int rc = pdh_shape_values(ctx, dim, fe.degree, fe.basis, nC, bb.data(), pt_ptr.data(), pts.data(), local.data());
+  const std::string msg = rc == PDH_OK ? "" : pdh_last_error(ctx);
+  pdh_destroy(ctx);
+  if (rc != PDH_OK)
+    throw std::runtime_error("pdh_shape_values: " + msg);
+  // the sparsity of utils.h:166-185: every fine row couples with the n dofs of its parent
+  const int64_t rows = fine_ah.n_dofs();
+  rowptr.resize(rows + 1);
+  for (int64_t r = 0; r <= rows; ++r)
+    rowptr[r] = r * n;
+  colind.resize((size_t)rows * n);
+  values.resize((size_t)rows * n);
+  for (int C = 0; C < nC; ++C)
+    for (int64_t q = pt_ptr[C]; q < pt_ptr[C + 1]; ++q)
+      for (int j = 0; j < n; ++j)
+        {
+          colind[(size_t)row_of_point[q] * n + j] = coarse_ah.dof_offset_of(C) + j;
+          values[(size_t)row_of_point[q] * n + j] = local[(size_t)q * n + j];
+        }
+}
+} // namespace Utils
 } // namespace polydeal_hip

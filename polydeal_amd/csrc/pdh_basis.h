@@ -7,8 +7,10 @@
 //                      index order "for iz: for iy < n1d-iz: for ix < n1d-iy-iz" (x fastest);
 //                      C(p+dim,dim) dofs (source/fe_agglodgp.cc:89-101).
 //
-// The kernels evaluate 1-D basis functions by Horner's rule from monomial coefficients; the
-// coefficients are generated here in long double.
+// The kernels evaluate 1-D basis functions by Horner's rule from monomial coefficients in the CENTRED variable
+// t = x - 1/2 (|t| <= 1/2 on the box: the coefficients of degree-7 Lagrange polynomials in x reach 1e4 and cost
+// three to four digits in the cancellation; in t the evaluation stays at a few ulp).  The coefficients are
+// generated here in long double.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -19,7 +21,7 @@ namespace pdh
 struct Basis1D
 {
   int n1d = 0;
-  std::vector<std::vector<long double>> coef; // coef[k][m]
+  std::vector<std::vector<long double>> coef; // coef[k][m]: phi_k(x) = sum_m coef[k][m] (x - 1/2)^m
 };
 
 inline std::vector<long double> gauss_lobatto_nodes(int p)
@@ -77,7 +79,7 @@ inline Basis1D lagrange_basis(int p)
             for (size_t m = 0; m < c.size(); ++m)
               {
                 d[m + 1] += c[m];
-                d[m] -= nodes[j] * c[m];
+                d[m] -= (nodes[j] - 0.5L) * c[m];
               }
             c.swap(d);
             denom *= nodes[k] - nodes[j];
@@ -95,14 +97,12 @@ inline Basis1D legendre_basis(int p)
   std::vector<std::vector<long double>> P(p + 1, std::vector<long double>(p + 1, 0.0L));
   P[0][0] = 1.0L;
   if (p >= 1)
-    {
-      P[1][0] = -1.0L;
-      P[1][1] = 2.0L;
-    }
+    P[1][1] = 2.0L; // P_1(2x-1) = 2t
   for (int k = 1; k < p; ++k)
     for (int m = 0; m <= p; ++m)
       {
-        long double v = -(long double)(2 * k + 1) * P[k][m];
+        // (k+1) P_{k+1} = (2k+1) (2t) P_k - k P_{k-1}
+        long double v = 0.0L;
         if (m > 0)
           v += (long double)(2 * k + 1) * 2.0L * P[k][m - 1];
         v -= (long double)k * P[k - 1][m];

@@ -34,6 +34,9 @@ extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *
                                       const int64_t *pt_ptr, const double *pts, int64_t pts_stride, double *out_u,
                                       double *out_g, hipStream_t stream);
 
+extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_boxes, const int64_t *pt_ptr,
+                                       const double *pts, int64_t pts_stride, double *out, hipStream_t stream);
+
 static pdh_launch_fn g_launch[PDH_N_GROUPS] = {pdh_launch_g0, pdh_launch_g1, pdh_launch_g2, pdh_launch_g3,
                                                pdh_launch_g4, pdh_launch_g5, pdh_launch_g6, pdh_launch_g7};
 
@@ -804,6 +807,83 @@ extern "C" int pdh_evaluate(pdh_ctx *ctx, const double *solution, const int64_t 
           for (int c = 0; c < dim; ++c)
             grad[(size_t)c * n_all + pt_ptr[own[sl]] + q] = hg[(size_t)c * n_loc + lptr[sl] + q];
       }
+  return PDH_OK;
+}
+
+extern "C" int pdh_shape_values(pdh_ctx *ctx, int dim, int degree, int basis, int n_boxes, const double *bbox,
+                                const int64_t *pt_ptr, const double *pts, double *values)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (dim < 2 || dim > 3 || degree < 0 || (basis != PDH_BASIS_DGQ && basis != PDH_BASIS_AGGLODGP))
+    return fail(ctx, PDH_EINVAL, "dim must be 2 or 3, degree >= 0, basis DGQ or AGGLODGP");
+  if (n_boxes < 0 || (n_boxes > 0 && (!bbox || !pt_ptr || !pts || !values)))
+    return fail(ctx, PDH_EINVAL, "bbox, pt_ptr, pts and values are required");
+  const int n = pdh::n_dofs_per_cell(dim, degree, basis);
+  const int n1d = degree + 1;
+  if (n > 64 || n1d > (dim == 2 ? 8 : 6))
+    return fail(ctx, PDH_EUNSUPPORTED, "no kernel instantiated for this (dim, basis, degree)");
+  if (n_boxes == 0)
+    return PDH_OK;
+  for (int b = 0; b < n_boxes; ++b)
+    {
+      if (pt_ptr[b + 1] < pt_ptr[b])
+        return fail(ctx, PDH_EINVAL, "pt_ptr must be non-decreasing");
+      for (int c = 0; c < dim; ++c)
+        if (!(bbox[(size_t)b * 2 * dim + dim + c] > bbox[(size_t)b * 2 * dim + c]))
+          return fail(ctx, PDH_EINVAL, "degenerate bounding box");
+    }
+  if (pt_ptr[0] != 0)
+    return fail(ctx, PDH_EINVAL, "pt_ptr[0] must be 0");
+  const int64_t N = pt_ptr[n_boxes];
+  if (N == 0)
+    return PDH_OK;
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PdhDev D;
+  std::memset(&D, 0, sizeof(D));
+  D.dim = dim;
+  D.n = n;
+  D.n1d = n1d;
+  const pdh::Basis1D b1 = (basis == PDH_BASIS_DGQ) ? pdh::lagrange_basis(degree) : pdh::legendre_basis(degree);
+  for (int k = 0; k < n1d; ++k)
+    for (int m = 0; m < n1d; ++m)
+      D.tab.coef[k][m] = (double)b1.coef[k][m];
+  const auto mi = pdh::multi_indices(dim, degree, basis);
+  std::vector<int32_t> midx(64, (int32_t)0xffffffffu);
+  for (int i = 0; i < n; ++i)
+    midx[i] = (int32_t)mi[i];
+  double *d_bbox = nullptr, *d_pts = nullptr, *d_out = nullptr;
+  int64_t *d_ptr = nullptr;
+  int32_t *d_midx = nullptr;
+  auto cleanup = [&]() {
+    for (void *p : {(void *)d_bbox, (void *)d_pts, (void *)d_out, (void *)d_ptr, (void *)d_midx})
+      if (p)
+        (void)hipFree(p);
+  };
+  auto up = [&](void **d, const void *h, size_t bytes) {
+    hipError_t e = hipMalloc(d, bytes);
+    return e == hipSuccess ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : e;
+  };
+  hipError_t e = up((void **)&d_bbox, bbox, (size_t)n_boxes * 2 * dim * sizeof(double));
+  if (e == hipSuccess)
+    e = up((void **)&d_pts, pts, (size_t)N * dim * sizeof(double));
+  if (e == hipSuccess)
+    e = up((void **)&d_ptr, pt_ptr, ((size_t)n_boxes + 1) * sizeof(int64_t));
+  if (e == hipSuccess)
+    e = up((void **)&d_midx, midx.data(), midx.size() * sizeof(int32_t));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&d_out, (size_t)N * n * sizeof(double));
+  D.bbox = d_bbox;
+  D.midx = d_midx;
+  if (e == hipSuccess)
+    e = pdh_launch_shape(dim, n1d, &D, n_boxes, d_ptr, d_pts, N, d_out, ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(values, d_out, (size_t)N * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess)
+    return fail(ctx, PDH_EDEVICE, std::string("pdh_shape_values: ") + hipGetErrorString(e));
   return PDH_OK;
 }
 

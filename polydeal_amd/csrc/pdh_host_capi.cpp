@@ -281,5 +281,23 @@ int pdhh_assemble_dg_matrix(void *h, double penalty_constant, int owner_rule, in
     return 0;
   });
 }
+
+// Utils::fill_injection_matrix through C: rowptr [n_fine_dofs+1], colind / values [n_fine_dofs * n].
+int pdhh_fill_injection_matrix(void *coarse, void *fine, int device, int64_t *rowptr, int32_t *colind, double *values,
+                               int64_t n_values)
+{
+  return guarded([&] {
+    std::vector<int64_t> rp;
+    std::vector<int32_t> ci;
+    std::vector<double> va;
+    Utils::fill_injection_matrix(static_cast<HandlerH *>(coarse)->ah, static_cast<HandlerH *>(fine)->ah, rp, ci, va, device);
+    if ((int64_t)va.size() != n_values)
+      throw std::invalid_argument("values buffer has the wrong length");
+    std::memcpy(rowptr, rp.data(), rp.size() * sizeof(int64_t));
+    std::memcpy(colind, ci.data(), ci.size() * sizeof(int32_t));
+    std::memcpy(values, va.data(), va.size() * sizeof(double));
+    return 0;
+  });
+}
 #undef AH
 }

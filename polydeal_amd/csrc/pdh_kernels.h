@@ -261,7 +261,8 @@ __device__ __forceinline__ void eval_point_record(const PdhBasisTab &tab, const 
   constexpr int p = N1D - 1;
   static_for<0, DIM>([&](auto c_) {
     constexpr int c = c_;
-    const double xh = (x[c] - lo[c]) / h[c]; // BoundingBox::real_to_unit (agglomeration_handler.cc:703-704)
+    // BoundingBox::real_to_unit (agglomeration_handler.cc:703-704), then centred: the tables are in t = x^ - 1/2
+    const double xh = (x[c] - lo[c]) / h[c] - 0.5;
     double ih = 1.0 / h[c];                  // inverse_cell_extents (mapping_box.cc:222)
     double sv = 1.0;
     if constexpr (c == 0)

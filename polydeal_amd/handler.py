@@ -57,6 +57,8 @@ def _lib():
         lib.pdhh_flat_sizes.restype = C.c_int64
         lib.pdhh_assemble_dg_matrix.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
                                                 C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        lib.pdhh_fill_injection_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_int64]
         _ready = True
     return lib
 
@@ -331,6 +333,24 @@ def assemble_dg_matrix(fe: FiniteElement, ah: AgglomerationHandler, variant: Sip
     rc = _lib().pdhh_assemble_dg_matrix(ah.h, variant.penalty_constant, variant.owner_rule, variant.h_rule,
                                          variant.boundary, variant.reaction_c, int(diag_first), device,
                                          values.ctypes.data, len(values))
+    if rc < 0:
+        _raise()
+    return rowptr, colind, values
+
+
+def fill_injection_matrix(coarse_ah: AgglomerationHandler, fine_ah: AgglomerationHandler, device=0):
+    """Utils::fill_injection_matrix (reference include/utils.h:95-270): CSR (rowptr, colind, values) of the
+    injection from the coarse polytopal space into the fine one; basis evaluation on the GPU
+    (pdh_shape_values).  The handlers must be nested over the same grid and carry the same FE_DGQ."""
+    if coarse_ah.grid is not fine_ah.grid:
+        raise ValueError("both handlers must live on the same grid")
+    n = fine_ah.n_dofs_per_cell
+    rows = fine_ah.n_dofs
+    rowptr = np.zeros(rows + 1, dtype=np.int64)
+    colind = np.zeros(rows * n, dtype=np.int32)
+    values = np.zeros(rows * n)
+    rc = _lib().pdhh_fill_injection_matrix(coarse_ah.h, fine_ah.h, device, rowptr.ctypes.data, colind.ctypes.data,
+                                            values.ctypes.data, len(values))
     if rc < 0:
         _raise()
     return rowptr, colind, values

@@ -433,3 +433,46 @@ def test_poisson_output_L2_error_evaluated_on_gpu():
     h2 = (V[:, 1, 0] - V[:, 0, 0]) * (V[:, 2, 1] - V[:, 0, 1])
     err = np.sqrt(np.sum(h2 * (uv.mean(axis=1) - np.sin(2 * pi * mid[:, 0]) * np.sin(2 * pi * mid[:, 1])) ** 2))
     assert "L2 error:" + gc.fmt(err) == gc.golden_lines("poisson.output")[0]
+
+
+@pytest.mark.parametrize("dim,lg,bc,bf,p,dist", [
+    (2, 3, 4, 2, 1, 0.0), (2, 3, 4, 1, 3, 0.2), (2, 4, 8, 2, 7, 0.1), (3, 2, 4, 2, 2, 0.1), (3, 2, 2, 1, 3, 0.0),
+])
+def test_injection_matrix_parity(dim, lg, bc, bf, p, dist):
+    """Utils::fill_injection_matrix (include/utils.h:95-270) through the host mirror + pdh_shape_values vs the
+    oracle, 1e-12 relative, and the property of test/polydeal/distributed_injection_01.cc."""
+    import polydeal_amd as pa
+
+    fe_o = po.FE_DGQ(dim, p)
+    grid_o = po.hyper_cube_refined(dim, 0.0, 1.0, lg)
+    grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, lg)
+    if dist:  # the two RNG streams differ: distort the product's grid and copy its vertices
+        grid.distort(dist, seed=3)
+        for cell in range(grid_o.n_cells):
+            grid_o.vertices[cell] = grid.cell_vertices(cell)
+    handlers, oracles = [], []
+    for b in (bc, bf):
+        ah = pa.AgglomerationHandler(grid)
+        ah.define_block_agglomerates(b)
+        ah.initialize_fe_values(p + 1, p + 1)
+        ah.distribute_agglomerated_dofs(pa.FE_DGQ(dim, p))
+        handlers.append(ah)
+        ao = po.AgglomerationHandler(grid_o)
+        for g in po.block_agglomerates(grid_o, b):
+            ao.define_agglomerate(g)
+        ao.initialize_fe_values(p + 1, p + 1)
+        ao.distribute_agglomerated_dofs(fe_o)
+        oracles.append(ao)
+    rp, ci, va = pa.fill_injection_matrix(handlers[0], handlers[1])
+    n = fe_o.n_dofs_per_cell
+    assert np.array_equal(rp, np.arange(len(rp)) * n)
+    M = po.fill_injection_matrix(oracles[0], oracles[1])
+    got = np.zeros_like(M)
+    rows = np.repeat(np.arange(len(rp) - 1), n)
+    got[rows, ci] = va
+    assert np.max(np.abs(got - M)) <= TOL * np.max(np.abs(M))
+    f = lambda x: 1.0 + x[:, 0] ** p - 0.5 * x[:, 1] ** p * x[:, 0] + (x[:, -1] ** p if dim == 3 else 0.0)
+    err = got @ po.interpolate_nodal(oracles[0], f) - po.interpolate_nodal(oracles[1], f)
+    assert np.max(np.abs(err)) < 5e-13
+    with pytest.raises(pa.HostError):
+        pa.fill_injection_matrix(handlers[1], handlers[0])  # coarse must be smaller (utils.h:120)

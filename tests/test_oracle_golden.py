@@ -282,3 +282,32 @@ def test_compute_global_error_known_answers():
     assert l2 < 1e-14 and h1 < 1e-13
     l2, h1 = po.compute_global_error(ah, np.zeros(ah.n_dofs), f, df)
     assert abs(l2 - 1.0 / 3.0) < 1e-14 and abs(h1 - np.sqrt(2.0 / 3.0)) < 1e-14
+
+
+def _nested_pair(dim, lg, b_coarse, b_fine, p, distort=0.0):
+    fe = po.FE_DGQ(dim, p)
+    grid = po.hyper_cube_refined(dim, 0.0, 1.0, lg)
+    if distort:
+        grid.distort(distort, seed=3)
+    out = []
+    for b in (b_coarse, b_fine):
+        ah = po.AgglomerationHandler(grid)
+        for g in po.block_agglomerates(grid, b):
+            ah.define_agglomerate(g)
+        ah.initialize_fe_values(p + 1, p + 1)
+        ah.distribute_agglomerated_dofs(fe)
+        out.append(ah)
+    return out
+
+
+@pytest.mark.parametrize("dim,lg,p,distort", [(2, 3, 1, 0.0), (2, 3, 3, 0.2), (3, 2, 2, 0.1)])
+def test_injection_matrix_reproduces_the_coarse_function(dim, lg, p, distort):
+    """The property test/polydeal/distributed_injection_01.cc checks (its .output prints 'Norm of error(L2):
+    9.97775e-16' / 2.75792e-15): injecting the coarse interpolant of a function of the polytopal space gives the
+    fine interpolant.  Here with a polynomial of degree p per direction on block hierarchies."""
+    coarse, fine = _nested_pair(dim, lg, 4, 2, p, distort)
+    f = lambda x: 1.0 + x[:, 0] ** p - 0.5 * x[:, 1] ** p * x[:, 0] + (x[:, -1] ** p if dim == 3 else 0.0)
+    M = po.fill_injection_matrix(coarse, fine)
+    err = M @ po.interpolate_nodal(coarse, f) - po.interpolate_nodal(fine, f)
+    assert np.max(np.abs(err)) < 5e-14
+    assert np.allclose(M.sum(axis=1), 1.0, atol=1e-13)  # partition of unity: rows sum to one

@@ -4,3 +4,4 @@ struct PdhDev;
 S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 extern "C" hipError_t pdh_launch_rhs(int,int,const PdhDev*,int,const double*,const double*,double*,hipStream_t){return hipSuccess;}
 extern "C" hipError_t pdh_launch_eval(int,int,int,const PdhDev*,int,const double*,const int64_t*,const double*,int64_t,double*,double*,hipStream_t){return hipSuccess;}
+extern "C" hipError_t pdh_launch_shape(int,int,const PdhDev*,int,const int64_t*,const double*,int64_t,double*,hipStream_t){return hipSuccess;}
