@@ -82,6 +82,23 @@ struct PdhDev
   PdhBasisTab tab;
 };
 
+// Experiment switches for tools/ab_bench.py (never defined in the shipped build): time the kernels without their
+// epilogue (-DPDH_EXP_NOSTORE) or without their accumulation loops (-DPDH_EXP_NOCOMPUTE).  Measured on the
+// default bench workload: k_diag 5.75 ms compute-only / 0.42 ms store-only (5.9 together); k_offdiag 1.85 ms
+// compute-only / 1.90 ms store-only (2.47 together).
+#if defined(PDH_EXP_NOCOMPUTE)
+#define PDH_EXP_LOOPCOND &&(P.n < 0)
+#else
+#define PDH_EXP_LOOPCOND
+#endif
+#if defined(PDH_EXP_NOSTORE)
+#define PDH_EXP_EPILOGUE_GUARD                                                                     \
+  if (acc[0] != 1.2345e300)                                                                        \
+    return;
+#else
+#define PDH_EXP_EPILOGUE_GUARD
+#endif
+
 namespace pdh
 {
 template <int I, int N, class F>
@@ -584,18 +601,30 @@ __device__ __forceinline__ void store_strip(double *values, int64_t base, int ro
     {
       double *dst = values + base + (int64_t)(16 * strip_idx) * row_len;
       const double *src = strip + lane;
-      for (int rr = 0; rr < rows; ++rr)
+      // batches of 8 rows: all LDS reads of a batch are in flight before the first store waits for its data
+      // (a read -> wait -> store chain per row exposed the LDS latency 16 times per strip).  The strip always
+      // holds 16 rows, so reading past `rows` is harmless; the stores are predicated.
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 8)
         {
-          int pos = pos0 + lane;
-          if constexpr (DIAG)
-            if (diag_first)
-              {
-                const int R = 16 * strip_idx + rr;
-                pos = (lane == R) ? 0 : (pos0 + lane + (lane < R ? 1 : 0));
-              }
-          dst[pos] = src[0];
-          dst += row_len;
-          src += ncol_pad;
+          double v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            v[k] = src[(r0 + k) * ncol_pad];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            {
+              const int rr = r0 + k;
+              int pos = pos0 + lane;
+              if constexpr (DIAG)
+                if (diag_first)
+                  {
+                    const int R = 16 * strip_idx + rr;
+                    pos = (lane == R) ? 0 : (pos0 + lane + (lane < R ? 1 : 0));
+                  }
+              if (rr < rows)
+                dst[(int64_t)rr * row_len + pos] = v[k];
+            }
         }
     }
 }
@@ -642,7 +671,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   // ---- volume term ---------------------------------------------------------------------------
   {
     const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
-    for (int64_t base = qb; base < qe; base += CH)
+    for (int64_t base = qb; base < qe PDH_EXP_LOOPCOND; base += CH)
       {
         const int cnt = (int)((qe - base < CH) ? (qe - base) : CH);
         __syncthreads();
@@ -705,7 +734,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   // ---- own-side face terms (all faces of the polytope, boundary included) ----------------------
   {
     const int64_t pb = P.ap_ptr[slot], pe = P.ap_ptr[slot + 1];
-    for (int64_t base = pb; base < pe; base += CH)
+    for (int64_t base = pb; base < pe PDH_EXP_LOOPCOND; base += CH)
       {
         const int cnt = (int)((pe - base < CH) ? (pe - base) : CH);
         __syncthreads();
@@ -762,6 +791,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   }
 
   // ---- epilogue: mirror + write rows in CSR order ------------------------------------------------
+  PDH_EXP_EPILOGUE_GUARD
   const int n = P.n;
   const int ncol_pad = 16 * NT + 2;
   double *strip = lds; // overlays the point records
@@ -831,7 +861,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
 
   const int kq = lane >> 4;
   const int64_t pb = P.it_pbeg[item], pe = pb + P.it_pcnt[item];
-  for (int64_t base = pb; base < pe; base += CH)
+  for (int64_t base = pb; base < pe PDH_EXP_LOOPCOND; base += CH)
     {
       const int cnt = (int)((pe - base < CH) ? (pe - base) : CH);
       __syncthreads();
@@ -884,6 +914,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
         }
     }
 
+  PDH_EXP_EPILOGUE_GUARD
   const int n = P.n;
   const int ncol_pad = 16 * NT + 2;
   double *strip = lds;
