@@ -476,3 +476,77 @@ def test_injection_matrix_parity(dim, lg, bc, bf, p, dist):
     assert np.max(np.abs(err)) < 5e-13
     with pytest.raises(pa.HostError):
         pa.fill_injection_matrix(handlers[1], handlers[0])  # coarse must be smaller (utils.h:120)
+
+
+def _dense_from_gpu(ah, var, diag_first=True):
+    kw = flatten(ah, var, diag_first=diag_first)
+    vals = gpu_values(kw)
+    return po.csr_to_dense(kw["rowptr"], kw["colind"], vals, ah.n_dofs), kw
+
+
+@pytest.mark.parametrize("dim,fe_cls,p", [(2, po.FE_DGQ, 2), (3, po.FE_AggloDGP, 2), (3, po.FE_DGQ, 3)])
+def test_single_polytope_has_no_interior_faces(dim, fe_cls, p):
+    """Edge case: the whole mesh is one polytope - zero coupling items, one boundary face made of every boundary
+    sub-face (agglomeration_handler.cc:1575-1577).  Also the other extreme: every cell its own polytope."""
+    fe = fe_cls(dim, p)
+    lg = 2 if dim == 2 else 1
+    ah = build(dim, lg, 2 ** lg, fe, p + 1)
+    assert ah.n_agglomerates == 1 and ah.n_faces_of(0) == 1
+    var = po.variant_poisson_example(fe)
+    A, kw = _dense_from_gpu(ah, var)
+    assert kw["n_faces"] == 1
+    ref = po.assemble_dense(ah, var)
+    assert np.max(np.abs(A - ref)) <= TOL * np.max(np.abs(ref))
+    ah1 = build(dim, lg, 1, fe, p + 1, distort=0.1)
+    A1, _ = _dense_from_gpu(ah1, var, diag_first=False)
+    ref1 = po.assemble_dense(ah1, var)
+    assert np.max(np.abs(A1 - ref1)) <= TOL * np.max(np.abs(ref1))
+
+
+@pytest.mark.parametrize("groups", [gc.GROUPS_FOUR, gc.GROUPS_QUAD_PTS])
+def test_poisson_sanity_identities_on_gpu(groups):
+    """test/polydeal/poisson_sanity_check_03.output (v^T A v = 1, 2, ~1e-14 for v = x, x+y, 1 on ANY agglomeration
+    of the unit square, boundary terms dropped) with the matrix from the HIP path."""
+    grid = po.hyper_cube_refined(2, 0.0, 1.0, 3)
+    ah = po.AgglomerationHandler(grid)
+    gc.define_with_singletons(ah, grid.n_cells, groups)
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(po.FE_DGQ(2, 1))
+    var = po.SipVariant("sanity", 10.0, "index", "diameter_in", boundary="zero")
+    A, _ = _dense_from_gpu(ah, var)
+    forms = [float(v @ A @ v) for v in (po.interpolate_nodal(ah, f) for f in
+                                         (lambda x: x[:, 0], lambda x: x[:, 0] + x[:, 1], lambda x: np.ones(len(x))))]
+    assert abs(forms[0] - 1.0) < 1e-12 and abs(forms[1] - 2.0) < 1e-12 and abs(forms[2]) < 1e-12
+    lines = gc.golden_lines("poisson_sanity_check_03.output")
+    assert "Test with f(x,y)=x:" + gc.fmt(round(forms[0], 12)) == lines[1]
+    assert "Test with f(x,y)=x+y:" + gc.fmt(round(forms[1], 12)) == lines[2]
+
+
+@pytest.mark.parametrize("fe_cls,p", [(po.FE_DGQ, 1), (po.FE_AggloDGP, 1), (po.FE_AggloDGP, 2), (po.FE_DGQ, 2)])
+def test_exact_solution_reproduced_all_on_gpu(fe_cls, p):
+    """test/polydeal/exact_solutions_dgp.cc:685-704: a solution inside the polytopal space is reproduced to
+    ~1e-14 on a randomly distorted grid - matrix, Nitsche right-hand side and the error evaluation on the HIP
+    path (dense solve on the host)."""
+    import polydeal_amd as pa
+
+    grid = po.hyper_cube_refined(2, 0.0, 1.0, 2).distort(0.25, seed=1)
+    ah = po.AgglomerationHandler(grid)
+    for g in [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]:
+        ah.define_agglomerate(g)
+    fe = fe_cls(2, p)
+    ah.initialize_fe_values(2 * p + 1, 2 * p + 1)
+    ah.distribute_agglomerated_dofs(fe)
+    var = po.variant_poisson_example(fe)
+    u_ex = (lambda x: x[:, 0] + x[:, 1] - 1.0) if p == 1 else (lambda x: x[:, 0] ** 2 + x[:, 0] * x[:, 1])
+    lap = 0.0 if p == 1 else -2.0
+    kw = flatten(ah, var)
+    prob = pa.Problem(**kw)
+    ctx = pa.Context(0)
+    ctx.set_problem(prob)
+    A = po.csr_to_dense(kw["rowptr"], kw["colind"], ctx.assemble(), ah.n_dofs)
+    b = ctx.assemble_rhs(np.full(kw["vq_x"].shape[1], lap), u_ex(kw["fq_x"].T))
+    u = np.linalg.solve(A, b)
+    l2, _ = pa.compute_global_error(ctx, kw["vq_ptr"], kw["vq_x"], kw["vq_w"], u, u_ex)
+    ctx.close()
+    assert l2 < 1e-12
+    assert np.max(np.abs(A - A.T)) < 1e-11 * np.max(np.abs(A))
