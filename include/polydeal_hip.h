@@ -132,6 +132,16 @@ int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values);
 int pdh_synchronize(pdh_ctx *ctx);
 void *pdh_stream(pdh_ctx *ctx); /* hipStream_t the kernels are launched on */
 
+/* Two algebraically identical forms of the same sums exist (results differ by rounding only, both are tested against
+ * the oracle): DIRECT contracts basis values over the quadrature points for all n^2 pairs (f64 MFMA, pdh_kernels.h);
+ * MOMENT first reduces the quadrature to (2p+1)^3 Legendre moments per polytope / face and obtains the blocks by sum
+ * factorisation (pdh_moment.h; 3-D, degree 1..3).  AUTO picks the faster one for the resident problem.          */
+#define PDH_ALG_AUTO 0
+#define PDH_ALG_DIRECT 1
+#define PDH_ALG_MOMENT 2
+int pdh_set_algorithm(pdh_ctx *ctx, int algorithm);
+int pdh_algorithm_in_use(pdh_ctx *ctx); /* PDH_ALG_DIRECT or PDH_ALG_MOMENT for the resident problem, < 0 on error */
+
 /* Measurement helpers (HIP events on the context's stream).  kernel 0 = diagonal-block kernel
  * (volume + own-side face terms), kernel 1 = off-diagonal (interface coupling) kernel.            */
 #define PDH_N_KERNELS 2

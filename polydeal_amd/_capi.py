@@ -43,7 +43,7 @@ EXPORTS = [
     "pdh_create", "pdh_destroy", "pdh_last_error", "pdh_set_problem", "pdh_set_problem_local",
     "pdh_assemble_device", "pdh_assemble", "pdh_assemble_sip", "pdh_assemble_sip_local",
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
-    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values",
+    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values", "pdh_set_algorithm", "pdh_algorithm_in_use",
 ]
 
 _lib = None
@@ -64,6 +64,8 @@ def _bind(lib):
     lib.pdh_assemble_sip_local.argtypes = [C.c_void_p, P(pdh_problem), C.c_int32, C.c_int32, C.c_void_p]
     lib.pdh_assemble_rhs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pdh_evaluate.argtypes = [C.c_void_p] * 6
+    lib.pdh_set_algorithm.argtypes = [C.c_void_p, C.c_int]
+    lib.pdh_algorithm_in_use.argtypes = [C.c_void_p]
     lib.pdh_shape_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
@@ -210,6 +212,16 @@ class Context:
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self.lib.pdh_device_values(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def set_algorithm(self, alg):
+        """'auto' | 'direct' (MFMA contraction over the points) | 'moment' (Legendre moments + sum factorisation)."""
+        self._chk(self.lib.pdh_set_algorithm(self.h, {"auto": 0, "direct": 1, "moment": 2}[alg]))
+
+    def algorithm_in_use(self):
+        rc = self.lib.pdh_algorithm_in_use(self.h)
+        if rc < 0:
+            self._chk(rc)
+        return {1: "direct", 2: "moment"}[rc]
 
     def set_profiling(self, on=True):
         self._chk(self.lib.pdh_set_profiling(self.h, int(on)))

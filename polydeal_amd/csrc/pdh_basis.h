@@ -148,6 +148,106 @@ inline std::vector<uint32_t> multi_indices(int dim, int p, int basis /*0 DGQ, 1 
   return mi;
 }
 
+// n-point Gauss-Legendre rule on [0,1] (Newton on P_n, long double)
+inline void gauss_legendre01(int n, std::vector<long double> &x, std::vector<long double> &w)
+{
+  x.assign(n, 0.0L);
+  w.assign(n, 0.0L);
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int i = 0; i < n; ++i)
+    {
+      long double t = -std::cos(pi * (i + 0.75L) / (n + 0.5L)), dp = 1.0L;
+      for (int it = 0; it < 100; ++it)
+        {
+          long double p0 = 1.0L, p1 = t;
+          for (int k = 1; k < n; ++k)
+            {
+              const long double p2 = ((2 * k + 1) * t * p1 - k * p0) / (k + 1);
+              p0 = p1;
+              p1 = p2;
+            }
+          dp = n * (t * p1 - p0) / (t * t - 1.0L);
+          const long double dt = p1 / dp;
+          t -= dt;
+          if (std::fabs((double)dt) < 1e-19)
+            break;
+        }
+      x[i] = 0.5L * (t + 1.0L);
+      w[i] = 1.0L / ((1.0L - t * t) * dp * dp); // = (2 / ((1-t^2) P_n'^2)) / 2 for the unit interval
+    }
+}
+
+// Tables of the moment form (pdh_moment.h, layout MT<N1D>): expansions of the 1-D products B_k B_l, B'_k B'_l and
+// (B_k B_l)' in the L2-orthonormal Legendre polynomials L_a(x) = sqrt(2a+1) P_a(2x-1), a <= 2p, followed by the
+// data of the per-face rule (Gauss points, L_a(x_g) w_g, B_k(x_g), B'_k(x_g)).
+inline std::vector<double> moment_tables(int p, int basis)
+{
+  const Basis1D b = (basis == 0) ? lagrange_basis(p) : legendre_basis(p);
+  const int n1d = p + 1, NA = 2 * n1d - 1, NAP = NA + 1, NG = 2 * n1d, TAB = n1d * n1d * NAP;
+  auto eval = [&](int k, long double x, long double &val, long double &der) {
+    const long double t = x - 0.5L;
+    val = b.coef[k][p];
+    der = 0.0L;
+    for (int m = p - 1; m >= 0; --m)
+      {
+        der = der * t + val;
+        val = val * t + b.coef[k][m];
+      }
+  };
+  auto leg = [&](int a, long double x) {
+    const long double t = 2.0L * x - 1.0L;
+    long double p0 = 1.0L, p1 = t;
+    if (a == 0)
+      return 1.0L;
+    for (int k = 1; k < a; ++k)
+      {
+        const long double p2 = ((2 * k + 1) * t * p1 - k * p0) / (k + 1);
+        p0 = p1;
+        p1 = p2;
+      }
+    return std::sqrt((long double)(2 * a + 1)) * p1;
+  };
+  std::vector<double> out((size_t)3 * TAB + NG + NA * NG + 2 * n1d * NG, 0.0);
+  std::vector<long double> qx, qw;
+  gauss_legendre01(2 * n1d + 2, qx, qw); // exact to degree 4p+7
+  for (int k = 0; k < n1d; ++k)
+    for (int l = 0; l < n1d; ++l)
+      for (int a = 0; a < NA; ++a)
+        {
+          long double e = 0.0L, d = 0.0L, f = 0.0L;
+          for (size_t g = 0; g < qx.size(); ++g)
+            {
+              long double vk, dk, vl, dl;
+              eval(k, qx[g], vk, dk);
+              eval(l, qx[g], vl, dl);
+              const long double la = leg(a, qx[g]) * qw[g];
+              e += vk * vl * la;
+              d += dk * dl * la;
+              f += (dk * vl + vk * dl) * la;
+            }
+          out[(size_t)0 * TAB + (k * n1d + l) * NAP + a] = (double)e;
+          out[(size_t)1 * TAB + (k * n1d + l) * NAP + a] = (double)d;
+          out[(size_t)2 * TAB + (k * n1d + l) * NAP + a] = (double)f;
+        }
+  std::vector<long double> gx, gw;
+  gauss_legendre01(NG, gx, gw);
+  const size_t off_gx = (size_t)3 * TAB, off_gl = off_gx + NG, off_bv = off_gl + (size_t)NA * NG, off_bd = off_bv + (size_t)n1d * NG;
+  for (int g = 0; g < NG; ++g)
+    {
+      out[off_gx + g] = (double)gx[g];
+      for (int a = 0; a < NA; ++a)
+        out[off_gl + (size_t)a * NG + g] = (double)(leg(a, gx[g]) * gw[g]);
+      for (int k = 0; k < n1d; ++k)
+        {
+          long double v, d;
+          eval(k, gx[g], v, d);
+          out[off_bv + (size_t)k * NG + g] = (double)v;
+          out[off_bd + (size_t)k * NG + g] = (double)d;
+        }
+    }
+  return out;
+}
+
 inline int n_dofs_per_cell(int dim, int p, int basis)
 {
   return (int)multi_indices(dim, p, basis).size();

@@ -37,6 +37,9 @@ extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *
 extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_boxes, const int64_t *pt_ptr,
                                        const double *pts, int64_t pts_stride, double *out, hipStream_t stream);
 
+extern "C" hipError_t pdh_launch_moment(int n1d, int which, const PdhDev *P, const double *mtab, int count, hipStream_t stream);
+extern "C" int pdh_moment_table_doubles(int n1d);
+
 static pdh_launch_fn g_launch[PDH_N_GROUPS] = {pdh_launch_g0, pdh_launch_g1, pdh_launch_g2, pdh_launch_g3,
                                                pdh_launch_g4, pdh_launch_g5, pdh_launch_g6, pdh_launch_g7};
 
@@ -95,6 +98,19 @@ struct pdh_ctx
   int64_t n_rows_owned = 0;
   int32_t n_agg_total = 0;
   int64_t mfma_diag = 0, mfma_offdiag = 0; // MFMA instructions per launch
+  // moment form (pdh_moment.h): available for 3-D bases of degree <= 3; `algorithm` = caller's choice
+  int algorithm = PDH_ALG_AUTO;
+  int basis = 0;
+  double *d_mtab = nullptr;
+  bool use_moment() const
+  {
+    if (!d_mtab || algorithm == PDH_ALG_DIRECT)
+      return false;
+    if (algorithm == PDH_ALG_MOMENT)
+      return true;
+    // auto: where the moment form was measured faster than the MFMA contraction (profiles/README.md)
+    return basis == PDH_BASIS_DGQ && dev.n1d == 4;
+  }
   bool profiling = false;
   std::vector<hipEvent_t> events; // 3 per profiled launch: before k_diag, between, after k_offdiag
   size_t ev_used = 0;
@@ -594,9 +610,39 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
     ctx->mfma_diag = kv * (p->dim + (p->reaction_c != 0.0 ? 1 : 0)) * i_sym + kf * 2 * i_sym;
     ctx->mfma_offdiag = ko * 2 * i_full;
   }
+  ctx->basis = p->basis;
+  ctx->d_mtab = nullptr;
+  if (p->dim == 3 && K.n1d >= 2 && K.n1d <= 4)
+    {
+      const std::vector<double> mt = pdh::moment_tables(p->degree, p->basis);
+      if ((int)mt.size() != pdh_moment_table_doubles(K.n1d))
+        return fail(ctx, PDH_EDEVICE, "moment table size mismatch");
+      void *dm = nullptr;
+      PDH_HIP(ctx, hipMalloc(&dm, mt.size() * sizeof(double)));
+      ctx->allocs.push_back(dm);
+      PDH_HIP(ctx, hipMemcpy(dm, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice));
+      ctx->d_mtab = static_cast<double *>(dm);
+    }
   ctx->has_problem = true;
   ctx->ev_used = 0;
   return PDH_OK;
+}
+
+extern "C" int pdh_set_algorithm(pdh_ctx *ctx, int algorithm)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (algorithm != PDH_ALG_AUTO && algorithm != PDH_ALG_DIRECT && algorithm != PDH_ALG_MOMENT)
+    return fail(ctx, PDH_EINVAL, "algorithm must be PDH_ALG_AUTO, PDH_ALG_DIRECT or PDH_ALG_MOMENT");
+  ctx->algorithm = algorithm;
+  return PDH_OK;
+}
+
+extern "C" int pdh_algorithm_in_use(pdh_ctx *ctx)
+{
+  if (!ctx || !ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "no problem resident");
+  return ctx->use_moment() ? PDH_ALG_MOMENT : PDH_ALG_DIRECT;
 }
 
 extern "C" int pdh_set_problem(pdh_ctx *ctx, const pdh_problem *p)
@@ -625,10 +671,22 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
         return fail(ctx, PDH_EDEVICE, "hipEventCreate failed");
       PDH_HIP(ctx, hipEventRecord(e0, ctx->stream));
     }
-  PDH_HIP(ctx, fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
-  if (ctx->profiling)
-    PDH_HIP(ctx, hipEventRecord(e1, ctx->stream));
-  PDH_HIP(ctx, fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
+  if (ctx->algorithm == PDH_ALG_MOMENT && !ctx->d_mtab)
+    return fail(ctx, PDH_EUNSUPPORTED, "the moment form exists for 3-D bases of degree 1..3 only");
+  if (ctx->use_moment())
+    {
+      PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_owned, ctx->stream));
+      if (ctx->profiling)
+        PDH_HIP(ctx, hipEventRecord(e1, ctx->stream));
+      PDH_HIP(ctx, pdh_launch_moment(n1d, 1, &ctx->dev, ctx->d_mtab, ctx->n_items, ctx->stream));
+    }
+  else
+    {
+      PDH_HIP(ctx, fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
+      if (ctx->profiling)
+        PDH_HIP(ctx, hipEventRecord(e1, ctx->stream));
+      PDH_HIP(ctx, fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
+    }
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(e2, ctx->stream));
   return PDH_OK;
@@ -937,8 +995,8 @@ extern "C" int pdh_kernel_work(pdh_ctx *ctx, int64_t *mfma_instr)
 {
   if (!ctx || !ctx->has_problem || !mfma_instr)
     return fail(ctx, PDH_ESTATE, "no problem resident");
-  mfma_instr[0] = ctx->mfma_diag;
-  mfma_instr[1] = ctx->mfma_offdiag;
+  mfma_instr[0] = ctx->use_moment() ? 0 : ctx->mfma_diag; // the moment form issues no MFMA at all
+  mfma_instr[1] = ctx->use_moment() ? 0 : ctx->mfma_offdiag;
   return PDH_OK;
 }
 

@@ -1,0 +1,837 @@
+// pdh_moment.h — the moment ("quadrature-free contraction") form of the SIP blocks, 3-D tensor-product bases.
+//
+// The direct kernels (pdh_kernels.h) contract  sum_q w_q f_i(x_q) g_j(x_q)  for all n^2 pairs: 2 d Nq n^2 flops per
+// polytope, MFMA-bound for n = 64.  Here the same sums are reorganised exactly (no approximation, the quadrature
+// rule stays the caller's): every integrand of the path is a product of 1-D polynomials of the bounding-box
+// coordinates, e.g. for the volume term
+//     d_c phi_i d_c phi_j = h_c^-2 [B'_k B'_l](x^_c)  prod_{d != c} [B_k B_l](x^_d),       i = (k0,k1,k2), j = (l0,l1,l2)
+// and each 1-D product of degree <= 2p is expanded ONCE (host tables, exact Gauss quadrature in long double) in the
+// L2-orthonormal Legendre polynomials L_a of [0,1]:   B_k B_l = sum_a E[k,l,a] L_a,  B'_k B'_l = sum_a D[k,l,a] L_a,
+// (B_k B_l)' = sum_a Fs[k,l,a] L_a.   Then with the MOMENTS of the quadrature
+//     M[a0,a1,a2] = sum_q w_q L_a0(x^_0) L_a1(x^_1) L_a2(x^_2)                         ((2p+1)^3 numbers)
+// the block is   A_ij = sum_a X[k0,l0,a0] Y[k1,l1,a1] Z[k2,l2,a2] M[a]   - evaluated by sum factorisation.
+// Face terms use moments weighted by  w sigma  and  -w n_c / 2;  a coupling block A[P,Q] uses tables of the mixed
+// products B^P_k(t) B^Q_l(alpha t + beta) (the two bounding-box frames differ by an axis-aligned affine map), built
+// per face on the device by an exact Gauss rule.  Cost per polytope: O(Nq (2p+1)^3) for the moments plus
+// O((p+1)^2d (2p+1)) for the contraction, instead of O(Nq n^2) - for FE_DGQ(3) about 8x fewer operations, all VALU,
+// which moves the headline workload from the f64 MFMA roof to the HBM write roof of the matrix values.
+// Numerics: every expansion is exact for polynomials, so results differ from the direct form by rounding only
+// (1e-14 relative measured; tests/test_gpu_parity.py runs both forms against the oracle).
+//
+// The statement of WHAT is computed is unchanged (reference include/poly_utils.h:2040-2084, 1870-1926, see
+// pdh_kernels.h); this file only changes the order of summation.
+#pragma once
+#include "pdh_kernels.h"
+
+// experiment switches (tools/ab_bench.py): -DPDHM_EXP=1 no per-face tables, 2 no moment accumulation, 3 no contraction,
+// 4 no stores - coupling kernel only; results are then garbage
+#ifndef PDHM_EXP
+#define PDHM_EXP 0
+#endif
+#if PDHM_EXP == 4
+#define PDHM_STORE_OK (P.n < 0)
+#else
+#define PDHM_STORE_OK true
+#endif
+
+namespace pdhm
+{
+using pdh::static_for;
+
+template <int N1D>
+struct MT
+{
+  static constexpr int NA = 2 * N1D - 1; // Legendre modes 0 .. 2p
+  static constexpr int NAP = NA + 1;     // padded (even: 16-byte rows)
+  static constexpr int NG = 2 * N1D;     // Gauss points of the per-face table rule: exact to degree 4p+3 >= 4p
+  static constexpr int PAIRS = N1D * N1D;
+  static constexpr int TAB = PAIRS * NAP; // one expansion table [k][l][NAP] in the global buffer
+  // In LDS the table rows and the T2 rows use a stride of NAP + 2 doubles: with 64-byte rows the 16 rows a wave
+  // touches in one ds_read_b128 (lanes differing in two 1-D indices) fall on four bank groups only - a 16-way conflict
+  // that made the contraction 8x slower than its instruction count; 80-byte rows are conflict-free.
+  static constexpr int RS = NAP + 2;
+  static constexpr int LTAB = PAIRS * RS;
+  // layout of the device table buffer (doubles); filled by pdh_capi.cpp:build_moment_tables
+  static constexpr int OFF_E = 0, OFF_D = TAB, OFF_FS = 2 * TAB, OFF_GX = 3 * TAB, OFF_GL = OFF_GX + NG /* [NA][NG] */,
+                       OFF_BV = OFF_GL + NA * NG /* [N1D][NG] */, OFF_BD = OFF_BV + N1D * NG, SIZE = OFF_BD + N1D * NG;
+};
+
+// L_a(x) = sqrt(2a+1) P_a(2x-1), a = 0 .. NA-1
+template <int NA>
+__device__ __forceinline__ void legendre01(double x, double *L)
+{
+  const double t = 2.0 * x - 1.0;
+  double pm = 1.0, pc = t;
+  L[0] = 1.0;
+  if constexpr (NA > 1)
+    L[1] = 1.7320508075688772935 * t;
+  static_for<1, NA - 1>([&](auto k_) {
+    constexpr int k = k_;
+    const double pn = ((2 * k + 1) * t * pc - k * pm) * (1.0 / (k + 1));
+    pm = pc;
+    pc = pn;
+    L[k + 1] = __builtin_sqrt((double)(2 * k + 3)) * pn;
+  });
+}
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+// The unrolled contraction loops below are split into basic blocks by branches on a value the compiler cannot see
+// through (a fresh `asm volatile` zero per iteration; identical conditions would be merged again).  Without them the
+// scheduler hoists the LDS row loads of all iterations to the top of one huge block and spills them at once
+// (454 VGPRs wanted); sched_barrier / memory-clobber fences made it worse.
+#define PDHM_BLOCK(...)                                                                                              \
+  do                                                                                                                 \
+    {                                                                                                                \
+      int z_ = 0;                                                                                                    \
+      asm volatile("" : "+s"(z_));                                                                                   \
+      if (z_ == 0)                                                                                                   \
+        {                                                                                                            \
+          __VA_ARGS__;                                                                                                  \
+        }                                                                                                            \
+    }                                                                                                                \
+  while (0)
+
+// acc[a2] += y * r[a2], a2 < NA, r 16-byte aligned with NAP entries (entry NA is zero)
+template <int NA>
+__device__ __forceinline__ void fma_row(double *acc, const double *r, double y)
+{
+  static_for<0, (NA + 1) / 2>([&](auto h_) {
+    constexpr int hh = h_;
+    const d2_t v = *reinterpret_cast<const d2_t *>(r + 2 * hh);
+    acc[2 * hh] += v.x * y;
+    if constexpr (2 * hh + 1 < NA)
+      acc[2 * hh + 1] += v.y * y;
+  });
+}
+
+// sum_a t[a] * r[a]: t in registers (never addressed through a vector pointer: that would pin it to scratch memory),
+// r a 16-byte aligned row in LDS
+template <int NA>
+__device__ __forceinline__ double dot_row(const double *t, const double *r)
+{
+  double s = 0.0;
+  static_for<0, (NA + 1) / 2>([&](auto h_) {
+    constexpr int hh = h_;
+    const d2_t b = *reinterpret_cast<const d2_t *>(r + 2 * hh);
+    s += t[2 * hh] * b.x;
+    if constexpr (2 * hh + 1 < NA)
+      s += t[2 * hh + 1] * b.y;
+  });
+  return s;
+}
+
+// Shared tail of both kernels.  T1 holds NT1 arrays [N1D (l2)][NA (a0)][NAP (a1)] for the current slab k2;
+// stage 2 for one X-type: T2[(l2,l1,k1)][NAP (a0)] = sum over the listed (Y table, T1 array, scale) terms of
+//   scale * sum_a1 Y[k1,l1,a1] T1[arr][l2][a0][a1]
+template <int N1D>
+struct Term
+{
+  const double *ytab; // [PAIRS][NAP] in LDS
+  int arr;            // T1 array
+  double scale;
+};
+
+// SWAP = false: this lane owns the column index l (function of the second side), the loops run over row indices k;
+// SWAP = true: the lane owns k, the loops run over l.  Tables are always indexed [k][l].
+template <int N1D, int NTERM, bool SWAP>
+__device__ __forceinline__ void stage2(const Term<N1D> (&terms)[NTERM], const double *T1, double *T2, int lane)
+{
+  using M = MT<N1D>;
+  constexpr int NA = M::NA, NAP = M::NAP;
+  if (lane < N1D * N1D * N1D)
+    {
+      const int low = lane % N1D, mid = (lane / N1D) % N1D, hi = lane / (N1D * N1D);
+      const int pair = SWAP ? (mid * N1D + low) : (low * N1D + mid); // (k1, l1)
+      double out[NAP];
+      for (int a0 = 0; a0 < NAP; ++a0)
+        out[a0] = 0.0;
+      static_for<0, NTERM>([&](auto t_) {
+        constexpr int t = t_;
+        double y[NAP];
+        static_for<0, NAP / 2>([&](auto h_) {
+          constexpr int hh = h_;
+          const d2_t v = *reinterpret_cast<const d2_t *>(terms[t].ytab + pair * M::RS + 2 * hh);
+          y[2 * hh] = v.x * terms[t].scale;
+          y[2 * hh + 1] = v.y * terms[t].scale;
+        });
+        const double *t1 = T1 + ((terms[t].arr * N1D + hi) * NA) * NAP;
+        // blocks of four rows: 16 row loads in flight, then 28 FMAs
+        static_for<0, (NA + 3) / 4>([&](auto g_) {
+          constexpr int g = g_;
+          PDHM_BLOCK(static_for<4 * g, (4 * g + 4 < NA ? 4 * g + 4 : NA)>([&](auto a0_) {
+            constexpr int a0 = a0_;
+            out[a0] += dot_row<NA>(y, t1 + a0 * NAP);
+          }));
+        });
+      });
+      static_for<0, NAP / 2>([&](auto h_) {
+        constexpr int hh = h_;
+        d2_t v;
+        v.x = out[2 * hh];
+        v.y = out[2 * hh + 1];
+        *reinterpret_cast<d2_t *>(T2 + ((low * N1D + hi) * N1D + mid) * M::RS + 2 * hh) = v;
+      });
+    }
+}
+
+// stage 3 for one X-type; (o0,o1,o2) = multi-index of the function this lane owns, the slab's other-side functions are
+// enumerated as r = s1 * N1D + s0 (all N1D^2 combinations; those that are not in the space - FE_AggloDGP - are computed
+// and dropped by the caller):   out[r] += sum_a0 X[k0, l0, a0] T2[(o2, o1, s1)][a0],  (k0,l0) = SWAP ? (o0,s0) : (s0,o0)
+template <int N1D, bool SWAP>
+__device__ __forceinline__ void stage3(const double *xtab, const double *T2, int o0, int o1, int o2, double *out)
+{
+  using M = MT<N1D>;
+  constexpr int NA = M::NA, NAP = M::NAP;
+  // the N1D rows of T2 this lane needs (one per s1) are read once and stay in registers for all s0: LDS return
+  // bandwidth (128 B/clk per CU), not the FMA count, bounds this kernel
+  double t2[N1D][NAP];
+  PDHM_BLOCK(static_for<0, N1D>([&](auto s1_) {
+    constexpr int s1 = s1_;
+    static_for<0, NAP / 2>([&](auto h_) {
+      constexpr int hh = h_;
+      const d2_t v = *reinterpret_cast<const d2_t *>(T2 + ((s1 * N1D + o2) * N1D + o1) * M::RS + 2 * hh);
+      t2[s1][2 * hh] = v.x;
+      t2[s1][2 * hh + 1] = v.y;
+    });
+  }));
+  static_for<0, N1D>([&](auto s0_) {
+    constexpr int s0 = s0_;
+    PDHM_BLOCK(
+      double xv[NAP]; const int pair = SWAP ? (o0 * N1D + s0) : (s0 * N1D + o0);
+      static_for<0, NAP / 2>([&](auto h_) {
+        constexpr int hh = h_;
+        const d2_t v = *reinterpret_cast<const d2_t *>(xtab + pair * M::RS + 2 * hh);
+        xv[2 * hh] = v.x;
+        xv[2 * hh + 1] = v.y;
+      });
+      static_for<0, N1D>([&](auto s1_) {
+        constexpr int s1 = s1_;
+        double sum = out[s1 * N1D + s0];
+        static_for<0, NA>([&](auto a_) {
+          constexpr int a = a_;
+          sum += xv[a] * t2[s1][a];
+        });
+        out[s1 * N1D + s0] = sum;
+      }));
+  });
+}
+
+// row index of the basis function with multi-index (k0,k1,k2), or -1 if the space does not contain it (FE_AggloDGP);
+// every lane holds the packed multi-index of its own function
+__device__ __forceinline__ int row_of(bool live, int packed_own, int k0, int k1, int k2)
+{
+  const unsigned long long m = __ballot(live && packed_own == (k0 | (k1 << 8) | (k2 << 16)));
+  return m ? (int)__builtin_ctzll(m) : -1;
+}
+
+// one past the last row whose k2 is <= `k2` (rows are ordered with k2 non-decreasing: FE_DGQ lexicographic, x fastest;
+// FE_AggloDGP "for iz: for iy: for ix"); l2 = this lane's own k2, live = lane < n
+__device__ __forceinline__ int slab_end(bool live, int l2, int k2)
+{
+  return (int)__builtin_popcountll(__ballot(live && l2 <= k2));
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Moment accumulation on the f64 MFMA.  M[(a0,a1)][(a2,t)] = sum_q [L_a0 L_a1](q) [s_t L_a2](q) is a GEMM over the
+// points: A rows = the NA^2 pairs (a0,a1) in NFA fragments of 16, B columns = blocks of the four weights t for one
+// a2 (NFB fragments of four blocks).  A first version kept the per-point factors wave-uniform and broadcast them
+// from LDS into VALU FMAs: LDS return bandwidth (128 B/clk per CU, a broadcast still returns 64 lanes) made it 9x
+// slower than this.  Operand layout as in pdh_kernels.h: lane = 16 k + 4 blk + idx (k = point of the 4-point step).
+// ------------------------------------------------------------------------------------------------------------
+template <int N1D>
+struct MomentAcc
+{
+  using M = MT<N1D>;
+  static constexpr int NA = M::NA, NAP = M::NAP, ROWS = NA * NA, NFA = (ROWS + 15) / 16, NFB = (NA + 3) / 4;
+  static constexpr int REC = 2 * NA + 4 * NAP + 4; // L0[NA], L1[NA], (s_t L2)[4][NAP], zero pair, pad (bank spread of the 4 points of a step)
+  static constexpr int ZERO = (2 * NA + 4 * NAP) * 8;
+  static constexpr int CH = 32; // points per chunk
+  int offA0[NFA], offA1[NFA], offBv, offBf[NFB];
+  pdh::Rotator rt;
+  double accv[NFA][2];      // volume: columns a2 (two blocks, B replicated [F0,F1,F0,F1]), rotations 0,1
+  double accf[NFA][NFB][4]; // faces
+  __device__ __forceinline__ void init(int lane)
+  {
+    const int blk = (lane >> 2) & 3, idx = lane & 3;
+    static_for<0, NFA>([&](auto a_) {
+      constexpr int a = a_;
+      const int row = 16 * a + 4 * blk + idx;
+      offA0[a] = row < ROWS ? (row / NA) * 8 : ZERO;
+      offA1[a] = row < ROWS ? (NA + row % NA) * 8 : ZERO;
+      accv[a][0] = accv[a][1] = 0.0;
+      static_for<0, NFB>([&](auto b_) {
+        constexpr int b = b_;
+        for (int r = 0; r < 4; ++r)
+          accf[a][b][r] = 0.0;
+      });
+    });
+    const int a2v = 4 * (blk & 1) + idx;
+    offBv = a2v < NA ? (2 * NA + a2v) * 8 : ZERO;
+    static_for<0, NFB>([&](auto b_) {
+      constexpr int b = b_;
+      const int a2 = 4 * b + blk;
+      offBf[b] = a2 < NA ? (2 * NA + idx * NAP + a2) * 8 : ZERO;
+    });
+    rt.init(lane);
+  }
+  // record of one point: x^ = unit coordinates, s[NS] = weights (NS = 1: volume, 4: faces); dead points: s = 0
+  template <int NS>
+  static __device__ __forceinline__ void write_record(double *r, const double *xu, const double *s)
+  {
+    double L[NA];
+    legendre01<NA>(xu[0], L);
+    for (int a = 0; a < NA; ++a)
+      r[a] = L[a];
+    legendre01<NA>(xu[1], L);
+    for (int a = 0; a < NA; ++a)
+      r[NA + a] = L[a];
+    legendre01<NA>(xu[2], L);
+    for (int t = 0; t < NS; ++t)
+      for (int a = 0; a < NA; ++a)
+        r[2 * NA + t * NAP + a] = s[t] * L[a];
+    r[2 * NA + 4 * NAP] = 0.0;
+    r[2 * NA + 4 * NAP + 1] = 0.0;
+  }
+  static __device__ __forceinline__ double ld(const char *rb, int off) { return *reinterpret_cast<const double *>(rb + off); }
+  __device__ __forceinline__ void volume_chunk(const double *rec, int cnt, int lane)
+  {
+    const int kq = lane >> 4;
+    const int nsteps = (cnt + 3) >> 2;
+    for (int step = 0; step < nsteps; ++step)
+      {
+        const char *rb = reinterpret_cast<const char *>(rec + (4 * step + kq) * REC);
+        double A[NFA];
+        static_for<0, NFA>([&](auto a_) {
+          constexpr int a = a_;
+          A[a] = ld(rb, offA0[a]) * ld(rb, offA1[a]);
+        });
+        const double B0 = ld(rb, offBv);
+        const double B1 = rt.template rot<1>(B0);
+        static_for<0, NFA>([&](auto a_) {
+          constexpr int a = a_;
+          accv[a][0] = pdh::mfma4(A[a], B0, accv[a][0]);
+          accv[a][1] = pdh::mfma4(A[a], B1, accv[a][1]);
+        });
+      }
+  }
+  __device__ __forceinline__ void face_chunk(const double *rec, int cnt, int lane)
+  {
+    const int kq = lane >> 4;
+    const int nsteps = (cnt + 3) >> 2;
+    for (int step = 0; step < nsteps; ++step)
+      {
+        const char *rb = reinterpret_cast<const char *>(rec + (4 * step + kq) * REC);
+        double A[NFA], B[NFB][4];
+        static_for<0, NFA>([&](auto a_) {
+          constexpr int a = a_;
+          A[a] = ld(rb, offA0[a]) * ld(rb, offA1[a]);
+        });
+        static_for<0, NFB>([&](auto b_) {
+          constexpr int b = b_;
+          B[b][0] = ld(rb, offBf[b]);
+          B[b][1] = rt.template rot<1>(B[b][0]);
+          B[b][2] = rt.template rot<2>(B[b][0]);
+          B[b][3] = rt.template rot<3>(B[b][0]);
+        });
+        static_for<0, NFA>([&](auto a_) {
+          constexpr int a = a_;
+          static_for<0, NFB>([&](auto b_) {
+            constexpr int b = b_;
+            static_for<0, 4>([&](auto r_) {
+              constexpr int r = r_;
+              accf[a][b][r] = pdh::mfma4(A[a], B[b][r], accf[a][b][r]);
+            });
+          });
+        });
+      }
+  }
+  // Scatter the accumulators into Mx[tensor][row][NA] (VOL: tensor 0 = volume, 1 + t = face weight t; else t).  D layout:
+  // lane = 16 i + 4 blk + j holds row 16 a + 4 blk + i; faces: a2 = 4 b + ((blk + r) & 3), t = j; volume: a2 =
+  // 4 ((blk + r) & 1) + j.
+  template <bool VOL>
+  __device__ __forceinline__ void scatter(double *Mx, int lane) const
+  {
+    const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+    static_for<0, NFA>([&](auto a_) {
+      constexpr int a = a_;
+      const int row = 16 * a + 4 * blk + i;
+      if (row < ROWS)
+        {
+          if constexpr (VOL)
+            static_for<0, 2>([&](auto r_) {
+              constexpr int r = r_;
+              const int a2 = 4 * ((blk + r) & 1) + j;
+              if (a2 < NA)
+                Mx[row * NA + a2] = accv[a][r];
+            });
+          static_for<0, NFB>([&](auto b_) {
+            constexpr int b = b_;
+            static_for<0, 4>([&](auto r_) {
+              constexpr int r = r_;
+              const int a2 = 4 * b + ((blk + r) & 3);
+              if (a2 < NA)
+                Mx[(((VOL ? 1 : 0) + j) * ROWS + row) * NA + a2] = accf[a][b][r];
+            });
+          });
+        }
+    });
+  }
+};
+
+template <int N1D>
+constexpr int lds_doubles_diag()
+{
+  using M = MT<N1D>;
+  using A = MomentAcc<N1D>;
+  constexpr int tb = 3 * M::LTAB;
+  constexpr int recs = A::CH * A::REC;
+  constexpr int mx = 5 * A::ROWS * M::NA;                                     // gathered moments
+  constexpr int work = 4 * N1D * M::NA * M::NAP + N1D * N1D * N1D * M::RS; // T1 (4 arrays) + T2
+  constexpr int m1 = recs > mx ? recs : mx;
+  return tb + (m1 > work ? m1 : work);
+}
+template <int N1D>
+constexpr int lds_doubles_offdiag()
+{
+  using M = MT<N1D>;
+  using A = MomentAcc<N1D>;
+  constexpr int tb = 6 * M::LTAB;
+  constexpr int recs = A::CH * A::REC;
+  constexpr int mx = 4 * A::ROWS * M::NA;
+  constexpr int work = 3 * N1D * M::NA * M::NAP + N1D * N1D * N1D * M::RS; // T1 (3 arrays) + T2
+  constexpr int stage = 64 * (N1D * N1D + 1);                  // transposed-store staging
+  constexpr int m1 = recs > mx ? recs : mx;
+  constexpr int m2 = work > stage ? work : stage;
+  return tb + (m1 > m2 ? m1 : m2);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Diagonal blocks: one wave per owned polytope.
+// ------------------------------------------------------------------------------------------------------------
+template <int N1D>
+__global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const double *__restrict__ mt, const int n_owned)
+{
+  using M = MT<N1D>;
+  constexpr int NA = M::NA, NAP = M::NAP, DIM = 3;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x;
+  if (slot >= n_owned)
+    return;
+  const int agg = P.own_agg[slot];
+  double lo[DIM], ih[DIM];
+  for (int c = 0; c < DIM; ++c)
+    {
+      lo[c] = P.bbox[(int64_t)agg * 2 * DIM + c];
+      ih[c] = 1.0 / (P.bbox[(int64_t)agg * 2 * DIM + DIM + c] - lo[c]);
+    }
+  double *tabE = lds, *tabD = lds + M::LTAB, *tabF = lds + 2 * M::LTAB;
+  double *work = lds + 3 * M::LTAB;
+  for (int t = lane; t < 3 * M::TAB; t += PDH_WAVE)
+    lds[(t / NAP) * M::RS + t % NAP] = mt[t]; // rows re-strided from NAP to RS
+
+  const bool act = lane < NA * NA;
+  const int a0 = act ? lane / NA : 0, a1 = act ? lane % NA : 0;
+  using Acc = MomentAcc<N1D>;
+  Acc ma;
+  ma.init(lane);
+  // ---- volume moments -----------------------------------------------------------------------------------
+  {
+    const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
+    for (int64_t base = qb; base < qe; base += Acc::CH)
+      {
+        const int cnt = (int)((qe - base < Acc::CH) ? (qe - base) : Acc::CH);
+        __syncthreads();
+        if (lane < Acc::CH)
+          {
+            double xu[DIM] = {0.5, 0.5, 0.5}, w = 0.0;
+            if (lane < cnt)
+              {
+                for (int c = 0; c < DIM; ++c)
+                  xu[c] = (P.vq_x[c * P.vq_stride + base + lane] - lo[c]) * ih[c];
+                w = P.vq_w[base + lane];
+              }
+            Acc::template write_record<1>(work + lane * Acc::REC, xu, &w);
+          }
+        __syncthreads();
+        ma.volume_chunk(work, cnt, lane);
+      }
+  }
+  // ---- moments of the own-side face points (all faces of the polytope, boundary included) ------------------
+  {
+    const int64_t pb = P.ap_ptr[slot], pe = P.ap_ptr[slot + 1];
+    for (int64_t base = pb; base < pe; base += Acc::CH)
+      {
+        const int cnt = (int)((pe - base < Acc::CH) ? (pe - base) : Acc::CH);
+        __syncthreads();
+        if (lane < Acc::CH)
+          {
+            double xu[DIM] = {0.5, 0.5, 0.5}, s[4] = {0.0, 0.0, 0.0, 0.0};
+            if (lane < cnt)
+              {
+                for (int c = 0; c < DIM; ++c)
+                  xu[c] = (P.ap_x[c * P.ap_stride + base + lane] - lo[c]) * ih[c];
+                const double w = P.ap_wself[base + lane];
+                // U_i phi_j + phi_i U_j  with  U = -1/2 grad phi . n + (sig/2) phi   (pdh_kernels.h, k_diag)
+                s[0] = w * P.ap_sig[base + lane];
+                for (int c = 0; c < DIM; ++c)
+                  s[1 + c] = -0.5 * w * P.ap_n[c * P.ap_stride + base + lane];
+              }
+            Acc::template write_record<4>(work + lane * Acc::REC, xu, s);
+          }
+        __syncthreads();
+        ma.face_chunk(work, cnt, lane);
+      }
+  }
+  // gather: this lane's (a0,a1) row of every moment tensor
+  double accM[NAP], accS[NAP], accN[DIM][NAP];
+  __syncthreads();
+  ma.template scatter<true>(work, lane);
+  __syncthreads();
+  for (int a = 0; a < NA; ++a)
+    {
+      const int row = act ? lane : 0;
+      accM[a] = work[(0 * Acc::ROWS + row) * NA + a];
+      accS[a] = work[(1 * Acc::ROWS + row) * NA + a];
+      for (int c = 0; c < DIM; ++c)
+        accN[c][a] = work[((2 + c) * Acc::ROWS + row) * NA + a];
+    }
+  // reaction term  c phi_i phi_j  shares the (E,E,E) contraction with the penalty moments
+  if (P.reaction_c != 0.0)
+    for (int a = 0; a < NA; ++a)
+      accS[a] += P.reaction_c * accM[a];
+
+  // ---- contraction, one slab of rows (fixed k2) at a time ------------------------------------------------
+  double *T1 = work;                          // [4][N1D][NA][NAP]: 0 = E.M, 1 = (D.M/h2^2 + E.S + Fs.N2/h2), 2 = E.N0, 3 = E.N1
+  double *T2 = work + 4 * N1D * NA * NAP;      // [N1D (s1)][N1D^2 (o2,o1)][RS]
+  const int n = P.n;
+  const bool live = lane < n;
+  int l0 = 0, l1 = 0, l2 = 0, packed_own = 0;
+  if (live)
+    {
+      packed_own = P.midx[lane];
+      l0 = packed_own & 0xff;
+      l1 = (packed_own >> 8) & 0xff;
+      l2 = (packed_own >> 16) & 0xff;
+    }
+  const int64_t rbase = P.row_base[slot];
+  const int rlen = P.row_len[slot];
+  const int L = P.diag_L[slot];
+  const double ih0 = ih[0], ih1 = ih[1], ih2 = ih[2];
+  int row_begin = 0;
+#pragma unroll 1
+  for (int k2 = 0; k2 < N1D && row_begin < n; ++k2)
+    {
+      const int row_end = slab_end(live, l2, k2);
+      // The X / Y table entries of this lane do not depend on k2: hoisted out of this loop by the compiler they would
+      // occupy 192 VGPRs for its whole duration (measured: 240 spills).  An opaque zero ties their address to the iteration.
+      int zero = 0;
+      asm volatile("" : "+s"(zero));
+      tabE = lds + zero;
+      tabD = lds + M::LTAB + zero;
+      tabF = lds + 2 * M::LTAB + zero;
+      __syncthreads();
+      // stage 1 (in registers: this lane's (a0,a1), contraction over a2)
+      if (act)
+        for (int ll = 0; ll < N1D; ++ll)
+          {
+            const int pr = (k2 * N1D + ll) * M::RS;
+            double g1 = 0.0, ee = 0.0, n0 = 0.0, n1 = 0.0;
+            static_for<0, NA>([&](auto a_) {
+              constexpr int a = a_;
+              const double e = tabE[pr + a];
+              g1 += e * accM[a];
+              ee += (tabD[pr + a] * (ih2 * ih2)) * accM[a] + e * accS[a] + (tabF[pr + a] * ih2) * accN[2][a];
+              n0 += e * accN[0][a];
+              n1 += e * accN[1][a];
+            });
+            const int o = (ll * NA + a0) * NAP + a1;
+            T1[0 * N1D * NA * NAP + o] = g1;
+            T1[1 * N1D * NA * NAP + o] = ee;
+            T1[2 * N1D * NA * NAP + o] = n0;
+            T1[3 * N1D * NA * NAP + o] = n1;
+            if (a1 == 0)
+              for (int g = 0; g < 4; ++g)
+                T1[g * N1D * NA * NAP + (ll * NA + a0) * NAP + NA] = 0.0;
+          }
+      double out[N1D * N1D];
+      for (int r = 0; r < N1D * N1D; ++r)
+        out[r] = 0.0;
+      // X = D :  D(dir 0) E(dir 1) on E.M / h0^2
+      {
+        __syncthreads();
+        const Term<N1D> terms[1] = {{tabE, 0, ih0 * ih0}};
+        stage2<N1D, 1, false>(terms, T1, T2, lane);
+        __syncthreads();
+        stage3<N1D, false>(tabD, T2, l0, l1, l2, out);
+      }
+      // X = E :  D(dir 1) on E.M / h1^2  +  E(dir 1) on the merged array  +  Fs(dir 1) on E.N1 / h1
+      {
+        __syncthreads();
+        const Term<N1D> terms[3] = {{tabD, 0, ih1 * ih1}, {tabE, 1, 1.0}, {tabF, 3, ih1}};
+        stage2<N1D, 3, false>(terms, T1, T2, lane);
+        __syncthreads();
+        stage3<N1D, false>(tabE, T2, l0, l1, l2, out);
+      }
+      // X = Fs :  E(dir 1) on E.N0 / h0
+      {
+        __syncthreads();
+        const Term<N1D> terms[1] = {{tabE, 2, ih0}};
+        stage2<N1D, 1, false>(terms, T1, T2, lane);
+        __syncthreads();
+        stage3<N1D, false>(tabF, T2, l0, l1, l2, out);
+      }
+      // rows of the slab: one contiguous segment per row at its CSR position (diagonal-first shift as in store_strip)
+      static_for<0, N1D * N1D>([&](auto r_) {
+        constexpr int r = r_;
+        const int R = row_of(live, packed_own, r % N1D, r / N1D, k2);
+        if (R >= 0 && live)
+          {
+            int pos = L + lane;
+            if (P.diag_first)
+              pos = (lane == R) ? 0 : (L + lane + (lane < R ? 1 : 0));
+            P.values[rbase + (int64_t)R * rlen + pos] = out[r];
+          }
+      });
+      row_begin = row_end;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Coupling blocks: one wave per interior face item (P = side whose packed points are used, Q = neighbour).
+//   A[P,Q]_ij = sum_q w [ (1/2 g^P_i - sigma phi^P_i) phi^Q_j - 1/2 phi^P_i g^Q_j ],   g = grad phi . n_P
+// ------------------------------------------------------------------------------------------------------------
+template <int N1D>
+__global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const double *__restrict__ mt, const int n_items)
+{
+  using M = MT<N1D>;
+  constexpr int NA = M::NA, NAP = M::NAP, NG = M::NG, DIM = 3;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x;
+  const int item = blockIdx.x;
+  if (item >= n_items)
+    return;
+  const int slot = P.it_own[item];
+  const int agg = P.own_agg[slot];
+  const int nbr = P.it_nbr[item];
+  double lo[DIM], ih[DIM], loq[DIM], ihq[DIM];
+  for (int c = 0; c < DIM; ++c)
+    {
+      lo[c] = P.bbox[(int64_t)agg * 2 * DIM + c];
+      ih[c] = 1.0 / (P.bbox[(int64_t)agg * 2 * DIM + DIM + c] - lo[c]);
+      loq[c] = P.bbox[(int64_t)nbr * 2 * DIM + c];
+      ihq[c] = 1.0 / (P.bbox[(int64_t)nbr * 2 * DIM + DIM + c] - loq[c]);
+    }
+  // per-face tables, direction c:  EQ_c[k,l,a] = <B_k(t) B_l(alpha t + beta), L_a>,
+  //   HQ_c = <B'_k B_l(.)>/h^P_c - <B_k B'_l(.)>/h^Q_c      (x^Q = alpha x^P + beta, alpha = h^P/h^Q, beta = (lo^P - lo^Q)/h^Q)
+  double *tabEQ = lds;                // [3][PAIRS][RS]
+  double *tabHQ = lds + 3 * M::LTAB;  // [3][PAIRS][RS]
+  double *work = lds + 6 * M::LTAB;
+#if PDHM_EXP == 1
+  if (lane < DIM * N1D * N1D && P.n < 0)
+#else
+  if (lane < DIM * N1D * N1D)
+#endif
+    {
+      const int c = lane / (N1D * N1D), k = (lane / N1D) % N1D, l = lane % N1D;
+      double lo_c = lo[0], ih_c = ih[0], loq_c = loq[0], ihq_c = ihq[0];
+      if (c == 1)
+        {
+          lo_c = lo[1], ih_c = ih[1], loq_c = loq[1], ihq_c = ihq[1];
+        }
+      if (c == 2)
+        {
+          lo_c = lo[2], ih_c = ih[2], loq_c = loq[2], ihq_c = ihq[2];
+        }
+      const double alpha = ihq_c / ih_c, beta = (lo_c - loq_c) * ihq_c;
+      double e[NA], f[NA], g[NA];
+      for (int a = 0; a < NA; ++a)
+        e[a] = f[a] = g[a] = 0.0;
+      constexpr int p = N1D - 1;
+      for (int gq = 0; gq < NG; ++gq)
+        {
+          const double xq = alpha * mt[M::OFF_GX + gq] + beta - 0.5; // centred Q-frame coordinate
+          double val = P.tab.coef[l][p], der = 0.0;
+          for (int m = p - 1; m >= 0; --m)
+            {
+              der = der * xq + val;
+              val = val * xq + P.tab.coef[l][m];
+            }
+          const double bv = mt[M::OFF_BV + k * NG + gq], bd = mt[M::OFF_BD + k * NG + gq];
+          const double vv = bv * val, dv = bd * val, vd = bv * der;
+          for (int a = 0; a < NA; ++a)
+            {
+              const double gl = mt[M::OFF_GL + a * NG + gq];
+              e[a] += vv * gl;
+              f[a] += dv * gl;
+              g[a] += vd * gl;
+            }
+        }
+      double *te = tabEQ + c * M::LTAB + (k * N1D + l) * M::RS, *th = tabHQ + c * M::LTAB + (k * N1D + l) * M::RS;
+      for (int a = 0; a < NA; ++a)
+        {
+          te[a] = e[a];
+          th[a] = f[a] * ih_c - g[a] * ihq_c;
+        }
+      te[NA] = 0.0;
+      th[NA] = 0.0;
+    }
+
+  const bool act = lane < NA * NA;
+  const int a0 = act ? lane / NA : 0, a1 = act ? lane % NA : 0;
+  using Acc = MomentAcc<N1D>;
+  Acc ma;
+  ma.init(lane);
+  {
+    const int64_t pb = P.it_pbeg[item], pe = pb + P.it_pcnt[item];
+#if PDHM_EXP == 2
+    for (int64_t base = pb; base < pe && P.n < 0; base += Acc::CH)
+#else
+    for (int64_t base = pb; base < pe; base += Acc::CH)
+#endif
+      {
+        const int cnt = (int)((pe - base < Acc::CH) ? (pe - base) : Acc::CH);
+        __syncthreads();
+        if (lane < Acc::CH)
+          {
+            double xu[DIM] = {0.5, 0.5, 0.5}, s[4] = {0.0, 0.0, 0.0, 0.0};
+            if (lane < cnt)
+              {
+                for (int c = 0; c < DIM; ++c)
+                  xu[c] = (P.ap_x[c * P.ap_stride + base + lane] - lo[c]) * ih[c];
+                const double w = P.ap_wcross[base + lane];
+                s[0] = -w * P.ap_sig[base + lane];
+                for (int c = 0; c < DIM; ++c)
+                  s[1 + c] = 0.5 * w * P.ap_n[c * P.ap_stride + base + lane];
+              }
+            Acc::template write_record<4>(work + lane * Acc::REC, xu, s);
+          }
+        __syncthreads();
+        ma.face_chunk(work, cnt, lane);
+      }
+  }
+  double accS[NAP], accN[DIM][NAP];
+  __syncthreads();
+  ma.template scatter<false>(work, lane);
+  __syncthreads();
+  for (int a = 0; a < NA; ++a)
+    {
+      const int row = act ? lane : 0;
+      accS[a] = work[(0 * Acc::ROWS + row) * NA + a];
+      for (int c = 0; c < DIM; ++c)
+        accN[c][a] = work[((1 + c) * Acc::ROWS + row) * NA + a];
+    }
+
+  // Contraction in the SWAPPED orientation: this lane owns ROW i of A[P,Q] (a function of P), slabs run over the k2-type
+  // index l2 of Q's functions.  A slab therefore yields complete rows j of the transposed block A[Q,P] - the block that
+  // sits left of the diagonal in Q's rows and is shifted by one double in deal.II's diagonal-first layout - as coalesced
+  // 512 B row stores, while the piece of A[P,Q] itself (right of the diagonal, aligned) goes through an LDS staging tile
+  // and is written as complete 128 B lines.
+  double *T1 = work;                      // [3][N1D (k2)][NA][NAP]: 0 = EQ2.S + HQ2.N2, 1 = EQ2.N0, 2 = EQ2.N1
+  double *T2 = work + 3 * N1D * NA * NAP;  // [N1D (s1)][N1D^2 (o2,o1)][RS]
+  const int n = P.n;
+  const bool live = lane < n;
+  int o0 = 0, o1 = 0, o2 = 0, packed_own = 0;
+  if (live)
+    {
+      packed_own = P.midx[lane];
+      o0 = packed_own & 0xff;
+      o1 = (packed_own >> 8) & 0xff;
+      o2 = (packed_own >> 16) & 0xff;
+    }
+  const int64_t rbase = P.row_base[slot];
+  const int rlen = P.row_len[slot];
+  const int pos0 = P.it_pos[item];
+  const int qslot = P.it_nbr_slot[item];
+  const int64_t qbase = qslot >= 0 ? P.row_base[qslot] : 0;
+  const int qlen = qslot >= 0 ? P.row_len[qslot] : 0;
+  const int post = P.it_pos_t[item];
+  constexpr int SROW = N1D * N1D + 1; // staging row stride (odd: conflict-free)
+  int col_begin = 0;
+#if PDHM_EXP == 3
+  if (P.n < 0)
+#endif
+#pragma unroll 1
+  for (int s2 = 0; s2 < N1D && col_begin < n; ++s2)
+    {
+      const int col_end = slab_end(live, o2, s2);
+      int zero = 0; // see k_mdiag: keeps the loop-invariant table loads inside the loop
+      asm volatile("" : "+s"(zero));
+      tabEQ = lds + zero;
+      tabHQ = lds + 3 * M::LTAB + zero;
+      __syncthreads();
+      if (act)
+        for (int kk = 0; kk < N1D; ++kk)
+          {
+            const int pr = 2 * M::LTAB + (kk * N1D + s2) * M::RS; // direction 2 tables, pair (k2 = kk, l2 = s2)
+            double ee = 0.0, n0 = 0.0, n1 = 0.0;
+            static_for<0, NA>([&](auto a_) {
+              constexpr int a = a_;
+              const double e = tabEQ[pr + a];
+              ee += e * accS[a] + tabHQ[pr + a] * accN[2][a];
+              n0 += e * accN[0][a];
+              n1 += e * accN[1][a];
+            });
+            const int o = (kk * NA + a0) * NAP + a1;
+            T1[0 * N1D * NA * NAP + o] = ee;
+            T1[1 * N1D * NA * NAP + o] = n0;
+            T1[2 * N1D * NA * NAP + o] = n1;
+            if (a1 == 0)
+              for (int g = 0; g < 3; ++g)
+                T1[g * N1D * NA * NAP + (kk * NA + a0) * NAP + NA] = 0.0;
+          }
+      double out[N1D * N1D]; // out[r], r = l1 * N1D + l0: A[P,Q][i = lane][j = (l0, l1, s2)]
+      for (int r = 0; r < N1D * N1D; ++r)
+        out[r] = 0.0;
+      // X = EQ0 :  EQ1 on array 0  +  HQ1 on EQ2.N1
+      {
+        __syncthreads();
+        const Term<N1D> terms[2] = {{tabEQ + M::LTAB, 0, 1.0}, {tabHQ + M::LTAB, 2, 1.0}};
+        stage2<N1D, 2, true>(terms, T1, T2, lane);
+        __syncthreads();
+        stage3<N1D, true>(tabEQ, T2, o0, o1, o2, out);
+      }
+      // X = HQ0 :  EQ1 on EQ2.N0
+      {
+        __syncthreads();
+        const Term<N1D> terms[1] = {{tabEQ + M::LTAB, 1, 1.0}};
+        stage2<N1D, 1, true>(terms, T1, T2, lane);
+        __syncthreads();
+        stage3<N1D, true>(tabHQ, T2, o0, o1, o2, out);
+      }
+      // A[Q,P] = A[P,Q]^T: rows j of the slab, one contiguous segment per row (columns = this wave's lanes)
+      int cols_of[N1D * N1D];
+      static_for<0, N1D * N1D>([&](auto r_) {
+        constexpr int r = r_;
+        cols_of[r] = row_of(live, packed_own, r % N1D, r / N1D, s2);
+        if (qslot >= 0 && cols_of[r] >= 0 && live && PDHM_STORE_OK)
+          P.values[qbase + (int64_t)cols_of[r] * qlen + post + lane] = out[r];
+      });
+      // A[P,Q]: this slab holds columns [col_begin,col_end) of every row i.  Through an LDS staging tile so that one
+      // store instruction writes 16-column (128 B) pieces of four rows.
+      {
+        __syncthreads();
+        double *stage = work;
+        if (live)
+          static_for<0, N1D * N1D>([&](auto r_) {
+            constexpr int r = r_;
+            if (cols_of[r] >= 0)
+              stage[lane * SROW + cols_of[r] - col_begin] = out[r];
+          });
+        __syncthreads();
+        const int cols = col_end - col_begin;
+        constexpr int W = N1D * N1D; // lanes per row piece (<= 16)
+        const int cc = lane % W;
+        for (int ib = 0; ib < n; ib += PDH_WAVE / W)
+          {
+            const int i = ib + lane / W;
+            if (i < n && cc < cols && lane < (PDH_WAVE / W) * W && PDHM_STORE_OK)
+              P.values[rbase + (int64_t)i * rlen + pos0 + col_begin + cc] = stage[i * SROW + cc];
+          }
+      }
+      col_begin = col_end;
+    }
+}
+} // namespace pdhm

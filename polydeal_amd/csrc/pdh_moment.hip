@@ -1,0 +1,35 @@
+// pdh_moment.hip — instantiations and launcher of the moment-form kernels (pdh_moment.h): 3-D, degree <= 3.
+#include "pdh_moment.h"
+
+// which: 0 = diagonal blocks (count = owned polytopes), 1 = coupling blocks (count = interior-face items)
+extern "C" hipError_t pdh_launch_moment(int n1d, int which, const PdhDev *P, const double *mtab, int count, hipStream_t stream)
+{
+  if (count <= 0)
+    return hipSuccess;
+  const dim3 grid((unsigned)count), block(PDH_WAVE);
+#define PDH_MOM_CASE(N)                                                                                              \
+  if (n1d == N)                                                                                                      \
+    {                                                                                                                \
+      if (which == 0)                                                                                                \
+        hipLaunchKernelGGL((pdhm::k_mdiag<N>), grid, block, pdhm::lds_doubles_diag<N>() * sizeof(double), stream, *P, \
+                           mtab, count);                                                                             \
+      else                                                                                                           \
+        hipLaunchKernelGGL((pdhm::k_moffdiag<N>), grid, block, pdhm::lds_doubles_offdiag<N>() * sizeof(double),       \
+                           stream, *P, mtab, count);                                                                 \
+      return hipGetLastError();                                                                                      \
+    }
+  PDH_MOM_CASE(2) PDH_MOM_CASE(3) PDH_MOM_CASE(4)
+#undef PDH_MOM_CASE
+  return hipErrorInvalidValue;
+}
+
+extern "C" int pdh_moment_table_doubles(int n1d)
+{
+  switch (n1d)
+    {
+    case 2: return pdhm::MT<2>::SIZE;
+    case 3: return pdhm::MT<3>::SIZE;
+    case 4: return pdhm::MT<4>::SIZE;
+    }
+  return 0;
+}

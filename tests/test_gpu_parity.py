@@ -550,3 +550,96 @@ def test_exact_solution_reproduced_all_on_gpu(fe_cls, p):
     ctx.close()
     assert l2 < 1e-12
     assert np.max(np.abs(A - A.T)) < 1e-11 * np.max(np.abs(A))
+
+
+def _values(kw, alg, r0=0, r1=None):
+    import polydeal_amd as pa
+
+    prob = pa.Problem(**kw)
+    ctx = pa.Context(0)
+    ctx.set_algorithm(alg)
+    ctx.set_problem(prob, r0, r1)
+    used = ctx.algorithm_in_use()
+    v = ctx.assemble()
+    ctx.close()
+    return v, used
+
+
+MOMENT_CASES = [
+    # fe, degree, log2 cells/dir, block, distort, variant, diag_first
+    (po.FE_DGQ, 3, 2, 2, 0.0, "poisson", True),
+    (po.FE_DGQ, 3, 2, 2, 0.2, "dr", True),
+    (po.FE_DGQ, 3, 2, 2, 0.1, "adm", False),
+    (po.FE_DGQ, 3, 1, 2, 0.0, "poisson", True),   # one polytope: no coupling items
+    (po.FE_DGQ, 3, 1, 1, 0.1, "test", True),      # every cell its own polytope
+    (po.FE_DGQ, 2, 2, 2, 0.15, "dr", True),
+    (po.FE_DGQ, 1, 2, 2, 0.1, "minsip", True),
+    (po.FE_AggloDGP, 3, 2, 2, 0.1, "poisson", True),
+    (po.FE_AggloDGP, 2, 2, 1, 0.0, "adm", False),
+    (po.FE_AggloDGP, 1, 2, 2, 0.2, "poisson", True),
+]
+
+
+@pytest.mark.parametrize("fe_cls,p,lg,b,dist,varname,diag_first", MOMENT_CASES,
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_moment_form_parity(fe_cls, p, lg, b, dist, varname, diag_first):
+    """The moment form (csrc/pdh_moment.h: Legendre moments of the quadrature + sum factorisation) against the oracle,
+    1e-12 relative, next to the direct form on the same inputs - the two differ by rounding only."""
+    fe = fe_cls(3, p)
+    ah = build(3, lg, b, fe, p + 1, distort=dist)
+    var = variant(varname, fe)
+    kw = flatten(ah, var, diag_first=diag_first)
+    ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
+    vm, used = _values(kw, "moment")
+    vd, used_d = _values(kw, "direct")
+    assert used == "moment" and used_d == "direct"
+    sc = np.max(np.abs(ref))
+    assert np.max(np.abs(vm - ref)) <= TOL * sc
+    assert np.max(np.abs(vd - ref)) <= TOL * sc
+    assert np.max(np.abs(vm - vd)) <= 1e-13 * sc
+
+
+@pytest.mark.parametrize("seed,disc", [(0, False), (1, True)])
+def test_moment_form_irregular_agglomerates_and_row_ranges(seed, disc):
+    """Moment form on random irregular (also disconnected) agglomerates with ragged point counts, and on row ranges:
+    a face cut by the partition is contracted from the side that is owned (coupling item with P = side 1)."""
+    from polydeal_amd.partition import row_range
+
+    rng = np.random.default_rng(seed)
+    fe = po.FE_DGQ(3, 3)
+    grid = po.hyper_cube_refined(3, 0.0, 1.0, 2)
+    grid.distort(0.15, seed=seed)
+    ah = po.AgglomerationHandler(grid)
+    for g in random_agglomeration(grid, 9, rng, allow_disconnected=disc):
+        ah.define_agglomerate(g)
+    ah.initialize_fe_values(4, 4)
+    ah.distribute_agglomerated_dofs(fe)
+    var = po.variant_poisson_example(fe)
+    kw = flatten(ah, var)
+    ref = po.assemble_csr(ah, var)[2]
+    sc = np.max(np.abs(ref))
+    vm, _ = _values(kw, "moment")
+    assert np.max(np.abs(vm - ref)) <= TOL * sc
+    n = fe.n_dofs_per_cell
+    parts = []
+    for r in range(3):
+        rb, re = row_range(ah.n_agglomerates, n, r, 3)
+        parts.append(_values(kw, "moment", rb, re)[0])
+    assert np.max(np.abs(np.concatenate(parts) - ref)) <= TOL * sc
+
+
+def test_moment_form_unavailable_is_reported():
+    """2-D problems have no moment form: forcing it must fail loudly, AUTO must fall back to the direct kernels."""
+    import polydeal_amd as pa
+
+    fe = po.FE_DGQ(2, 2)
+    ah = build(2, 3, 2, fe, 3)
+    kw = flatten(ah, po.variant_poisson_example(fe))
+    prob = pa.Problem(**kw)
+    ctx = pa.Context(0)
+    ctx.set_problem(prob)
+    assert ctx.algorithm_in_use() == "direct"
+    ctx.set_algorithm("moment")
+    with pytest.raises(pa.PdhError):
+        ctx.assemble()
+    ctx.close()
