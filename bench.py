@@ -71,7 +71,7 @@ def build_handler(pa, dim, cells, block, basis, degree, nq):
     return grid, ah, fe
 
 
-def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup):
+def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto"):
     t0 = time.time()
     grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1)
     var = make_variant(pa, args.variant, fe)
@@ -82,7 +82,9 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     from polydeal_amd.partition import row_range
     r0, r1 = row_range(n_agg, n, rank, world)
     ctx = pa.Context(local_rank)
+    ctx.set_algorithm(alg)
     ctx.set_problem(flat, r0, r1)
+    alg_used = ctx.algorithm_in_use()
     t_setup = time.time() - t0
     for _ in range(warmup):
         ctx.assemble_device()
@@ -118,7 +120,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     chk = float(np.sum(vals)) if vals is not None else None
     ctx.close()
     return dict(n_dofs=ah.n_dofs, n_agg=n_agg, n=n, dt=dt, kms=kms, nl=nl, stats=stats, work=work, mfma=mfma,
-                t_setup=t_setup, nnz=flat.nnz, checksum=chk)
+                t_setup=t_setup, nnz=flat.nnz, checksum=chk, alg=alg_used)
 
 
 def effective_cpus():
@@ -226,7 +228,11 @@ def main():
         extra = {"fe": ("FE_AggloDGP" if other == "dgp" else "FE_DGQ") + "(%d)" % args.degree,
                  "dofs_per_polytope": r2["n"], "n_dofs": r2["n_dofs"],
                  "value": r2["n_dofs"] / (r2["dt"] / args.steps), "ms_per_step": 1e3 * r2["dt"] / args.steps,
-                 "kernel_ms": {"k_diag": r2["kms"][0], "k_offdiag": r2["kms"][1]}}
+                 "algorithm": r2["alg"], "kernel_ms": {"diagonal_blocks": r2["kms"][0], "coupling_blocks": r2["kms"][1]}}
+    direct = None
+    if main_res["alg"] == "moment" and not args.no_extra:
+        # the same workload through the direct (MFMA contraction) form, for the record
+        direct = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, max(3, args.steps // 3), 1, alg="direct")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -251,18 +257,70 @@ def main():
         ms_step = 1e3 * r["dt"] / args.steps
         value = r["n_dofs"] / (r["dt"] / args.steps)
         w = r["work"]
-        # dominant kernel: k_diag (volume + own-side face terms).  At N>1 rank 0 holds 1/N of the launch.
         frac_rows = r["stats"]["n_owned_agg"] / r["n_agg"]
-        kd = r["kms"][0] * 1e-3
-        ach_tf = w["flops"][0] * frac_rows / kd * 1e-12
-        traffic = None
+        moment = r["alg"] == "moment"
+        names = ("k_mdiag", "k_moffdiag") if moment else ("k_diag", "k_offdiag")
+        t_k = [r["kms"][0] * 1e-3, r["kms"][1] * 1e-3]
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         wl = "%dD cells=%d block=%d %s p=%d" % (args.dim, args.cells, args.block, args.fe, args.degree)
+        tj = {}
         if os.path.exists(tpath) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get(wl, {}).get("k_diag_bytes")
+                tj = json.load(open(tpath)).get(wl, {})
             except Exception:
-                traffic = None
+                tj = {}
+
+        def kernel_entry(i):
+            return {"kernel": names[i], "kernel_ms": t_k[i] * 1e3,
+                    "algorithmic_flops_per_launch": w["flops"][i] * frac_rows,
+                    "algorithmic_bytes_per_launch": w["bytes"][i] * frac_rows,
+                    "algorithmic_TFLOPs": w["flops"][i] * frac_rows / t_k[i] * 1e-12,
+                    "hbm_achieved_GBs": w["bytes"][i] * frac_rows / t_k[i] * 1e-9,
+                    "traffic": tj.get(names[i] + "_bytes")}
+
+        ke = [kernel_entry(0), kernel_entry(1)]
+        if moment:
+            # The moment form removes ~85 % of the arithmetic of SURVEY 8(d)'s count, so the f64-MFMA roof no longer binds:
+            # the roof that remains is the HBM traffic of the values (written once) + quadrature data (read once).
+            dom = 0 if t_k[0] >= t_k[1] else 1
+            roof = {"bound": "hbm", "kernel": names[dom], "achieved": ke[dom]["hbm_achieved_GBs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ke[dom]["hbm_achieved_GBs"] / HBM_PEAK_GBS, "traffic": ke[dom]["traffic"],
+                    "kernel_ms": ke[dom]["kernel_ms"], "launches_timed": r["nl"],
+                    "algorithmic_bytes_per_launch": ke[dom]["algorithmic_bytes_per_launch"],
+                    "algorithmic_flops_per_launch": ke[dom]["algorithmic_flops_per_launch"],
+                    "algorithm": "moment form (pdh_moment.h): Legendre moments of the quadrature on the f64 MFMA + sum "
+                                 "factorisation; VALU / LDS bound, not at the HBM roof yet",
+                    "other_kernel": ke[1 - dom],
+                    "whole_step_GBs": (w["bytes"][0] + w["bytes"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-9,
+                    "whole_step_algorithmic_TFLOPs": (w["flops"][0] + w["flops"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-12}
+            if direct is not None:
+                d = direct
+                dk = [d["kms"][0] * 1e-3, d["kms"][1] * 1e-3]
+                roof["direct_form"] = {
+                    "note": "same workload, pdh_set_algorithm(PDH_ALG_DIRECT): contraction over the points on the f64 MFMA "
+                            "(k_diag / k_offdiag); algorithmic flops count both triangles and all four interface blocks, the "
+                            "kernels execute 0.48x of them (symmetry, M21 = M12^T)",
+                    "ms_per_step": 1e3 * d["dt"] / max(3, args.steps // 3), "k_diag_ms": dk[0] * 1e3, "k_offdiag_ms": dk[1] * 1e3,
+                    "k_diag_algorithmic_TFLOPs": w["flops"][0] * frac_rows / dk[0] * 1e-12,
+                    "k_diag_executed_mfma_TFLOPs": 512.0 * d["mfma"][0] / dk[0] * 1e-12,
+                    "k_diag_executed_frac_of_peak": 512.0 * d["mfma"][0] / dk[0] * 1e-12 / FP64_PEAK_TFLOPS,
+                    "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS}
+        else:
+            ach_tf = ke[0]["algorithmic_TFLOPs"]
+            roof = {"bound": "mfma", "kernel": names[0], "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": ke[0]["traffic"], "kernel_ms": ke[0]["kernel_ms"],
+                    "launches_timed": r["nl"], "algorithmic_flops_per_launch": ke[0]["algorithmic_flops_per_launch"],
+                    "algorithmic_bytes_per_launch": ke[0]["algorithmic_bytes_per_launch"],
+                    "hbm_achieved_GBs": ke[0]["hbm_achieved_GBs"], "hbm_peak_GBs": HBM_PEAK_GBS, "k_offdiag": ke[1],
+                    "whole_step_TFLOPs": (w["flops"][0] + w["flops"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-12,
+                    "executed": {
+                        "note": "algorithmic flops (SURVEY 8(d)) count both triangles of the symmetric diagonal blocks and "
+                                "all four interface blocks; the kernels compute upper tile pairs only and write "
+                                "A[Q,P] = A[P,Q]^T, so `frac` can exceed 1; these are the MFMA flops actually issued "
+                                "(v_mfma_f64_4x4x4_4b_f64, 512 flop; measured instruction ceiling 73 TFLOP/s)",
+                        "k_diag_flops_per_launch": 512.0 * r["mfma"][0], "k_diag_TFLOPs": 512.0 * r["mfma"][0] / t_k[0] * 1e-12,
+                        "k_diag_frac_of_peak": 512.0 * r["mfma"][0] / t_k[0] * 1e-12 / FP64_PEAK_TFLOPS,
+                        "k_offdiag_TFLOPs": 512.0 * r["mfma"][1] / t_k[1] * 1e-12}}
         out = {
             "metric": "assembled DoF/s (SIP Poisson, p=%d, %dD)" % (args.degree, args.dim),
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -275,25 +333,9 @@ def main():
                                       args.degree + 1, {"poisson": "examples/poisson.cc", "diffusion_reaction": "examples/diffusion_reaction.cc",
                                                         "assemble_dg_matrix": "PolyUtils::assemble_dg_matrix"}[args.variant],
                                       r["n_dofs"], r["nnz"]),
+                       "algorithm": r["alg"],
                        "parallelism": "rows(polytopes) split in %d contiguous ranges, owner-computes-rows, no collective" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_diag", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kd * 1e3, "launches_timed": r["nl"],
-                         "algorithmic_flops_per_launch": w["flops"][0] * frac_rows,
-                         "algorithmic_bytes_per_launch": w["bytes"][0] * frac_rows,
-                         "hbm_achieved_GBs": w["bytes"][0] * frac_rows / kd * 1e-9, "hbm_peak_GBs": HBM_PEAK_GBS,
-                         "k_offdiag": {"kernel_ms": r["kms"][1],
-                                       "achieved": w["flops"][1] * frac_rows / (r["kms"][1] * 1e-3) * 1e-12,
-                                       "hbm_achieved_GBs": w["bytes"][1] * frac_rows / (r["kms"][1] * 1e-3) * 1e-9},
-                         "whole_step_TFLOPs": (w["flops"][0] + w["flops"][1]) / (r["dt"] / args.steps) * 1e-12,
-                         "executed": {
-                             "note": "algorithmic flops (SURVEY 8(d)) count both triangles of the symmetric diagonal blocks and "
-                                     "all four interface blocks; the kernels compute upper tile pairs only and write "
-                                     "A[Q,P] = A[P,Q]^T, so `frac` can exceed 1; these are the MFMA flops actually issued "
-                                     "(v_mfma_f64_4x4x4_4b_f64, 512 flop; measured instruction ceiling 73 TFLOP/s)",
-                             "k_diag_flops_per_launch": 512.0 * r["mfma"][0], "k_diag_TFLOPs": 512.0 * r["mfma"][0] / kd * 1e-12,
-                             "k_diag_frac_of_peak": 512.0 * r["mfma"][0] / kd * 1e-12 / FP64_PEAK_TFLOPS,
-                             "k_offdiag_TFLOPs": 512.0 * r["mfma"][1] / (r["kms"][1] * 1e-3) * 1e-12}},
+            "roofline": roof,
             "cpu_baseline": cpu,
             "extra": extra,
             "setup_s": r["t_setup"], "checksum": r["checksum"],

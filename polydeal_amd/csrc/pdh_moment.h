@@ -185,7 +185,16 @@ __device__ __forceinline__ void stage3(const double *xtab, const double *T2, int
   constexpr int NA = M::NA, NAP = M::NAP;
   // the N1D rows of T2 this lane needs (one per s1) are read once and stay in registers for all s0: LDS return
   // bandwidth (128 B/clk per CU), not the FMA count, bounds this kernel
-  double t2[N1D][NAP];
+  double t2[N1D][NAP], xv[2][NAP];
+  auto load_x = [&](int s0, double *dst) {
+    const int pair = SWAP ? (o0 * N1D + s0) : (s0 * N1D + o0);
+    static_for<0, NAP / 2>([&](auto h_) {
+      constexpr int hh = h_;
+      const d2_t v = *reinterpret_cast<const d2_t *>(xtab + pair * M::RS + 2 * hh);
+      dst[2 * hh] = v.x;
+      dst[2 * hh + 1] = v.y;
+    });
+  };
   PDHM_BLOCK(static_for<0, N1D>([&](auto s1_) {
     constexpr int s1 = s1_;
     static_for<0, NAP / 2>([&](auto h_) {
@@ -194,23 +203,19 @@ __device__ __forceinline__ void stage3(const double *xtab, const double *T2, int
       t2[s1][2 * hh] = v.x;
       t2[s1][2 * hh + 1] = v.y;
     });
-  }));
+  });
+             load_x(0, xv[0]));
   static_for<0, N1D>([&](auto s0_) {
     constexpr int s0 = s0_;
+    // the X row of the next s0 is requested before this one is consumed (LDS latency behind the FMAs)
     PDHM_BLOCK(
-      double xv[NAP]; const int pair = SWAP ? (o0 * N1D + s0) : (s0 * N1D + o0);
-      static_for<0, NAP / 2>([&](auto h_) {
-        constexpr int hh = h_;
-        const d2_t v = *reinterpret_cast<const d2_t *>(xtab + pair * M::RS + 2 * hh);
-        xv[2 * hh] = v.x;
-        xv[2 * hh + 1] = v.y;
-      });
+      if constexpr (s0 + 1 < N1D) load_x(s0 + 1, xv[(s0 + 1) & 1]);
       static_for<0, N1D>([&](auto s1_) {
         constexpr int s1 = s1_;
         double sum = out[s1 * N1D + s0];
         static_for<0, NA>([&](auto a_) {
           constexpr int a = a_;
-          sum += xv[a] * t2[s1][a];
+          sum += xv[s0 & 1][a] * t2[s1][a];
         });
         out[s1 * N1D + s0] = sum;
       }));

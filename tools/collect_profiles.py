@@ -33,15 +33,20 @@ def tr(k):
 
 tpath = "profiles/traffic.json"
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-t["3D cells=64 block=2 dgq p=3"] = {
-    "k_diag_bytes": tr("k_diag"), "k_offdiag_bytes": tr("k_offdiag"), "round": tag,
-    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/%s_pmc_summary.json); bytes = "
-            "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of coalesced streaming reads "
-            "(MI355X_MICROARCH.md, HBM); checked here: 2*FETCH matches the algorithmic read bytes within a few %%" % tag}
+wl = "3D cells=64 block=2 dgq p=3"
+entry = t.get(wl, {})
+for kname in sorted({k for (k, c) in out}):
+    if (kname, "FETCH_SIZE") in out and (kname, "WRITE_SIZE") in out and kname.startswith("k_"):
+        entry[kname + "_bytes"] = tr(kname)
+entry["round"] = tag
+entry["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/%s_pmc_summary.json); bytes = "
+                 "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of coalesced streaming reads "
+                 "(MI355X_MICROARCH.md, HBM); checked: 2*FETCH matches the algorithmic read bytes of k_diag within a few %%" % tag)
+t[wl] = entry
 json.dump(t, open(tpath, "w"), indent=1)
 print(open("profiles/%s_kernel_stats.csv" % tag).read())
-print("bench under rocprof: value %.4g ms/step %.3f k_diag %.3f ms k_offdiag %.3f ms" % (
-    bench["value"], bench["ms_per_step"], bench["roofline"]["kernel_ms"], bench["roofline"]["k_offdiag"]["kernel_ms"]))
+print("bench under rocprof: value %.4g ms/step %.3f dominant kernel %s %.3f ms" % (
+    bench["value"], bench["ms_per_step"], bench["roofline"]["kernel"], bench["roofline"]["kernel_ms"]))
 print("cpu:", bench["cpu_baseline"])
-print("traffic:", t["3D cells=64 block=2 dgq p=3"]["k_diag_bytes"], t["3D cells=64 block=2 dgq p=3"]["k_offdiag_bytes"])
-print("alg bytes k_diag:", bench["roofline"]["algorithmic_bytes_per_launch"])
+print("traffic:", {k: v for k, v in entry.items() if k.endswith("_bytes")})
+print("alg bytes dominant kernel:", bench["roofline"]["algorithmic_bytes_per_launch"])
