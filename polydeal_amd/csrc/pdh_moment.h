@@ -385,6 +385,110 @@ struct MomentAcc
   }
 };
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Contraction stages 2 and 3 on the f64 MFMA - FE_DGQ(3): N1D = 4, n = 64, function index = k0 + 4 k1 + 16 k2.
+// Both stages are small GEMMs with K = 8 (seven Legendre modes + a zero pad):
+//   stage 2   C2[(s1,o1)][(o2,a0)]    = sum_terms scale * sum_a1 Y[pair(s1,o1)][a1] T1[arr][o2][a0][a1]
+//   stage 3   OUT[(s0,o0)][(s1,o1,o2)] = sum_X sum_a0 X[pair(s0,o0)][a0] T2_X[a0][(s1,o1,o2)]
+// (s = index of the side the slab loop runs over - the rows -, o = index on the side of the columns).  A operands are the
+// expansion tables; they do not depend on the slab and stay in registers, one copy per s with all four lane blocks
+// holding the same table block (so that a result register is a complete row; no block rotations needed).  B operands are
+// written to LDS by the producing stage in exactly the lane order the consumer reads (T1B, T2B: one conflict-free
+// 512-byte read per fragment).  In the VALU form of these stages (kept below for the other elements) the LDS return
+// bandwidth of the row reads and the FMA issue bounded the kernels; here a slab costs 112-176 MFMA.
+// Result layout (D of stage 3, register [cf][s0], lane = 16 i + 4 blk + j):  row S = s0 + 4 cf + 16 s2, column
+// O = i + 4 j + 16 blk  - a register is one complete row of the block, a store instruction writes its 512 bytes.
+// ------------------------------------------------------------------------------------------------------------
+struct ASet
+{
+  double a[4][2]; // [s][k-step]
+};
+
+// tab: [16 pairs][stride] in LDS, pair = 4 k + l;  SWAP = false: rows s are k, columns o are l
+template <bool SWAP>
+__device__ __forceinline__ void load_aset(const double *tab, int stride, int lane, ASet &A)
+{
+  const int kq = lane >> 4, idx = lane & 3;
+  static_for<0, 4>([&](auto r_) {
+    constexpr int r = r_;
+    constexpr int sidx = r;
+    const int pair = SWAP ? (idx * 4 + sidx) : (sidx * 4 + idx);
+    A.a[r][0] = tab[pair * stride + kq];
+    A.a[r][1] = tab[pair * stride + kq + 4]; // entry 7 is the zero pad
+  });
+}
+
+// position of T1[arr][hi][a0][a1] in the B-operand order of stage 2
+__device__ __forceinline__ int t1b_index(int arr, int hi, int a0, int a1)
+{
+  return ((arr * 2 + (hi >> 1)) * 2 + (a1 >> 2)) * 64 + (a1 & 3) * 16 + (2 * (hi & 1) + (a0 >> 2)) * 4 + (a0 & 3);
+}
+
+// write one stage-1 value and the zero pads that belong to this lane's (a0,a1) (a0 = 6 / a1 = 6 own the pad row / column)
+__device__ __forceinline__ void t1b_store(double *T1B, int arr, int hi, int a0, int a1, double v)
+{
+  T1B[t1b_index(arr, hi, a0, a1)] = v;
+  if (a1 == 6)
+    T1B[t1b_index(arr, hi, a0, 7)] = 0.0;
+  if (a0 == 6)
+    T1B[t1b_index(arr, hi, 7, a1)] = 0.0;
+  if (a0 == 6 && a1 == 6)
+    T1B[t1b_index(arr, hi, 7, 7)] = 0.0;
+}
+
+// one term of stage 2: D2[bf][r] += (scale * A) . T1B[arr]      (ASets are passed by reference and indexed statically
+// only: a pointer to one would move it to scratch memory)
+__device__ __forceinline__ void mstage2_term(const ASet &A, int arr, double scale, const double *T1B, int lane, double (&D2)[2][4])
+{
+  static_for<0, 2>([&](auto ks_) {
+    constexpr int ks = ks_;
+    double ar[4];
+    static_for<0, 4>([&](auto r_) {
+      constexpr int r = r_;
+      ar[r] = A.a[r][ks] * scale;
+    });
+    static_for<0, 2>([&](auto bf_) {
+      constexpr int bf = bf_;
+      const double b = T1B[((arr * 2 + bf) * 2 + ks) * 64 + lane];
+      static_for<0, 4>([&](auto r_) {
+        constexpr int r = r_;
+        D2[bf][r] = pdh::mfma4(ar[r], b, D2[bf][r]);
+      });
+    });
+  });
+}
+
+// scatter the stage-2 result into T2B (B-operand order of stage 3):
+// D2[bf][s1] lane (i, blk, j) = T2[a0 = 4 (blk & 1) + j][(s1, o1 = i, o2 = 2 bf + (blk >> 1))]
+__device__ __forceinline__ void mstage2_scatter(const double (&D2)[2][4], double *T2B, int lane)
+{
+  const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+  static_for<0, 2>([&](auto bf_) {
+    constexpr int bf = bf_;
+    static_for<0, 4>([&](auto r_) {
+      constexpr int r = r_;
+      T2B[((blk & 1) * 4 + r) * 64 + j * 16 + (2 * bf + (blk >> 1)) * 4 + i] = D2[bf][r];
+    });
+  });
+}
+
+// stage 3 for one X-type: D3[cf][s0] += X . T2B
+__device__ __forceinline__ void mstage3(const ASet &X, const double *T2B, int lane, double (&D3)[4][4])
+{
+  static_for<0, 2>([&](auto ks_) {
+    constexpr int ks = ks_;
+    static_for<0, 4>([&](auto cf_) {
+      constexpr int cf = cf_;
+      const double b = T2B[(ks * 4 + cf) * 64 + lane];
+      static_for<0, 4>([&](auto r_) {
+        constexpr int r = r_;
+        D3[cf][r] = pdh::mfma4(X.a[r][ks], b, D3[cf][r]);
+      });
+    });
+  });
+}
+
 template <int N1D>
 constexpr int lds_doubles_diag()
 {
@@ -415,7 +519,7 @@ constexpr int lds_doubles_offdiag()
 // ------------------------------------------------------------------------------------------------------------
 // Diagonal blocks: one wave per owned polytope.
 // ------------------------------------------------------------------------------------------------------------
-template <int N1D>
+template <int N1D, bool MFMA>
 __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const double *__restrict__ mt, const int n_owned)
 {
   using M = MT<N1D>;
@@ -508,6 +612,93 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
     for (int a = 0; a < NA; ++a)
       accS[a] += P.reaction_c * accM[a];
 
+  // ---- FE_DGQ(3): contraction stages 2 and 3 on the MFMA (MFMA = true is launched for n = 64 only) ------------------
+  if constexpr (MFMA)
+      {
+        static_assert(N1D == 4, "the MFMA contraction is written for FE_DGQ(3)");
+        double *T1B = work;               // [4 arrays][2 bf][2 ks][64]
+        double *T2B = work + 4 * 2 * 2 * 64; // [2 ks][4 cf][64]
+        const int64_t rbase = P.row_base[slot];
+        const int rlen = P.row_len[slot];
+        const int L = P.diag_L[slot];
+        const double ih0 = ih[0], ih1 = ih[1], ih2 = ih[2];
+        const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
+        const int O = di + 4 * dj + 16 * dblk; // this lane's column
+#pragma unroll 1
+        for (int k2 = 0; k2 < 4; ++k2)
+          {
+            __syncthreads();
+            if (act)
+              for (int ll = 0; ll < 4; ++ll)
+                {
+                  const int pr = (k2 * 4 + ll) * M::RS;
+                  double g1 = 0.0, ee = 0.0, n0 = 0.0, n1 = 0.0;
+                  static_for<0, NA>([&](auto a_) {
+                    constexpr int a = a_;
+                    const double e = tabE[pr + a];
+                    g1 += e * accM[a];
+                    ee += (tabD[pr + a] * (ih2 * ih2)) * accM[a] + e * accS[a] + (tabF[pr + a] * ih2) * accN[2][a];
+                    n0 += e * accN[0][a];
+                    n1 += e * accN[1][a];
+                  });
+                  t1b_store(T1B, 0, ll, a0, a1, g1);
+                  t1b_store(T1B, 1, ll, a0, a1, ee);
+                  t1b_store(T1B, 2, ll, a0, a1, n0);
+                  t1b_store(T1B, 3, ll, a0, a1, n1);
+                }
+            // the A operands (24 doubles) are re-read per slab instead of living through stage 1 (register pressure);
+            // the opaque zero keeps the compiler from hoisting the loads out of the loop again
+            int zero = 0;
+            asm volatile("" : "+s"(zero));
+            ASet AE, AD, AF;
+            load_aset<false>(tabE + zero, M::RS, lane, AE);
+            load_aset<false>(tabD + zero, M::RS, lane, AD);
+            load_aset<false>(tabF + zero, M::RS, lane, AF);
+            double D3[4][4];
+            for (int c = 0; c < 4; ++c)
+              for (int r = 0; r < 4; ++r)
+                D3[c][r] = 0.0;
+            {
+              __syncthreads();
+              double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = D
+              mstage2_term(AE, 0, ih0 * ih0, T1B, lane, D2);
+              mstage2_scatter(D2, T2B, lane);
+              __syncthreads();
+              mstage3(AD, T2B, lane, D3);
+            }
+            {
+              __syncthreads();
+              double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = E
+              mstage2_term(AD, 0, ih1 * ih1, T1B, lane, D2);
+              mstage2_term(AE, 1, 1.0, T1B, lane, D2);
+              mstage2_term(AF, 3, ih1, T1B, lane, D2);
+              mstage2_scatter(D2, T2B, lane);
+              __syncthreads();
+              mstage3(AE, T2B, lane, D3);
+            }
+            {
+              __syncthreads();
+              double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = Fs
+              mstage2_term(AE, 2, ih0, T1B, lane, D2);
+              mstage2_scatter(D2, T2B, lane);
+              __syncthreads();
+              mstage3(AF, T2B, lane, D3);
+            }
+            static_for<0, 4>([&](auto cf_) {
+              constexpr int cf = cf_;
+              static_for<0, 4>([&](auto s0_) {
+                constexpr int s0 = s0_;
+                const int R = s0 + 4 * cf + 16 * k2;
+                int pos = L + O;
+                if (P.diag_first)
+                  pos = (O == R) ? 0 : (L + O + (O < R ? 1 : 0));
+                P.values[rbase + (int64_t)R * rlen + pos] = D3[cf][s0];
+              });
+            });
+          }
+      }
+  else
+  {
   // ---- contraction, one slab of rows (fixed k2) at a time ------------------------------------------------
   double *T1 = work;                          // [4][N1D][NA][NAP]: 0 = E.M, 1 = (D.M/h2^2 + E.S + Fs.N2/h2), 2 = E.N0, 3 = E.N1
   double *T2 = work + 4 * N1D * NA * NAP;      // [N1D (s1)][N1D^2 (o2,o1)][RS]
@@ -602,13 +793,14 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
       });
       row_begin = row_end;
     }
+  } // VALU contraction
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // Coupling blocks: one wave per interior face item (P = side whose packed points are used, Q = neighbour).
 //   A[P,Q]_ij = sum_q w [ (1/2 g^P_i - sigma phi^P_i) phi^Q_j - 1/2 phi^P_i g^Q_j ],   g = grad phi . n_P
 // ------------------------------------------------------------------------------------------------------------
-template <int N1D>
+template <int N1D, bool MFMA>
 __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const double *__restrict__ mt, const int n_items)
 {
   using M = MT<N1D>;
@@ -729,6 +921,106 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
         accN[c][a] = work[((1 + c) * Acc::ROWS + row) * NA + a];
     }
 
+  // ---- FE_DGQ(3): contraction stages 2 and 3 on the MFMA -------------------------------------------------------------
+  // Swapped orientation: the slabs run over Q's functions l (rows S of the result), this lane's column O is a function k
+  // of P.  The result rows are therefore rows of A[Q,P] - the block left of the diagonal, shifted by one double in
+  // deal.II's layout - and are written complete (512 B per instruction); A[P,Q] itself (aligned) goes through an LDS
+  // staging tile as full 128-byte lines.
+  if constexpr (MFMA)
+      {
+        static_assert(N1D == 4, "the MFMA contraction is written for FE_DGQ(3)");
+        ASet AE0, AH0, AE1, AH1;
+        __syncthreads(); // per-face tables complete
+        load_aset<true>(tabEQ, M::RS, lane, AE0);
+        load_aset<true>(tabHQ, M::RS, lane, AH0);
+        load_aset<true>(tabEQ + M::LTAB, M::RS, lane, AE1);
+        load_aset<true>(tabHQ + M::LTAB, M::RS, lane, AH1);
+        double *T1B = work;                  // [3 arrays][2 bf][2 ks][64]
+        double *T2B = work + 3 * 2 * 2 * 64; // [2 ks][4 cf][64]
+        const int64_t rbase = P.row_base[slot];
+        const int rlen = P.row_len[slot];
+        const int pos0 = P.it_pos[item];
+        const int qslot = P.it_nbr_slot[item];
+        const int64_t qbase = qslot >= 0 ? P.row_base[qslot] : 0;
+        const int qlen = qslot >= 0 ? P.row_len[qslot] : 0;
+        const int post = P.it_pos_t[item];
+        const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
+        const int O = di + 4 * dj + 16 * dblk; // this lane's function of P
+#pragma unroll 1
+        for (int s2 = 0; s2 < 4; ++s2)
+          {
+            __syncthreads();
+            if (act)
+              for (int kk = 0; kk < 4; ++kk)
+                {
+                  const int pr = 2 * M::LTAB + (kk * 4 + s2) * M::RS; // direction 2 tables, pair (k2 = kk, l2 = s2)
+                  double ee = 0.0, n0 = 0.0, n1 = 0.0;
+                  static_for<0, NA>([&](auto a_) {
+                    constexpr int a = a_;
+                    const double e = tabEQ[pr + a];
+                    ee += e * accS[a] + tabHQ[pr + a] * accN[2][a];
+                    n0 += e * accN[0][a];
+                    n1 += e * accN[1][a];
+                  });
+                  t1b_store(T1B, 0, kk, a0, a1, ee);
+                  t1b_store(T1B, 1, kk, a0, a1, n0);
+                  t1b_store(T1B, 2, kk, a0, a1, n1);
+                }
+            double D3[4][4];
+            for (int c = 0; c < 4; ++c)
+              for (int r = 0; r < 4; ++r)
+                D3[c][r] = 0.0;
+            {
+              __syncthreads();
+              double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = EQ0
+              mstage2_term(AE1, 0, 1.0, T1B, lane, D2);
+              mstage2_term(AH1, 2, 1.0, T1B, lane, D2);
+              mstage2_scatter(D2, T2B, lane);
+              __syncthreads();
+              mstage3(AE0, T2B, lane, D3);
+            }
+            {
+              __syncthreads();
+              double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = HQ0
+              mstage2_term(AE1, 1, 1.0, T1B, lane, D2);
+              mstage2_scatter(D2, T2B, lane);
+              __syncthreads();
+              mstage3(AH0, T2B, lane, D3);
+            }
+            // A[Q,P] = A[P,Q]^T: rows 16 s2 .. 16 s2 + 15 of Q's block, complete
+            if (qslot >= 0)
+              static_for<0, 4>([&](auto cf_) {
+                constexpr int cf = cf_;
+                static_for<0, 4>([&](auto s0_) {
+                  constexpr int s0 = s0_;
+                  const int R = s0 + 4 * cf + 16 * s2;
+                  P.values[qbase + (int64_t)R * qlen + post + O] = D3[cf][s0];
+                });
+              });
+            // A[P,Q]: columns 16 s2 .. 16 s2 + 15 of every row O, through an LDS staging tile (full 128-byte lines)
+            {
+              constexpr int SR = 17;
+              __syncthreads();
+              double *stage = work;
+              static_for<0, 4>([&](auto cf_) {
+                constexpr int cf = cf_;
+                static_for<0, 4>([&](auto r_) {
+                  constexpr int r = r_;
+                  stage[O * SR + r + 4 * cf] = D3[cf][r];
+                });
+              });
+              __syncthreads();
+              const int cc = lane & 15;
+              for (int jb = 0; jb < 64; jb += 4)
+                {
+                  const int j = jb + (lane >> 4);
+                  P.values[rbase + (int64_t)j * rlen + pos0 + 16 * s2 + cc] = stage[j * SR + cc];
+                }
+            }
+          }
+      }
+  else
+  {
   // Contraction in the SWAPPED orientation: this lane owns ROW i of A[P,Q] (a function of P), slabs run over the k2-type
   // index l2 of Q's functions.  A slab therefore yields complete rows j of the transposed block A[Q,P] - the block that
   // sits left of the diagonal in Q's rows and is shifted by one double in deal.II's diagonal-first layout - as coalesced
@@ -838,5 +1130,6 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
       }
       col_begin = col_end;
     }
+  } // VALU contraction
 }
 } // namespace pdhm

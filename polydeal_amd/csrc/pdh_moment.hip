@@ -7,14 +7,23 @@ extern "C" hipError_t pdh_launch_moment(int n1d, int which, const PdhDev *P, con
   if (count <= 0)
     return hipSuccess;
   const dim3 grid((unsigned)count), block(PDH_WAVE);
+  if (n1d == 4 && P->n == 64) // FE_DGQ(3): contraction stages 2 and 3 on the MFMA
+    {
+      if (which == 0)
+        hipLaunchKernelGGL((pdhm::k_mdiag<4, true>), grid, block, pdhm::lds_doubles_diag<4>() * sizeof(double), stream, *P, mtab, count);
+      else
+        hipLaunchKernelGGL((pdhm::k_moffdiag<4, true>), grid, block, pdhm::lds_doubles_offdiag<4>() * sizeof(double), stream, *P,
+                           mtab, count);
+      return hipGetLastError();
+    }
 #define PDH_MOM_CASE(N)                                                                                              \
   if (n1d == N)                                                                                                      \
     {                                                                                                                \
       if (which == 0)                                                                                                \
-        hipLaunchKernelGGL((pdhm::k_mdiag<N>), grid, block, pdhm::lds_doubles_diag<N>() * sizeof(double), stream, *P, \
+        hipLaunchKernelGGL((pdhm::k_mdiag<N, false>), grid, block, pdhm::lds_doubles_diag<N>() * sizeof(double), stream, *P, \
                            mtab, count);                                                                             \
       else                                                                                                           \
-        hipLaunchKernelGGL((pdhm::k_moffdiag<N>), grid, block, pdhm::lds_doubles_offdiag<N>() * sizeof(double),       \
+        hipLaunchKernelGGL((pdhm::k_moffdiag<N, false>), grid, block, pdhm::lds_doubles_offdiag<N>() * sizeof(double),       \
                            stream, *P, mtab, count);                                                                 \
       return hipGetLastError();                                                                                      \
     }
