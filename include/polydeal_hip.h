@@ -139,8 +139,9 @@ void *pdh_stream(pdh_ctx *ctx); /* hipStream_t the kernels are launched on */
 #define PDH_ALG_AUTO 0
 #define PDH_ALG_DIRECT 1
 #define PDH_ALG_MOMENT 2
+#define PDH_ALG_MIXED 3 /* reported only: AUTO chose MOMENT for the diagonal blocks and DIRECT for the coupling blocks */
 int pdh_set_algorithm(pdh_ctx *ctx, int algorithm);
-int pdh_algorithm_in_use(pdh_ctx *ctx); /* PDH_ALG_DIRECT or PDH_ALG_MOMENT for the resident problem, < 0 on error */
+int pdh_algorithm_in_use(pdh_ctx *ctx); /* PDH_ALG_DIRECT, PDH_ALG_MOMENT or PDH_ALG_MIXED for the resident problem, < 0 on error */
 
 /* Measurement helpers (HIP events on the context's stream).  kernel 0 = diagonal-block kernel
  * (volume + own-side face terms), kernel 1 = off-diagonal (interface coupling) kernel.            */

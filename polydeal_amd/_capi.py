@@ -221,7 +221,7 @@ class Context:
         rc = self.lib.pdh_algorithm_in_use(self.h)
         if rc < 0:
             self._chk(rc)
-        return {1: "direct", 2: "moment"}[rc]
+        return {1: "direct", 2: "moment", 3: "mixed"}[rc]
 
     def set_profiling(self, on=True):
         self._chk(self.lib.pdh_set_profiling(self.h, int(on)))

@@ -102,17 +102,22 @@ struct pdh_ctx
   int algorithm = PDH_ALG_AUTO;
   int basis = 0;
   double *d_mtab = nullptr;
-  bool use_moment() const
+  // which form each of the two launches uses: [0] diagonal blocks, [1] coupling blocks
+  bool use_moment(int kind) const
   {
     if (!d_mtab || algorithm == PDH_ALG_DIRECT)
       return false;
     if (algorithm == PDH_ALG_MOMENT)
       return true;
-    // auto: where the moment form was measured faster than the MFMA contraction (profiles/README.md)
-    return basis == PDH_BASIS_DGQ && dev.n1d == 4;
+    // auto: where the moment form was measured faster than the MFMA contraction (profiles/README.md): FE_DGQ(3) both
+    // kinds (8.5 -> 4.7 ms), FE_DGQ(2) the diagonal blocks only (BASELINE configs[3]: 9.7 -> 5.6 ms; its coupling blocks
+    // 4.3 ms direct vs 6.4 ms moment)
+    if (basis != PDH_BASIS_DGQ)
+      return false;
+    return dev.n1d == 4 || (dev.n1d == 3 && kind == 0);
   }
   bool profiling = false;
-  std::vector<hipEvent_t> events; // 3 per profiled launch: before k_diag, between, after k_offdiag
+  std::vector<hipEvent_t> events; // 3 per profiled launch: before the diagonal kernel, between, after the coupling kernel
   size_t ev_used = 0;
   hipEvent_t next_event()
   {
@@ -642,7 +647,8 @@ extern "C" int pdh_algorithm_in_use(pdh_ctx *ctx)
 {
   if (!ctx || !ctx->has_problem)
     return fail(ctx, PDH_ESTATE, "no problem resident");
-  return ctx->use_moment() ? PDH_ALG_MOMENT : PDH_ALG_DIRECT;
+  const bool d = ctx->use_moment(0), o = ctx->use_moment(1);
+  return d && o ? PDH_ALG_MOMENT : (d || o ? PDH_ALG_MIXED : PDH_ALG_DIRECT);
 }
 
 extern "C" int pdh_set_problem(pdh_ctx *ctx, const pdh_problem *p)
@@ -673,20 +679,16 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
     }
   if (ctx->algorithm == PDH_ALG_MOMENT && !ctx->d_mtab)
     return fail(ctx, PDH_EUNSUPPORTED, "the moment form exists for 3-D bases of degree 1..3 only");
-  if (ctx->use_moment())
-    {
-      PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_owned, ctx->stream));
-      if (ctx->profiling)
-        PDH_HIP(ctx, hipEventRecord(e1, ctx->stream));
-      PDH_HIP(ctx, pdh_launch_moment(n1d, 1, &ctx->dev, ctx->d_mtab, ctx->n_items, ctx->stream));
-    }
+  if (ctx->use_moment(0))
+    PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_owned, ctx->stream));
   else
-    {
-      PDH_HIP(ctx, fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
-      if (ctx->profiling)
-        PDH_HIP(ctx, hipEventRecord(e1, ctx->stream));
-      PDH_HIP(ctx, fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
-    }
+    PDH_HIP(ctx, fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, ctx->stream));
+  if (ctx->profiling)
+    PDH_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  if (ctx->use_moment(1))
+    PDH_HIP(ctx, pdh_launch_moment(n1d, 1, &ctx->dev, ctx->d_mtab, ctx->n_items, ctx->stream));
+  else
+    PDH_HIP(ctx, fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, ctx->stream));
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(e2, ctx->stream));
   return PDH_OK;
@@ -995,8 +997,8 @@ extern "C" int pdh_kernel_work(pdh_ctx *ctx, int64_t *mfma_instr)
 {
   if (!ctx || !ctx->has_problem || !mfma_instr)
     return fail(ctx, PDH_ESTATE, "no problem resident");
-  mfma_instr[0] = ctx->use_moment() ? 0 : ctx->mfma_diag; // the moment form issues no MFMA at all
-  mfma_instr[1] = ctx->use_moment() ? 0 : ctx->mfma_offdiag;
+  mfma_instr[0] = ctx->use_moment(0) ? 0 : ctx->mfma_diag; // counted for the direct form only
+  mfma_instr[1] = ctx->use_moment(1) ? 0 : ctx->mfma_offdiag;
   return PDH_OK;
 }
 

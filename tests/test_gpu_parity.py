@@ -597,6 +597,15 @@ def test_moment_form_parity(fe_cls, p, lg, b, dist, varname, diag_first):
     assert np.max(np.abs(vm - ref)) <= TOL * sc
     assert np.max(np.abs(vd - ref)) <= TOL * sc
     assert np.max(np.abs(vm - vd)) <= 1e-13 * sc
+    # AUTO: moment form for both kinds of block at FE_DGQ(3), for the diagonal blocks only at FE_DGQ(2), else direct
+    va, used_a = _values(kw, "auto")
+    expect = "direct"
+    if fe_cls is po.FE_DGQ and p == 3:
+        expect = "moment"
+    elif fe_cls is po.FE_DGQ and p == 2:
+        expect = "mixed"
+    assert used_a == expect
+    assert np.max(np.abs(va - ref)) <= TOL * sc
 
 
 @pytest.mark.parametrize("seed,disc", [(0, False), (1, True)])
