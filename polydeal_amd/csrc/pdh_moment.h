@@ -33,6 +33,11 @@
 #else
 #define PDHM_STORE_OK true
 #endif
+#if PDHM_EXP == 3
+#define PDHM_SLABS (P.n < 0 ? 4 : 0)
+#else
+#define PDHM_SLABS 4
+#endif
 
 namespace pdhm
 {
@@ -252,8 +257,12 @@ struct MomentAcc
   static constexpr int NA = M::NA, NAP = M::NAP, ROWS = NA * NA, NFA = (ROWS + 15) / 16, NFB = (NA + 3) / 4;
   static constexpr int REC = 2 * NA + 4 * NAP + 4; // L0[NA], L1[NA], (s_t L2)[4][NAP], zero pair, pad (bank spread of the 4 points of a step)
   static constexpr int ZERO = (2 * NA + 4 * NAP) * 8;
-  static constexpr int CH = 32; // points per chunk
-  int offA0[NFA], offA1[NFA], offBv, offBf[NFB];
+  static constexpr int CH = 32; // face points per chunk
+  // volume points need one weight only: smaller records, 64 points per chunk (one point per lane in the record phase)
+  static constexpr int VREC = 2 * NA + NAP + 2; // L0[NA], L1[NA], (w L2)[NAP], zero pair
+  static constexpr int VZERO = (2 * NA + NAP) * 8;
+  static constexpr int VCH = 64;
+  int offA0[NFA], offA1[NFA], offA0v[NFA], offA1v[NFA], offBv, offBf[NFB];
   pdh::Rotator rt;
   double accv[NFA][2];      // volume: columns a2 (two blocks, B replicated [F0,F1,F0,F1]), rotations 0,1
   double accf[NFA][NFB][4]; // faces
@@ -265,6 +274,8 @@ struct MomentAcc
       const int row = 16 * a + 4 * blk + idx;
       offA0[a] = row < ROWS ? (row / NA) * 8 : ZERO;
       offA1[a] = row < ROWS ? (NA + row % NA) * 8 : ZERO;
+      offA0v[a] = row < ROWS ? (row / NA) * 8 : VZERO;
+      offA1v[a] = row < ROWS ? (NA + row % NA) * 8 : VZERO;
       accv[a][0] = accv[a][1] = 0.0;
       static_for<0, NFB>([&](auto b_) {
         constexpr int b = b_;
@@ -273,7 +284,7 @@ struct MomentAcc
       });
     });
     const int a2v = 4 * (blk & 1) + idx;
-    offBv = a2v < NA ? (2 * NA + a2v) * 8 : ZERO;
+    offBv = a2v < NA ? (2 * NA + a2v) * 8 : VZERO;
     static_for<0, NFB>([&](auto b_) {
       constexpr int b = b_;
       const int a2 = 4 * b + blk;
@@ -281,9 +292,8 @@ struct MomentAcc
     });
     rt.init(lane);
   }
-  // record of one point: x^ = unit coordinates, s[NS] = weights (NS = 1: volume, 4: faces); dead points: s = 0
-  template <int NS>
-  static __device__ __forceinline__ void write_record(double *r, const double *xu, const double *s)
+  // volume record of one point (all 64 lanes, one point each); dead points: w = 0
+  static __device__ __forceinline__ void write_volume_record(double *r, const double *xu, double w)
   {
     double L[NA];
     legendre01<NA>(xu[0], L);
@@ -293,26 +303,64 @@ struct MomentAcc
     for (int a = 0; a < NA; ++a)
       r[NA + a] = L[a];
     legendre01<NA>(xu[2], L);
-    for (int t = 0; t < NS; ++t)
-      for (int a = 0; a < NA; ++a)
-        r[2 * NA + t * NAP + a] = s[t] * L[a];
-    r[2 * NA + 4 * NAP] = 0.0;
-    r[2 * NA + 4 * NAP + 1] = 0.0;
+    for (int a = 0; a < NA; ++a)
+      r[2 * NA + a] = w * L[a];
+    r[2 * NA + NA] = 0.0;
+    r[2 * NA + NAP] = 0.0;
+    r[2 * NA + NAP + 1] = 0.0;
+  }
+  // face record of one point, written by two lanes: half 0 (lanes 0-31) the factors of directions 0 and 1, half 1
+  // (lanes 32-63) the four weighted copies of direction 2;  xa, xb = the unit coordinates this half needs
+  static __device__ __forceinline__ void write_face_record_half(double *r, int half, double xa, double xb, const double *s)
+  {
+    double L[NA];
+    legendre01<NA>(xa, L);
+    if (half == 0)
+      {
+        for (int a = 0; a < NA; ++a)
+          r[a] = L[a];
+        legendre01<NA>(xb, L);
+        for (int a = 0; a < NA; ++a)
+          r[NA + a] = L[a];
+      }
+    else
+      {
+        for (int t = 0; t < 4; ++t)
+          {
+            for (int a = 0; a < NA; ++a)
+              r[2 * NA + t * NAP + a] = s[t] * L[a];
+            r[2 * NA + t * NAP + NA] = 0.0;
+          }
+        r[2 * NA + 4 * NAP] = 0.0;
+        r[2 * NA + 4 * NAP + 1] = 0.0;
+      }
   }
   static __device__ __forceinline__ double ld(const char *rb, int off) { return *reinterpret_cast<const double *>(rb + off); }
+  // One step = 4 points.  The LDS factors of the next step are requested before the MFMAs of the current one.
   __device__ __forceinline__ void volume_chunk(const double *rec, int cnt, int lane)
   {
     const int kq = lane >> 4;
     const int nsteps = (cnt + 3) >> 2;
+    double r0[NFA], r1[NFA], rb0;
+    auto fetch = [&](int step) {
+      const char *rb = reinterpret_cast<const char *>(rec + (4 * step + kq) * VREC);
+      static_for<0, NFA>([&](auto a_) {
+        constexpr int a = a_;
+        r0[a] = ld(rb, offA0v[a]);
+        r1[a] = ld(rb, offA1v[a]);
+      });
+      rb0 = ld(rb, offBv);
+    };
+    fetch(0);
     for (int step = 0; step < nsteps; ++step)
       {
-        const char *rb = reinterpret_cast<const char *>(rec + (4 * step + kq) * REC);
         double A[NFA];
         static_for<0, NFA>([&](auto a_) {
           constexpr int a = a_;
-          A[a] = ld(rb, offA0[a]) * ld(rb, offA1[a]);
+          A[a] = r0[a] * r1[a];
         });
-        const double B0 = ld(rb, offBv);
+        const double B0 = rb0;
+        fetch(step + 1 < nsteps ? step + 1 : step);
         const double B1 = rt.template rot<1>(B0);
         static_for<0, NFA>([&](auto a_) {
           constexpr int a = a_;
@@ -325,17 +373,34 @@ struct MomentAcc
   {
     const int kq = lane >> 4;
     const int nsteps = (cnt + 3) >> 2;
+    double r0[NFA], r1[NFA], rb[NFB];
+    auto fetch = [&](int step) {
+      const char *p = reinterpret_cast<const char *>(rec + (4 * step + kq) * REC);
+      static_for<0, NFA>([&](auto a_) {
+        constexpr int a = a_;
+        r0[a] = ld(p, offA0[a]);
+        r1[a] = ld(p, offA1[a]);
+      });
+      static_for<0, NFB>([&](auto b_) {
+        constexpr int b = b_;
+        rb[b] = ld(p, offBf[b]);
+      });
+    };
+    fetch(0);
     for (int step = 0; step < nsteps; ++step)
       {
-        const char *rb = reinterpret_cast<const char *>(rec + (4 * step + kq) * REC);
         double A[NFA], B[NFB][4];
         static_for<0, NFA>([&](auto a_) {
           constexpr int a = a_;
-          A[a] = ld(rb, offA0[a]) * ld(rb, offA1[a]);
+          A[a] = r0[a] * r1[a];
         });
         static_for<0, NFB>([&](auto b_) {
           constexpr int b = b_;
-          B[b][0] = ld(rb, offBf[b]);
+          B[b][0] = rb[b];
+        });
+        fetch(step + 1 < nsteps ? step + 1 : step);
+        static_for<0, NFB>([&](auto b_) {
+          constexpr int b = b_;
           B[b][1] = rt.template rot<1>(B[b][0]);
           B[b][2] = rt.template rot<2>(B[b][0]);
           B[b][3] = rt.template rot<3>(B[b][0]);
@@ -495,7 +560,7 @@ constexpr int lds_doubles_diag()
   using M = MT<N1D>;
   using A = MomentAcc<N1D>;
   constexpr int tb = 3 * M::LTAB;
-  constexpr int recs = A::CH * A::REC;
+  constexpr int recs = (A::CH * A::REC > A::VCH * A::VREC) ? A::CH * A::REC : A::VCH * A::VREC;
   constexpr int mx = 5 * A::ROWS * M::NA;                                     // gathered moments
   constexpr int work = 4 * N1D * M::NA * M::NAP + N1D * N1D * N1D * M::RS; // T1 (4 arrays) + T2
   constexpr int m1 = recs > mx ? recs : mx;
@@ -549,21 +614,24 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
   // ---- volume moments -----------------------------------------------------------------------------------
   {
     const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
-    for (int64_t base = qb; base < qe; base += Acc::CH)
+#if PDHM_EXP == 2
+    for (int64_t base = qb; base < qe && P.n < 0; base += Acc::VCH)
+#else
+    for (int64_t base = qb; base < qe; base += Acc::VCH)
+#endif
       {
-        const int cnt = (int)((qe - base < Acc::CH) ? (qe - base) : Acc::CH);
+        const int cnt = (int)((qe - base < Acc::VCH) ? (qe - base) : Acc::VCH);
         __syncthreads();
-        if (lane < Acc::CH)
-          {
-            double xu[DIM] = {0.5, 0.5, 0.5}, w = 0.0;
-            if (lane < cnt)
-              {
-                for (int c = 0; c < DIM; ++c)
-                  xu[c] = (P.vq_x[c * P.vq_stride + base + lane] - lo[c]) * ih[c];
-                w = P.vq_w[base + lane];
-              }
-            Acc::template write_record<1>(work + lane * Acc::REC, xu, &w);
-          }
+        {
+          double xu[DIM] = {0.5, 0.5, 0.5}, w = 0.0;
+          if (lane < cnt)
+            {
+              for (int c = 0; c < DIM; ++c)
+                xu[c] = (P.vq_x[c * P.vq_stride + base + lane] - lo[c]) * ih[c];
+              w = P.vq_w[base + lane];
+            }
+          Acc::write_volume_record(work + lane * Acc::VREC, xu, w);
+        }
         __syncthreads();
         ma.volume_chunk(work, cnt, lane);
       }
@@ -571,25 +639,36 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
   // ---- moments of the own-side face points (all faces of the polytope, boundary included) ------------------
   {
     const int64_t pb = P.ap_ptr[slot], pe = P.ap_ptr[slot + 1];
+#if PDHM_EXP == 2
+    for (int64_t base = pb; base < pe && P.n < 0; base += Acc::CH)
+#else
     for (int64_t base = pb; base < pe; base += Acc::CH)
+#endif
       {
         const int cnt = (int)((pe - base < Acc::CH) ? (pe - base) : Acc::CH);
         __syncthreads();
-        if (lane < Acc::CH)
-          {
-            double xu[DIM] = {0.5, 0.5, 0.5}, s[4] = {0.0, 0.0, 0.0, 0.0};
-            if (lane < cnt)
-              {
-                for (int c = 0; c < DIM; ++c)
-                  xu[c] = (P.ap_x[c * P.ap_stride + base + lane] - lo[c]) * ih[c];
-                const double w = P.ap_wself[base + lane];
-                // U_i phi_j + phi_i U_j  with  U = -1/2 grad phi . n + (sig/2) phi   (pdh_kernels.h, k_diag)
-                s[0] = w * P.ap_sig[base + lane];
-                for (int c = 0; c < DIM; ++c)
-                  s[1 + c] = -0.5 * w * P.ap_n[c * P.ap_stride + base + lane];
-              }
-            Acc::template write_record<4>(work + lane * Acc::REC, xu, s);
-          }
+        {
+          const int half = lane >> 5, pt = lane & 31;
+          double xa = 0.5, xb = 0.5, s[4] = {0.0, 0.0, 0.0, 0.0};
+          if (pt < cnt)
+            {
+              if (half == 0)
+                {
+                  xa = (P.ap_x[0 * P.ap_stride + base + pt] - lo[0]) * ih[0];
+                  xb = (P.ap_x[1 * P.ap_stride + base + pt] - lo[1]) * ih[1];
+                }
+              else
+                {
+                  xa = (P.ap_x[2 * P.ap_stride + base + pt] - lo[2]) * ih[2];
+                  const double w = P.ap_wself[base + pt];
+                  // U_i phi_j + phi_i U_j  with  U = -1/2 grad phi . n + (sig/2) phi   (pdh_kernels.h, k_diag)
+                  s[0] = w * P.ap_sig[base + pt];
+                  for (int c = 0; c < DIM; ++c)
+                    s[1 + c] = -0.5 * w * P.ap_n[c * P.ap_stride + base + pt];
+                }
+            }
+          Acc::write_face_record_half(work + pt * Acc::REC, half, xa, xb, s);
+        }
         __syncthreads();
         ma.face_chunk(work, cnt, lane);
       }
@@ -625,7 +704,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
         const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
         const int O = di + 4 * dj + 16 * dblk; // this lane's column
 #pragma unroll 1
-        for (int k2 = 0; k2 < 4; ++k2)
+        for (int k2 = 0; k2 < PDHM_SLABS; ++k2)
           {
             __syncthreads();
             if (act)
@@ -692,7 +771,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
                 int pos = L + O;
                 if (P.diag_first)
                   pos = (O == R) ? 0 : (L + O + (O < R ? 1 : 0));
-                P.values[rbase + (int64_t)R * rlen + pos] = D3[cf][s0];
+                if (PDHM_STORE_OK)
+                  P.values[rbase + (int64_t)R * rlen + pos] = D3[cf][s0];
               });
             });
           }
@@ -891,20 +971,27 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
       {
         const int cnt = (int)((pe - base < Acc::CH) ? (pe - base) : Acc::CH);
         __syncthreads();
-        if (lane < Acc::CH)
-          {
-            double xu[DIM] = {0.5, 0.5, 0.5}, s[4] = {0.0, 0.0, 0.0, 0.0};
-            if (lane < cnt)
-              {
-                for (int c = 0; c < DIM; ++c)
-                  xu[c] = (P.ap_x[c * P.ap_stride + base + lane] - lo[c]) * ih[c];
-                const double w = P.ap_wcross[base + lane];
-                s[0] = -w * P.ap_sig[base + lane];
-                for (int c = 0; c < DIM; ++c)
-                  s[1 + c] = 0.5 * w * P.ap_n[c * P.ap_stride + base + lane];
-              }
-            Acc::template write_record<4>(work + lane * Acc::REC, xu, s);
-          }
+        {
+          const int half = lane >> 5, pt = lane & 31;
+          double xa = 0.5, xb = 0.5, s[4] = {0.0, 0.0, 0.0, 0.0};
+          if (pt < cnt)
+            {
+              if (half == 0)
+                {
+                  xa = (P.ap_x[0 * P.ap_stride + base + pt] - lo[0]) * ih[0];
+                  xb = (P.ap_x[1 * P.ap_stride + base + pt] - lo[1]) * ih[1];
+                }
+              else
+                {
+                  xa = (P.ap_x[2 * P.ap_stride + base + pt] - lo[2]) * ih[2];
+                  const double w = P.ap_wcross[base + pt];
+                  s[0] = -w * P.ap_sig[base + pt];
+                  for (int c = 0; c < DIM; ++c)
+                    s[1 + c] = 0.5 * w * P.ap_n[c * P.ap_stride + base + pt];
+                }
+            }
+          Acc::write_face_record_half(work + pt * Acc::REC, half, xa, xb, s);
+        }
         __syncthreads();
         ma.face_chunk(work, cnt, lane);
       }
@@ -947,7 +1034,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
         const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
         const int O = di + 4 * dj + 16 * dblk; // this lane's function of P
 #pragma unroll 1
-        for (int s2 = 0; s2 < 4; ++s2)
+        for (int s2 = 0; s2 < PDHM_SLABS; ++s2)
           {
             __syncthreads();
             if (act)
@@ -994,7 +1081,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
                 static_for<0, 4>([&](auto s0_) {
                   constexpr int s0 = s0_;
                   const int R = s0 + 4 * cf + 16 * s2;
-                  P.values[qbase + (int64_t)R * qlen + post + O] = D3[cf][s0];
+                  if (PDHM_STORE_OK)
+                    P.values[qbase + (int64_t)R * qlen + post + O] = D3[cf][s0];
                 });
               });
             // A[P,Q]: columns 16 s2 .. 16 s2 + 15 of every row O, through an LDS staging tile (full 128-byte lines)
@@ -1014,7 +1102,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
               for (int jb = 0; jb < 64; jb += 4)
                 {
                   const int j = jb + (lane >> 4);
-                  P.values[rbase + (int64_t)j * rlen + pos0 + 16 * s2 + cc] = stage[j * SR + cc];
+                  if (PDHM_STORE_OK)
+                    P.values[rbase + (int64_t)j * rlen + pos0 + 16 * s2 + cc] = stage[j * SR + cc];
                 }
             }
           }
