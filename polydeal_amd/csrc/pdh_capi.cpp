@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -679,6 +680,33 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
     }
   if (ctx->algorithm == PDH_ALG_MOMENT && !ctx->d_mtab)
     return fail(ctx, PDH_EUNSUPPORTED, "the moment form exists for 3-D bases of degree 1..3 only");
+  static const int two = std::getenv("PDH_EXP_TWO_STREAMS") ? std::atoi(std::getenv("PDH_EXP_TWO_STREAMS")) : 0;
+  if (two && !ctx->profiling && ctx->use_moment(0) && ctx->use_moment(1))
+    {
+      static hipStream_t s2 = nullptr;
+      static hipEvent_t ef = nullptr, ej = nullptr;
+      if (!s2)
+        {
+          PDH_HIP(ctx, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+          PDH_HIP(ctx, hipEventCreateWithFlags(&ef, hipEventDisableTiming));
+          PDH_HIP(ctx, hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        }
+      PDH_HIP(ctx, hipEventRecord(ef, ctx->stream));
+      PDH_HIP(ctx, hipStreamWaitEvent(s2, ef, 0));
+      if (two == 1)
+        {
+          PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_owned, ctx->stream));
+          PDH_HIP(ctx, pdh_launch_moment(n1d, 1, &ctx->dev, ctx->d_mtab, ctx->n_items, s2));
+        }
+      else
+        {
+          PDH_HIP(ctx, pdh_launch_moment(n1d, 1, &ctx->dev, ctx->d_mtab, ctx->n_items, s2));
+          PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_owned, ctx->stream));
+        }
+      PDH_HIP(ctx, hipEventRecord(ej, s2));
+      PDH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ej, 0));
+      return PDH_OK;
+    }
   if (ctx->use_moment(0))
     PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_owned, ctx->stream));
   else

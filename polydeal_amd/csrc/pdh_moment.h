@@ -262,7 +262,13 @@ struct MomentAcc
   static constexpr int VREC = 2 * NA + NAP + 2; // L0[NA], L1[NA], (w L2)[NAP], zero pair
   static constexpr int VZERO = (2 * NA + NAP) * 8;
   static constexpr int VCH = 64;
-  int offA0[NFA], offA1[NFA], offA0v[NFA], offA1v[NFA], offBv, offBf[NFB];
+  // If the last A fragment holds a single live row (NA^2 = 16 m + 1: 49 pairs for FE_DGQ(3), 25 for p = 2, 9 for p = 1) its
+  // NFB * 4 (+2) MFMAs per step would run at 1/16 row utilisation.  That row - the pair (NA-1, NA-1) - is computed
+  // transposed instead: the B fragments act as rows and one column carries y = L_{NA-1}(x0) L_{NA-1}(x1), NFB (+1) MFMAs.
+  static constexpr bool LAST_ROW = (ROWS % 16 == 1) && NFA > 1;
+  static constexpr int NFAM = LAST_ROW ? NFA - 1 : NFA; // A fragments multiplied in the regular way
+  int offA0[NFA], offA1[NFA], offA0v[NFA], offA1v[NFA], offBv, offBf[NFB], offY0, offY0v;
+  double accyv, accyf[NFB]; // transposed products of the last row
   pdh::Rotator rt;
   double accv[NFA][2];      // volume: columns a2 (two blocks, B replicated [F0,F1,F0,F1]), rotations 0,1
   double accf[NFA][NFB][4]; // faces
@@ -282,6 +288,14 @@ struct MomentAcc
         for (int r = 0; r < 4; ++r)
           accf[a][b][r] = 0.0;
       });
+    });
+    // y operand: column 0 of every lane block carries L_{NA-1}(x0) * L_{NA-1}(x1) (offY0 / the L1 entry NA doubles later)
+    offY0 = idx == 0 ? (NA - 1) * 8 : ZERO - NA * 8;
+    offY0v = idx == 0 ? (NA - 1) * 8 : VZERO - NA * 8;
+    accyv = 0.0;
+    static_for<0, NFB>([&](auto b_) {
+      constexpr int b = b_;
+      accyf[b] = 0.0;
     });
     const int a2v = 4 * (blk & 1) + idx;
     offBv = a2v < NA ? (2 * NA + a2v) * 8 : VZERO;
@@ -341,46 +355,59 @@ struct MomentAcc
   {
     const int kq = lane >> 4;
     const int nsteps = (cnt + 3) >> 2;
-    double r0[NFA], r1[NFA], rb0;
+    double r0[NFA], r1[NFA], rb0, ry0 = 0.0, ry1 = 0.0;
     auto fetch = [&](int step) {
       const char *rb = reinterpret_cast<const char *>(rec + (4 * step + kq) * VREC);
-      static_for<0, NFA>([&](auto a_) {
+      static_for<0, NFAM>([&](auto a_) {
         constexpr int a = a_;
         r0[a] = ld(rb, offA0v[a]);
         r1[a] = ld(rb, offA1v[a]);
       });
+      if constexpr (LAST_ROW)
+        {
+          ry0 = ld(rb, offY0v);
+          ry1 = ld(rb, offY0v + NA * 8);
+        }
       rb0 = ld(rb, offBv);
     };
     fetch(0);
     for (int step = 0; step < nsteps; ++step)
       {
         double A[NFA];
-        static_for<0, NFA>([&](auto a_) {
+        static_for<0, NFAM>([&](auto a_) {
           constexpr int a = a_;
           A[a] = r0[a] * r1[a];
         });
+        const double Y = ry0 * ry1;
         const double B0 = rb0;
         fetch(step + 1 < nsteps ? step + 1 : step);
         const double B1 = rt.template rot<1>(B0);
-        static_for<0, NFA>([&](auto a_) {
+        static_for<0, NFAM>([&](auto a_) {
           constexpr int a = a_;
           accv[a][0] = pdh::mfma4(A[a], B0, accv[a][0]);
           accv[a][1] = pdh::mfma4(A[a], B1, accv[a][1]);
         });
+        if constexpr (LAST_ROW)
+          accyv = pdh::mfma4(B0, Y, accyv);
       }
   }
   __device__ __forceinline__ void face_chunk(const double *rec, int cnt, int lane)
   {
     const int kq = lane >> 4;
     const int nsteps = (cnt + 3) >> 2;
-    double r0[NFA], r1[NFA], rb[NFB];
+    double r0[NFA], r1[NFA], rb[NFB], ry0 = 0.0, ry1 = 0.0;
     auto fetch = [&](int step) {
       const char *p = reinterpret_cast<const char *>(rec + (4 * step + kq) * REC);
-      static_for<0, NFA>([&](auto a_) {
+      static_for<0, NFAM>([&](auto a_) {
         constexpr int a = a_;
         r0[a] = ld(p, offA0[a]);
         r1[a] = ld(p, offA1[a]);
       });
+      if constexpr (LAST_ROW)
+        {
+          ry0 = ld(p, offY0);
+          ry1 = ld(p, offY0 + NA * 8);
+        }
       static_for<0, NFB>([&](auto b_) {
         constexpr int b = b_;
         rb[b] = ld(p, offBf[b]);
@@ -390,10 +417,11 @@ struct MomentAcc
     for (int step = 0; step < nsteps; ++step)
       {
         double A[NFA], B[NFB][4];
-        static_for<0, NFA>([&](auto a_) {
+        static_for<0, NFAM>([&](auto a_) {
           constexpr int a = a_;
           A[a] = r0[a] * r1[a];
         });
+        const double Y = ry0 * ry1;
         static_for<0, NFB>([&](auto b_) {
           constexpr int b = b_;
           B[b][0] = rb[b];
@@ -405,7 +433,7 @@ struct MomentAcc
           B[b][2] = rt.template rot<2>(B[b][0]);
           B[b][3] = rt.template rot<3>(B[b][0]);
         });
-        static_for<0, NFA>([&](auto a_) {
+        static_for<0, NFAM>([&](auto a_) {
           constexpr int a = a_;
           static_for<0, NFB>([&](auto b_) {
             constexpr int b = b_;
@@ -415,6 +443,11 @@ struct MomentAcc
             });
           });
         });
+        if constexpr (LAST_ROW)
+          static_for<0, NFB>([&](auto b_) {
+            constexpr int b = b_;
+            accyf[b] = pdh::mfma4(B[b][0], Y, accyf[b]);
+          });
       }
   }
   // Scatter the accumulators into Mx[tensor][row][NA] (VOL: tensor 0 = volume, 1 + t = face weight t; else t).  D layout:
@@ -424,7 +457,21 @@ struct MomentAcc
   __device__ __forceinline__ void scatter(double *Mx, int lane) const
   {
     const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
-    static_for<0, NFA>([&](auto a_) {
+    if constexpr (LAST_ROW)
+      if (j == 0)
+        {
+          // transposed products: D lane (i, blk, 0) = sum_q B[row' = 4 blk + i](q) y(q); faces: row' = (a2 = 4 b + blk, t = i),
+          // volume: row' = a2 = 4 (blk & 1) + i (replicated, blocks 0 and 1 are the live copies)
+          if constexpr (VOL)
+            if (blk < 2 && 4 * blk + i < NA)
+              Mx[(ROWS - 1) * NA + 4 * blk + i] = accyv;
+          static_for<0, NFB>([&](auto b_) {
+            constexpr int b = b_;
+            if (4 * b + blk < NA)
+              Mx[(((VOL ? 1 : 0) + i) * ROWS + ROWS - 1) * NA + 4 * b + blk] = accyf[b];
+          });
+        }
+    static_for<0, NFAM>([&](auto a_) {
       constexpr int a = a_;
       const int row = 16 * a + 4 * blk + i;
       if (row < ROWS)

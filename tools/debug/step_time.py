@@ -26,4 +26,4 @@ for _ in range(10):
     ctx.assemble_device()
 print("LDS pad %s: kernel ms" % os.environ.get("PDH_EXP_LDS_PAD", "0"), ctx.kernel_times_ms(), ctx.stats()["lds_bytes_diag"])
 ctx.set_profiling(False)
-print("DIAG_FIRST=%s PDH_TWO_STREAMS=%s %s: %.3f ms/step" % (os.environ.get("DIAG_FIRST", "1"), os.environ.get("PDH_TWO_STREAMS", "0"), basis, best * 1e3))
+print("DIAG_FIRST=%s PDH_TWO_STREAMS=%s %s: %.3f ms/step" % (os.environ.get("DIAG_FIRST", "1"), os.environ.get("PDH_EXP_TWO_STREAMS", "0"), basis, best * 1e3))
