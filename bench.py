@@ -83,6 +83,10 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     r0, r1 = row_range(n_agg, n, rank, world)
     ctx = pa.Context(local_rank)
     ctx.set_algorithm(alg)
+    # The library overlaps its two kernels on large problems (two streams, ~3 % faster).  The timed region runs them one
+    # after the other so that the per-kernel HIP-event durations the roofline uses are those of kernels that have the
+    # device to themselves (and match rocprofv3); the overlapped step time is measured afterwards and reported beside it.
+    ctx.set_overlap(False)
     ctx.set_problem(flat, r0, r1)
     alg_used = ctx.algorithm_in_use()
     t_setup = time.time() - t0
@@ -106,6 +110,15 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     dt = time.perf_counter() - t1
     kms, nl = ctx.kernel_times_ms()
     ctx.set_profiling(False)
+    ctx.set_overlap(True)
+    ctx.assemble_device()
+    sync_all()
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        ctx.assemble_device()
+    sync_all()
+    dt_overlap = time.perf_counter() - t2
+    ctx.set_overlap(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -120,7 +133,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     chk = float(np.sum(vals)) if vals is not None else None
     ctx.close()
     return dict(n_dofs=ah.n_dofs, n_agg=n_agg, n=n, dt=dt, kms=kms, nl=nl, stats=stats, work=work, mfma=mfma,
-                t_setup=t_setup, nnz=flat.nnz, checksum=chk, alg=alg_used)
+                t_setup=t_setup, nnz=flat.nnz, checksum=chk, alg=alg_used, dt_overlap=dt_overlap)
 
 
 def effective_cpus():
@@ -294,6 +307,9 @@ def main():
                     "algorithm": "moment form (pdh_moment.h): Legendre moments of the quadrature on the f64 MFMA + sum "
                                  "factorisation; VALU / LDS bound, not at the HBM roof yet",
                     "other_kernel": ke[1 - dom],
+                    "overlapped_ms_per_step": 1e3 * r["dt_overlap"] / args.steps,
+                    "overlap_note": "library default: the two kernels run concurrently on two streams (pdh_set_overlap); the timed "
+                                    "region above serialises them so that kernel_ms are undisturbed per-kernel durations",
                     "whole_step_GBs": (w["bytes"][0] + w["bytes"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-9,
                     "whole_step_algorithmic_TFLOPs": (w["flops"][0] + w["flops"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-12}
             if direct is not None:

@@ -143,6 +143,11 @@ void *pdh_stream(pdh_ctx *ctx); /* hipStream_t the kernels are launched on */
 int pdh_set_algorithm(pdh_ctx *ctx, int algorithm);
 int pdh_algorithm_in_use(pdh_ctx *ctx); /* PDH_ALG_DIRECT, PDH_ALG_MOMENT or PDH_ALG_MIXED for the resident problem, < 0 on error */
 
+/* On large problems the two kernels of a step (diagonal blocks / coupling blocks: disjoint values, complementary
+ * bottlenecks) run concurrently, the second on an internal stream forked from and joined into pdh_stream() - callers
+ * still see one ordered stream.  pdh_set_overlap(ctx, 0) serialises them (cleaner per-kernel timings, ~4 % slower).   */
+int pdh_set_overlap(pdh_ctx *ctx, int enabled);
+
 /* Measurement helpers (HIP events on the context's stream).  kernel 0 = diagonal-block kernel
  * (volume + own-side face terms), kernel 1 = off-diagonal (interface coupling) kernel.            */
 #define PDH_N_KERNELS 2

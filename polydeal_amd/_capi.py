@@ -43,7 +43,7 @@ EXPORTS = [
     "pdh_create", "pdh_destroy", "pdh_last_error", "pdh_set_problem", "pdh_set_problem_local",
     "pdh_assemble_device", "pdh_assemble", "pdh_assemble_sip", "pdh_assemble_sip_local",
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
-    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values", "pdh_set_algorithm", "pdh_algorithm_in_use",
+    "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values", "pdh_set_algorithm", "pdh_algorithm_in_use", "pdh_set_overlap",
 ]
 
 _lib = None
@@ -65,6 +65,7 @@ def _bind(lib):
     lib.pdh_assemble_rhs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pdh_evaluate.argtypes = [C.c_void_p] * 6
     lib.pdh_set_algorithm.argtypes = [C.c_void_p, C.c_int]
+    lib.pdh_set_overlap.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_algorithm_in_use.argtypes = [C.c_void_p]
     lib.pdh_shape_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
@@ -216,6 +217,10 @@ class Context:
     def set_algorithm(self, alg):
         """'auto' | 'direct' (MFMA contraction over the points) | 'moment' (Legendre moments + sum factorisation)."""
         self._chk(self.lib.pdh_set_algorithm(self.h, {"auto": 0, "direct": 1, "moment": 2}[alg]))
+
+    def set_overlap(self, on=True):
+        """Run the two kernels of a step concurrently on large problems (default) or strictly one after the other."""
+        self._chk(self.lib.pdh_set_overlap(self.h, int(on)))
 
     def algorithm_in_use(self):
         rc = self.lib.pdh_algorithm_in_use(self.h)

@@ -652,3 +652,31 @@ def test_moment_form_unavailable_is_reported():
     with pytest.raises(pa.PdhError):
         ctx.assemble()
     ctx.close()
+
+
+def test_overlapped_and_serial_launch_agree():
+    """Large problems run their two kernels concurrently on two streams (pdh_set_overlap); the values - every CSR entry is
+    written by exactly one work item - must be bitwise those of the serial launch, with either algorithm."""
+    import polydeal_amd as pa
+
+    fe = po.FE_DGQ(3, 1)
+    ah = build(3, 4, 1, fe, 2)  # 4096 polytopes + 11520 interior faces: above the overlap threshold
+    kw = flatten(ah, po.variant_poisson_example(fe), with_colind=False)
+    prob = pa.Problem(**kw)
+    ctx = pa.Context(0)
+    ctx.set_problem(prob)
+    out = {}
+    for alg in ("direct", "moment"):
+        ctx.set_algorithm(alg)
+        for ov in (True, False):
+            ctx.set_overlap(ov)
+            out[(alg, ov)] = ctx.assemble()
+        assert np.array_equal(out[(alg, True)], out[(alg, False)])
+    ctx.set_overlap(True)
+    ctx.set_profiling(True)
+    ctx.assemble_device()
+    (t0, t1), nl = ctx.kernel_times_ms()
+    ctx.close()
+    assert nl == 1 and t0 > 0 and t1 > 0
+    sc = np.max(np.abs(out[("direct", False)]))
+    assert np.max(np.abs(out[("direct", False)] - out[("moment", False)])) <= 1e-13 * sc
