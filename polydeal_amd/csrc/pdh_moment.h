@@ -537,16 +537,32 @@ __device__ __forceinline__ int t1b_index(int arr, int hi, int a0, int a1)
   return ((arr * 2 + (hi >> 1)) * 2 + (a1 >> 2)) * 64 + (a1 & 3) * 16 + (2 * (hi & 1) + (a0 >> 2)) * 4 + (a0 & 3);
 }
 
-// write one stage-1 value and the zero pads that belong to this lane's (a0,a1) (a0 = 6 / a1 = 6 own the pad row / column)
-__device__ __forceinline__ void t1b_store(double *T1B, int arr, int hi, int a0, int a1, double v)
+// Offsets of this lane's stage-1 outputs inside one [hi] slice of T1B (everything that depends on (a0,a1) only, computed
+// once per kernel): the value itself and the zero pads the lane owns (a1 = 6: column 7; a0 = 6: row 7; both: the corner).
+struct T1Off
 {
-  T1B[t1b_index(arr, hi, a0, a1)] = v;
-  if (a1 == 6)
-    T1B[t1b_index(arr, hi, a0, 7)] = 0.0;
-  if (a0 == 6)
-    T1B[t1b_index(arr, hi, 7, a1)] = 0.0;
-  if (a0 == 6 && a1 == 6)
-    T1B[t1b_index(arr, hi, 7, 7)] = 0.0;
+  int val, padc, padr, padx; // pad offsets are -1 when the lane does not own that pad
+  __device__ __forceinline__ void init(int a0, int a1)
+  {
+    val = t1b_index(0, 0, a0, a1);
+    padc = a1 == 6 ? t1b_index(0, 0, a0, 7) : -1;
+    padr = a0 == 6 ? t1b_index(0, 0, 7, a1) : -1;
+    padx = (a0 == 6 && a1 == 6) ? t1b_index(0, 0, 7, 7) : -1;
+  }
+};
+
+// ARR, HI compile-time: T1B offset of the slice = ARR * 256 + (HI >> 1) * 128 + (HI & 1) * 8
+template <int ARR, int HI>
+__device__ __forceinline__ void t1b_store(double *T1B, const T1Off &o, double v)
+{
+  constexpr int base = ARR * 256 + (HI >> 1) * 128 + (HI & 1) * 8;
+  T1B[base + o.val] = v;
+  if (o.padc >= 0)
+    T1B[base + o.padc] = 0.0;
+  if (o.padr >= 0)
+    T1B[base + o.padr] = 0.0;
+  if (o.padx >= 0)
+    T1B[base + o.padx] = 0.0;
 }
 
 // one term of stage 2: D2[bf][r] += (scale * A) . T1B[arr]      (ASets are passed by reference and indexed statically
@@ -750,28 +766,30 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
         const double ih0 = ih[0], ih1 = ih[1], ih2 = ih[2];
         const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
         const int O = di + 4 * dj + 16 * dblk; // this lane's column
+        T1Off t1o;
+        t1o.init(a0, a1);
 #pragma unroll 1
         for (int k2 = 0; k2 < PDHM_SLABS; ++k2)
           {
             __syncthreads();
             if (act)
-              for (int ll = 0; ll < 4; ++ll)
-                {
-                  const int pr = (k2 * 4 + ll) * M::RS;
-                  double g1 = 0.0, ee = 0.0, n0 = 0.0, n1 = 0.0;
-                  static_for<0, NA>([&](auto a_) {
-                    constexpr int a = a_;
-                    const double e = tabE[pr + a];
-                    g1 += e * accM[a];
-                    ee += (tabD[pr + a] * (ih2 * ih2)) * accM[a] + e * accS[a] + (tabF[pr + a] * ih2) * accN[2][a];
-                    n0 += e * accN[0][a];
-                    n1 += e * accN[1][a];
-                  });
-                  t1b_store(T1B, 0, ll, a0, a1, g1);
-                  t1b_store(T1B, 1, ll, a0, a1, ee);
-                  t1b_store(T1B, 2, ll, a0, a1, n0);
-                  t1b_store(T1B, 3, ll, a0, a1, n1);
-                }
+              static_for<0, 4>([&](auto ll_) {
+                constexpr int ll = ll_;
+                const int pr = (k2 * 4 + ll) * M::RS;
+                double g1 = 0.0, ee = 0.0, n0 = 0.0, n1 = 0.0;
+                static_for<0, NA>([&](auto a_) {
+                  constexpr int a = a_;
+                  const double e = tabE[pr + a];
+                  g1 += e * accM[a];
+                  ee += (tabD[pr + a] * (ih2 * ih2)) * accM[a] + e * accS[a] + (tabF[pr + a] * ih2) * accN[2][a];
+                  n0 += e * accN[0][a];
+                  n1 += e * accN[1][a];
+                });
+                t1b_store<0, ll>(T1B, t1o, g1);
+                t1b_store<1, ll>(T1B, t1o, ee);
+                t1b_store<2, ll>(T1B, t1o, n0);
+                t1b_store<3, ll>(T1B, t1o, n1);
+              });
             // the A operands (24 doubles) are re-read per slab instead of living through stage 1 (register pressure);
             // the opaque zero keeps the compiler from hoisting the loads out of the loop again
             int zero = 0;
@@ -1080,26 +1098,28 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
         const int post = P.it_pos_t[item];
         const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
         const int O = di + 4 * dj + 16 * dblk; // this lane's function of P
+        T1Off t1o;
+        t1o.init(a0, a1);
 #pragma unroll 1
         for (int s2 = 0; s2 < PDHM_SLABS; ++s2)
           {
             __syncthreads();
             if (act)
-              for (int kk = 0; kk < 4; ++kk)
-                {
-                  const int pr = 2 * M::LTAB + (kk * 4 + s2) * M::RS; // direction 2 tables, pair (k2 = kk, l2 = s2)
-                  double ee = 0.0, n0 = 0.0, n1 = 0.0;
-                  static_for<0, NA>([&](auto a_) {
-                    constexpr int a = a_;
-                    const double e = tabEQ[pr + a];
-                    ee += e * accS[a] + tabHQ[pr + a] * accN[2][a];
-                    n0 += e * accN[0][a];
-                    n1 += e * accN[1][a];
-                  });
-                  t1b_store(T1B, 0, kk, a0, a1, ee);
-                  t1b_store(T1B, 1, kk, a0, a1, n0);
-                  t1b_store(T1B, 2, kk, a0, a1, n1);
-                }
+              static_for<0, 4>([&](auto kk_) {
+                constexpr int kk = kk_;
+                const int pr = 2 * M::LTAB + (kk * 4 + s2) * M::RS; // direction 2 tables, pair (k2 = kk, l2 = s2)
+                double ee = 0.0, n0 = 0.0, n1 = 0.0;
+                static_for<0, NA>([&](auto a_) {
+                  constexpr int a = a_;
+                  const double e = tabEQ[pr + a];
+                  ee += e * accS[a] + tabHQ[pr + a] * accN[2][a];
+                  n0 += e * accN[0][a];
+                  n1 += e * accN[1][a];
+                });
+                t1b_store<0, kk>(T1B, t1o, ee);
+                t1b_store<1, kk>(T1B, t1o, n0);
+                t1b_store<2, kk>(T1B, t1o, n1);
+              });
             double D3[4][4];
             for (int c = 0; c < 4; ++c)
               for (int r = 0; r < 4; ++r)

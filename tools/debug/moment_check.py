@@ -41,6 +41,7 @@ if len(sys.argv) > 1:
         flat = ah.flatten(pa.SipVariant.poisson_example(fe), diag_first=True, with_colind=False)
         ctx = pa.Context(0)
         ctx.set_problem(flat)
+        ctx.set_overlap(False)
         for alg in ("direct", "moment"):
             ctx.set_algorithm(alg)
             for _ in range(2):
