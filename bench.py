@@ -110,15 +110,17 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     dt = time.perf_counter() - t1
     kms, nl = ctx.kernel_times_ms()
     ctx.set_profiling(False)
-    ctx.set_overlap(True)
-    ctx.assemble_device()
-    sync_all()
-    t2 = time.perf_counter()
-    for _ in range(steps):
+    dt_overlap = None
+    if args.overlap_extra:
+        ctx.set_overlap(True)
         ctx.assemble_device()
-    sync_all()
-    dt_overlap = time.perf_counter() - t2
-    ctx.set_overlap(False)
+        sync_all()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            ctx.assemble_device()
+        sync_all()
+        dt_overlap = time.perf_counter() - t2
+        ctx.set_overlap(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,6 +205,10 @@ def main():
     ap.add_argument("--variant", choices=["poisson", "diffusion_reaction", "assemble_dg_matrix"], default="poisson",
                     help="caller variant (penalty / face ownership / reaction term), SURVEY.md 8(a)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary FE measurement")
+    ap.add_argument("--overlap-extra", action="store_true",
+                    help="also time the step with the library's default overlapped launch of its two kernels "
+                         "(roofline.overlapped_ms_per_step); off by default so that a rocprofv3 trace of the default command "
+                         "contains serialised launches only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses device 0 and the gloo backend "
@@ -307,7 +313,7 @@ def main():
                     "algorithm": "moment form (pdh_moment.h): Legendre moments of the quadrature on the f64 MFMA + sum "
                                  "factorisation; VALU / LDS bound, not at the HBM roof yet",
                     "other_kernel": ke[1 - dom],
-                    "overlapped_ms_per_step": 1e3 * r["dt_overlap"] / args.steps,
+                    "overlapped_ms_per_step": None if r["dt_overlap"] is None else 1e3 * r["dt_overlap"] / args.steps,
                     "overlap_note": "library default: the two kernels run concurrently on two streams (pdh_set_overlap); the timed "
                                     "region above serialises them so that kernel_ms are undisturbed per-kernel durations",
                     "whole_step_GBs": (w["bytes"][0] + w["bytes"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-9,
