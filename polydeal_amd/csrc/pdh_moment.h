@@ -11,20 +11,23 @@
 //     M[a0,a1,a2] = sum_q w_q L_a0(x^_0) L_a1(x^_1) L_a2(x^_2)                         ((2p+1)^3 numbers)
 // the block is   A_ij = sum_a X[k0,l0,a0] Y[k1,l1,a1] Z[k2,l2,a2] M[a]   - evaluated by sum factorisation.
 // Face terms use moments weighted by  w sigma  and  -w n_c / 2;  a coupling block A[P,Q] uses tables of the mixed
-// products B^P_k(t) B^Q_l(alpha t + beta) (the two bounding-box frames differ by an axis-aligned affine map), built
+// products B^P_k(xi^P(t)) B^Q_l(xi^Q(t)) (the two bounding-box frames differ by an axis-aligned affine map), built
 // per face on the device by an exact Gauss rule.  Cost per polytope: O(Nq (2p+1)^3) for the moments plus
-// O((p+1)^2d (2p+1)) for the contraction, instead of O(Nq n^2) - for FE_DGQ(3) about 8x fewer operations, all VALU,
-// which moves the headline workload from the f64 MFMA roof to the HBM write roof of the matrix values.
+// O((p+1)^2d (2p+1)) for the contraction, instead of O(Nq n^2) - for FE_DGQ(3) about 8x fewer operations, which moves
+// the headline workload off the f64 MFMA roof towards the HBM write roof of the matrix values.
+// Where the work runs: moment accumulation on the f64 MFMA (a GEMM over the points, struct MomentAcc); contraction
+// stage 1 on the VALU; stages 2 and 3 on the MFMA for FE_DGQ(3) (k_*<4, true>), on the VALU otherwise (k_*<N, false>).
 // Numerics: every expansion is exact for polynomials, so results differ from the direct form by rounding only
-// (1e-14 relative measured; tests/test_gpu_parity.py runs both forms against the oracle).
+// (1e-14 relative measured; tests/test_gpu_parity.py runs both forms against the oracle, tests/test_moment_math.py
+// checks the algebra in NumPy).
 //
 // The statement of WHAT is computed is unchanged (reference include/poly_utils.h:2040-2084, 1870-1926, see
 // pdh_kernels.h); this file only changes the order of summation.
 #pragma once
 #include "pdh_kernels.h"
 
-// experiment switches (tools/ab_bench.py): -DPDHM_EXP=1 no per-face tables, 2 no moment accumulation, 3 no contraction,
-// 4 no stores - coupling kernel only; results are then garbage
+// experiment switches (tools/ab_bench.py; never defined in the shipped build, results are garbage with them):
+// -DPDHM_EXP=1 no per-face tables, 2 no moment accumulation, 3 no contraction, 4 no stores
 #ifndef PDHM_EXP
 #define PDHM_EXP 0
 #endif
@@ -97,19 +100,6 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
     }                                                                                                                \
   while (0)
 
-// acc[a2] += y * r[a2], a2 < NA, r 16-byte aligned with NAP entries (entry NA is zero)
-template <int NA>
-__device__ __forceinline__ void fma_row(double *acc, const double *r, double y)
-{
-  static_for<0, (NA + 1) / 2>([&](auto h_) {
-    constexpr int hh = h_;
-    const d2_t v = *reinterpret_cast<const d2_t *>(r + 2 * hh);
-    acc[2 * hh] += v.x * y;
-    if constexpr (2 * hh + 1 < NA)
-      acc[2 * hh + 1] += v.y * y;
-  });
-}
-
 // sum_a t[a] * r[a]: t in registers (never addressed through a vector pointer: that would pin it to scratch memory),
 // r a 16-byte aligned row in LDS
 template <int NA>
@@ -126,7 +116,7 @@ __device__ __forceinline__ double dot_row(const double *t, const double *r)
   return s;
 }
 
-// Shared tail of both kernels.  T1 holds NT1 arrays [N1D (l2)][NA (a0)][NAP (a1)] for the current slab k2;
+// VALU form of stages 2 and 3 (all elements but FE_DGQ(3)).  T1 holds the stage-1 arrays [N1D][NA (a0)][NAP (a1)] of the current slab;
 // stage 2 for one X-type: T2[(l2,l1,k1)][NAP (a0)] = sum over the listed (Y table, T1 array, scale) terms of
 //   scale * sum_a1 Y[k1,l1,a1] T1[arr][l2][a0][a1]
 template <int N1D>
