@@ -33,6 +33,8 @@ def main():
     for name, path in (("A", a.lib_a), ("B", a.lib_b)):
         c = pa.Context(0, lib_path=os.path.abspath(path))
         c.set_problem(flat)
+        if hasattr(c.lib, "pdh_set_overlap"):
+            c.set_overlap(False)  # per-kernel times of kernels that have the device to themselves
         c.assemble_device()
         c.synchronize()
         ctxs[name] = c
