@@ -102,3 +102,10 @@ def test_config3_3d_p3_32768_polytopes_dgq():
     """BASELINE.json configs[2] with FE_DGQ(3), (p+1)^3 = 64 dofs per polytope: the bench workload itself."""
     n_dofs, nnz = run_identities(3, 64, 2, pa.FE_DGQ(3, 3), 4)
     assert n_dofs == 2097152 and nnz == 914358272
+
+
+def test_3d_p2_32768_polytopes_dgq_mixed_algorithm():
+    """FE_DGQ(2), n = 27 (the element of BASELINE.json configs[3]) at 32 768 polytopes: AUTO takes the moment form for the
+    diagonal blocks and the direct form for the coupling blocks - the identities see both."""
+    n_dofs, nnz = run_identities(3, 64, 2, pa.FE_DGQ(3, 2), 3)
+    assert n_dofs == 884736 and nnz == 27 * 27 * 223232
