@@ -64,21 +64,21 @@ struct MT
                        OFF_BV = OFF_GL + NA * NG /* [N1D][NG] */, OFF_BD = OFF_BV + N1D * NG, SIZE = OFF_BD + N1D * NG;
 };
 
-// L_a(x) = sqrt(2a+1) P_a(2x-1), a = 0 .. NA-1
+// L_a(x) = sqrt(2a+1) P_a(2x-1), a = 0 .. NA-1, by the three-term recurrence of the ORTHONORMAL polynomials
+//   L_{k+1} = A_k t L_k - C_k L_{k-1},  t = 2x-1,  A_k = sqrt((2k+1)(2k+3))/(k+1),  C_k = k/(k+1) sqrt((2k+3)/(2k-1))
+// (three operations per degree; the record phase is VALU time that the f64 MFMA of the same SIMD cannot overlap).
 template <int NA>
 __device__ __forceinline__ void legendre01(double x, double *L)
 {
   const double t = 2.0 * x - 1.0;
-  double pm = 1.0, pc = t;
   L[0] = 1.0;
   if constexpr (NA > 1)
     L[1] = 1.7320508075688772935 * t;
   static_for<1, NA - 1>([&](auto k_) {
     constexpr int k = k_;
-    const double pn = ((2 * k + 1) * t * pc - k * pm) * (1.0 / (k + 1));
-    pm = pc;
-    pc = pn;
-    L[k + 1] = __builtin_sqrt((double)(2 * k + 3)) * pn;
+    const double Ak = __builtin_sqrt((double)((2 * k + 1) * (2 * k + 3))) / (double)(k + 1);
+    const double Ck = (double)k / (double)(k + 1) * __builtin_sqrt((double)(2 * k + 3) / (double)(2 * k - 1));
+    L[k + 1] = Ak * (t * L[k]) - Ck * L[k - 1];
   });
 }
 
@@ -245,11 +245,15 @@ struct MomentAcc
 {
   using M = MT<N1D>;
   static constexpr int NA = M::NA, NAP = M::NAP, ROWS = NA * NA, NFA = (ROWS + 15) / 16, NFB = (NA + 3) / 4;
-  static constexpr int REC = 2 * NA + 4 * NAP + 4; // L0[NA], L1[NA], (s_t L2)[4][NAP], zero pair, pad (bank spread of the 4 points of a step)
+  // record strides are ODD numbers of doubles: the record phase writes one record per lane, and with an even stride
+  // such as 24 doubles (48 dwords) the 64 lanes of a ds_write fall on 4 bank offsets - a 16-way conflict on every write
+  // (the face records keep an even stride: 2-way conflicts only with 32 points per chunk, and one more double per record
+  // would push the coupling kernel over 20 KB of LDS = 7 instead of 8 waves per CU)
+  static constexpr int REC = 2 * NA + 4 * NAP + 4; // L0[NA], L1[NA], (s_t L2)[4][NAP], zero pair, pad
   static constexpr int ZERO = (2 * NA + 4 * NAP) * 8;
   static constexpr int CH = 32; // face points per chunk
   // volume points need one weight only: smaller records, 64 points per chunk (one point per lane in the record phase)
-  static constexpr int VREC = 2 * NA + NAP + 2; // L0[NA], L1[NA], (w L2)[NAP], zero pair
+  static constexpr int VREC = (2 * NA + NAP + 2) | 1; // L0[NA], L1[NA], (w L2)[NAP], zero pair, pad
   static constexpr int VZERO = (2 * NA + NAP) * 8;
   static constexpr int VCH = 64;
   // If the last A fragment holds a single live row (NA^2 = 16 m + 1: 49 pairs for FE_DGQ(3), 25 for p = 2, 9 for p = 1) its
@@ -664,9 +668,19 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
   using Acc = MomentAcc<N1D>;
   Acc ma;
   ma.init(lane);
+  // Point data of a chunk is loaded one chunk ahead (registers) so that the global-load latency sits behind the MFMA
+  // loop of the previous chunk: measured, the record phase of this kernel was 0.53 of its 2.14 ms, mostly waiting.
   // ---- volume moments -----------------------------------------------------------------------------------
   {
     const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
+    double px[DIM] = {0.0, 0.0, 0.0}, pw = 0.0;
+    auto fetch = [&](int64_t base) {
+      const bool on = base + lane < qe;
+      for (int c = 0; c < DIM; ++c)
+        px[c] = on ? P.vq_x[c * P.vq_stride + base + lane] : 0.0;
+      pw = on ? P.vq_w[base + lane] : 0.0;
+    };
+    fetch(qb);
 #if PDHM_EXP == 2
     for (int64_t base = qb; base < qe && P.n < 0; base += Acc::VCH)
 #else
@@ -680,18 +694,46 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
           if (lane < cnt)
             {
               for (int c = 0; c < DIM; ++c)
-                xu[c] = (P.vq_x[c * P.vq_stride + base + lane] - lo[c]) * ih[c];
-              w = P.vq_w[base + lane];
+                xu[c] = (px[c] - lo[c]) * ih[c];
+              w = pw;
             }
+          fetch(base + Acc::VCH);
+#if PDHM_EXP != 5
           Acc::write_volume_record(work + lane * Acc::VREC, xu, w);
+#endif
         }
         __syncthreads();
+#if PDHM_EXP != 6
         ma.volume_chunk(work, cnt, lane);
+#endif
       }
   }
   // ---- moments of the own-side face points (all faces of the polytope, boundary included) ------------------
   {
     const int64_t pb = P.ap_ptr[slot], pe = P.ap_ptr[slot + 1];
+    const int half = lane >> 5, pt = lane & 31;
+    // half 0 needs x0, x1; half 1 needs x2, w, sigma, n0, n1, n2
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0, f4 = 0.0, f5 = 0.0;
+    auto fetch = [&](int64_t base) {
+      const bool on = base + pt < pe;
+      const int64_t q = on ? base + pt : pb;
+      if (half == 0)
+        {
+          f0 = P.ap_x[0 * P.ap_stride + q];
+          f1 = P.ap_x[1 * P.ap_stride + q];
+        }
+      else
+        {
+          f0 = P.ap_x[2 * P.ap_stride + q];
+          f1 = on ? P.ap_wself[q] : 0.0;
+          f2 = P.ap_sig[q];
+          f3 = P.ap_n[0 * P.ap_stride + q];
+          f4 = P.ap_n[1 * P.ap_stride + q];
+          f5 = P.ap_n[2 * P.ap_stride + q];
+        }
+    };
+    if (pb < pe)
+      fetch(pb);
 #if PDHM_EXP == 2
     for (int64_t base = pb; base < pe && P.n < 0; base += Acc::CH)
 #else
@@ -701,29 +743,35 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
         const int cnt = (int)((pe - base < Acc::CH) ? (pe - base) : Acc::CH);
         __syncthreads();
         {
-          const int half = lane >> 5, pt = lane & 31;
           double xa = 0.5, xb = 0.5, s[4] = {0.0, 0.0, 0.0, 0.0};
           if (pt < cnt)
             {
               if (half == 0)
                 {
-                  xa = (P.ap_x[0 * P.ap_stride + base + pt] - lo[0]) * ih[0];
-                  xb = (P.ap_x[1 * P.ap_stride + base + pt] - lo[1]) * ih[1];
+                  xa = (f0 - lo[0]) * ih[0];
+                  xb = (f1 - lo[1]) * ih[1];
                 }
               else
                 {
-                  xa = (P.ap_x[2 * P.ap_stride + base + pt] - lo[2]) * ih[2];
-                  const double w = P.ap_wself[base + pt];
+                  xa = (f0 - lo[2]) * ih[2];
+                  const double w = f1;
                   // U_i phi_j + phi_i U_j  with  U = -1/2 grad phi . n + (sig/2) phi   (pdh_kernels.h, k_diag)
-                  s[0] = w * P.ap_sig[base + pt];
-                  for (int c = 0; c < DIM; ++c)
-                    s[1 + c] = -0.5 * w * P.ap_n[c * P.ap_stride + base + pt];
+                  s[0] = w * f2;
+                  s[1] = -0.5 * w * f3;
+                  s[2] = -0.5 * w * f4;
+                  s[3] = -0.5 * w * f5;
                 }
             }
+          if (base + Acc::CH < pe)
+            fetch(base + Acc::CH);
+#if PDHM_EXP != 5
           Acc::write_face_record_half(work + pt * Acc::REC, half, xa, xb, s);
+#endif
         }
         __syncthreads();
+#if PDHM_EXP != 6
         ma.face_chunk(work, cnt, lane);
+#endif
       }
   }
   // gather: this lane's (a0,a1) row of every moment tensor
