@@ -48,12 +48,22 @@ typedef struct pdh_problem
   int32_t dim;     /* 2 or 3                                                                       */
   int32_t degree;  /* polynomial degree p                                                          */
   int32_t basis;   /* PDH_BASIS_*                                                                  */
-  int32_t n_agg;   /* number of polytopes (agglomerates)                                           */
+  int32_t n_agg;   /* number of polytopes (agglomerates) in this description                       */
   int32_t n_faces; /* polytopal faces; each interior face stored ONCE (in/out), boundary: out = -1 */
-  int32_t n_rows;  /* global number of dofs = n_dofs_per_cell * n_agg                              */
+  int32_t n_rows;  /* GLOBAL number of dofs (= n_dofs_per_cell * n_agg for a global description)   */
   int32_t diag_first; /* 1: deal.II SparsityPattern row layout (diagonal first, then ascending);
                          0: plain ascending columns (Epetra local CSR)                       [A4] */
-  int32_t reserved;
+  int32_t local;   /* 0: GLOBAL description - all polytopes, rowptr [n_rows+1] over all rows.
+                      1: RANK-LOCAL description, what an MPI rank of the reference holds
+                         (source/agglomeration_handler.cc:1026-1091: locally owned polytopes + the ghost
+                         polytopes across its partition boundary, with their bounding boxes and GLOBAL dof
+                         indices).  Polytopes are numbered locally 0..n_agg-1: the owned ones - exactly those
+                         whose dof_offset lies in [row_begin,row_end) - and at least every neighbour of an owned
+                         one.  dof_offset holds GLOBAL dof numbers; ghosts need bbox and dof_offset only (their
+                         volume range may be empty); every face with an owned side must be listed, with the
+                         quadrature data of side 0 as always; faces between two ghosts are ignored.
+                         rowptr has row_end - row_begin + 1 entries (owned rows only, rowptr[0] = 0), colind
+                         - if given - global column numbers of those rows.                              */
   double reaction_c; /* adds c * phi_i phi_j to the volume term (diffusion_reaction.cc:495-501)    */
 
   const double  *bbox;       /* [n_agg][2][dim] lower, upper corner of the bounding box      [A1] */
@@ -72,8 +82,20 @@ typedef struct pdh_problem
   const double  *fq_w_out; /* [Nqf_tot] JxW seen from side 1, or NULL if identical     */
   const double  *face_sigma; /* [n_faces] penalty sigma = C / h_f, resolved per caller variant     */
 
-  const int64_t *rowptr; /* [n_rows+1] target CSR row pointers                                [A4] */
+  const int64_t *rowptr; /* [n_rows+1] (local: [row_end-row_begin+1]) target CSR row pointers    [A4] */
   const int32_t *colind; /* [nnz] target CSR columns, or NULL: canonical DG block pattern assumed  */
+
+  /* Optional (NULL = dof_offset): column number of the first dof of every polytope in the numbering that ORDERS the
+   * entries of a row.  An Epetra_CrsMatrix row is sorted by LOCAL column id, and the column map lists the owned
+   * columns first and the ghost columns after them, so on rank > 0 a ghost block with a smaller global number sits
+   * BEHIND the owned blocks of the row (TrilinosWrappers::SparseMatrix, reference examples/diffusion_reaction.cc:
+   * 448-466).  With col_offset = local column ids the values come out in exactly that order (colind, if given, is
+   * then checked against these numbers).  Requires diag_first = 0.                                              */
+  const int32_t *col_offset;
+  /* Optional: owning rank of every polytope (the calling rank's own number for the owned ones).  Needed only by the
+   * ghost-block exchange variant (pdh_set_exchange_mode), which ships the M21/M22 blocks of the faces cut by the
+   * partition to the rank that owns their rows (reference include/poly_utils.h:1930-1992, 2134-2194).             */
+  const int32_t *agg_rank;
 } pdh_problem;
 
 /* Lifetime -------------------------------------------------------------------------------------- */
@@ -86,6 +108,8 @@ const char *pdh_last_error(const pdh_ctx *ctx); /* valid until the next call on 
  * distribute_agglomerated_dofs / initialize_fe_values (agglomeration_handler.cc:210-236, 326-379).
  * [row_begin,row_end) selects the dof rows this context owns (multi-GPU: one contiguous range per
  * rank, whole polytopes only, like the reference asserts at agglomeration_handler.cc:83-87).     */
+/* With problem->local = 1 the description itself is rank-local (owned + ghost polytopes, global dof numbers): a
+ * rank never needs the global mesh.  With local = 0 every rank passes the same global description and its range. */
 int pdh_set_problem(pdh_ctx *ctx, const pdh_problem *problem);
 int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *problem, int32_t row_begin, int32_t row_end);
 

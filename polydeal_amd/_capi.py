@@ -28,7 +28,7 @@ class PdhError(RuntimeError):
 class pdh_problem(C.Structure):
     _fields_ = [
         ("dim", C.c_int32), ("degree", C.c_int32), ("basis", C.c_int32), ("n_agg", C.c_int32),
-        ("n_faces", C.c_int32), ("n_rows", C.c_int32), ("diag_first", C.c_int32), ("reserved", C.c_int32),
+        ("n_faces", C.c_int32), ("n_rows", C.c_int32), ("diag_first", C.c_int32), ("local", C.c_int32),
         ("reaction_c", C.c_double),
         ("bbox", C.c_void_p), ("dof_offset", C.c_void_p),
         ("vq_ptr", C.c_void_p), ("vq_x", C.c_void_p), ("vq_w", C.c_void_p),
@@ -36,6 +36,7 @@ class pdh_problem(C.Structure):
         ("fq_x", C.c_void_p), ("fq_n", C.c_void_p), ("fq_w", C.c_void_p), ("fq_w_out", C.c_void_p),
         ("face_sigma", C.c_void_p),
         ("rowptr", C.c_void_p), ("colind", C.c_void_p),
+        ("col_offset", C.c_void_p), ("agg_rank", C.c_void_p),
     ]
 
 
@@ -101,18 +102,19 @@ _DTYPES = {
     "bbox": np.float64, "dof_offset": np.int32, "vq_ptr": np.int64, "vq_x": np.float64, "vq_w": np.float64,
     "face_in": np.int32, "face_out": np.int32, "fq_ptr": np.int64, "fq_x": np.float64, "fq_n": np.float64,
     "fq_w": np.float64, "fq_w_out": np.float64, "face_sigma": np.float64, "rowptr": np.int64, "colind": np.int32,
+    "col_offset": np.int32, "agg_rank": np.int32,
 }
 
 
 class Problem:
     """Owns the NumPy arrays behind a pdh_problem (keeps them alive while the struct is in use)."""
 
-    def __init__(self, *, dim, degree, basis, n_agg, n_faces, n_rows, diag_first=1, reaction_c=0.0, **arrays):
+    def __init__(self, *, dim, degree, basis, n_agg, n_faces, n_rows, diag_first=1, reaction_c=0.0, local=0, **arrays):
         self.arrays = {}
         self.c = pdh_problem()
         self.c.dim, self.c.degree, self.c.basis = dim, degree, basis
         self.c.n_agg, self.c.n_faces, self.c.n_rows = n_agg, n_faces, n_rows
-        self.c.diag_first, self.c.reaction_c = int(diag_first), float(reaction_c)
+        self.c.diag_first, self.c.reaction_c, self.c.local = int(diag_first), float(reaction_c), int(local)
         for name, dt in _DTYPES.items():
             a = arrays.get(name)
             if a is None:

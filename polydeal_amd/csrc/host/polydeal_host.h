@@ -448,7 +448,7 @@ struct FlatProblem
 {
   pdh_problem c{};
   std::vector<double> bbox, vq_x, vq_w, fq_x, fq_n, fq_w, fq_w_out, face_sigma;
-  std::vector<int32_t> dof_offset, face_in, face_out, colind;
+  std::vector<int32_t> dof_offset, face_in, face_out, colind, col_offset, agg_rank;
   std::vector<int64_t> vq_ptr, fq_ptr, rowptr;
   void bind()
   {
@@ -467,6 +467,8 @@ struct FlatProblem
     c.face_sigma = face_sigma.data();
     c.rowptr = rowptr.data();
     c.colind = colind.empty() ? nullptr : colind.data();
+    c.col_offset = col_offset.empty() ? nullptr : col_offset.data();
+    c.agg_rank = agg_rank.empty() ? nullptr : agg_rank.data();
   }
 };
 
@@ -755,6 +757,195 @@ public:
           F.fq_n[c * nft + q] = fin.n[q * dim + c];
         }
     create_agglomeration_sparsity_pattern(F.rowptr, with_colind ? &F.colind : nullptr, diag_first);
+    F.bind();
+  }
+
+  // Rank-local description (pdh_problem::local = 1) of the dof rows [row_begin,row_end): what one MPI rank of the
+  // reference holds after setup_ghost_polytopes / the ghost exchanges (source/agglomeration_handler.cc:1026-1091,
+  // 531-618) - its own polytopes plus the ghost polytopes across the partition boundary with their bounding boxes
+  // and GLOBAL dof indices (recv_ghosted_bbox / recv_ghost_dofs, :1081-1090).  Local numbering: owned polytopes first
+  // (polytope order), then the ghosts in order of first contact.  Volume quadrature for the owned ones only; every face
+  // with an owned side, described from its owner side exactly as in flatten().  rowptr / colind cover the owned rows
+  // only (colind holds global columns); `local_of` (optional) receives the global polytope index of every local one.
+  // epetra_columns: col_offset = local column ids of an Epetra column map (owned columns first, ghosts behind in
+  // ascending global order) and rows sorted by them - the layout of TrilinosWrappers::SparseMatrix; needs !diag_first.
+  void flatten_local(const SipVariant &var, FlatProblem &F, int row_begin, int row_end, bool diag_first = true,
+                     bool with_colind = false, std::vector<int> *local_of = nullptr,
+                     const std::vector<int> *row_splits = nullptr, bool epetra_columns = false) const
+  {
+    if (!connectivity_ready)
+      throw std::logic_error("distribute_agglomerated_dofs must be called first");
+    if (nq <= 0 || nqf <= 0)
+      throw std::logic_error("initialize_fe_values must be called first");
+    if (epetra_columns && diag_first)
+      throw std::invalid_argument("Epetra column order needs the ascending row layout");
+    const int dim = tria->dim, nA = (int)master_cells.size(), n = fe.n_dofs_per_cell();
+    auto owned = [&](int P) { return dof_offset[P] >= row_begin && dof_offset[P] < row_end; };
+    std::vector<int> loc(nA, -1), glob;
+    for (int P = 0; P < nA; ++P)
+      if (owned(P))
+        {
+          loc[P] = (int)glob.size();
+          glob.push_back(P);
+        }
+    const int n_owned = (int)glob.size();
+    if ((int64_t)n_owned * n != (int64_t)row_end - row_begin)
+      throw std::invalid_argument("row range must consist of whole polytopes");
+    for (int i = 0; i < n_owned; ++i)
+      for (int Q : face_nbr[glob[i]])
+        if (Q != invalid_index && loc[Q] < 0)
+          {
+            loc[Q] = (int)glob.size();
+            glob.push_back(Q);
+          }
+    const int nL = (int)glob.size();
+    F = FlatProblem();
+    F.c.dim = dim;
+    F.c.degree = fe.degree;
+    F.c.basis = fe.basis;
+    F.c.n_agg = nL;
+    F.c.n_rows = (int32_t)n_dofs_;
+    F.c.diag_first = diag_first ? 1 : 0;
+    F.c.local = 1;
+    F.c.reaction_c = var.reaction_c;
+    F.bbox.resize((size_t)nL * 2 * dim);
+    F.dof_offset.resize(nL);
+    F.vq_ptr.assign(1, 0);
+    QPoints vol;
+    for (int l = 0; l < nL; ++l)
+      {
+        const int P = glob[l];
+        for (int c = 0; c < dim; ++c)
+          {
+            F.bbox[(size_t)l * 2 * dim + c] = bboxes[P][c];
+            F.bbox[(size_t)l * 2 * dim + dim + c] = bboxes[P][3 + c];
+          }
+        F.dof_offset[l] = dof_offset[P];
+        if (l < n_owned)
+          agglomerated_quadrature(P, vol);
+        F.vq_ptr.push_back((int64_t)vol.w.size());
+      }
+    const size_t nqt = vol.w.size();
+    F.vq_w = std::move(vol.w);
+    F.vq_x.resize(nqt * dim);
+    for (size_t q = 0; q < nqt; ++q)
+      for (int c = 0; c < dim; ++c)
+        F.vq_x[c * nqt + q] = vol.x[q * dim + c];
+    vol = QPoints();
+
+    QPoints fin, fout;
+    F.fq_ptr.assign(1, 0);
+    for (int i = 0; i < n_owned; ++i)
+      {
+        const int P = glob[i];
+        for (unsigned f = 0; f < n_faces(P); ++f)
+          {
+            if (at_boundary(P, f))
+              {
+                if (var.boundary == 1)
+                  continue;
+                const size_t before = fin.w.size();
+                face_quadrature_of(P, f, fin);
+                fout.w.insert(fout.w.end(), fin.w.begin() + before, fin.w.end());
+                F.face_in.push_back(i);
+                F.face_out.push_back(-1);
+                F.face_sigma.push_back(sigma(var, P, invalid_index));
+              }
+            else
+              {
+                const int Q = neighbor(P, f);
+                const bool p_owns = owns(var, P, Q);
+                if (!p_owns && owned(Q))
+                  continue; // listed when Q's faces are walked
+                // the face is described from its owner side I (normal, JxW_0, sigma as the reference's owner sees them)
+                const int I = p_owns ? P : Q, O = p_owns ? Q : P;
+                const unsigned fI = p_owns ? f : (unsigned)neighbor_of_agglomerated_neighbor(P, f);
+                const int fO = neighbor_of_agglomerated_neighbor(I, fI);
+                face_quadrature_of(I, fI, fin);
+                QPoints tmp;
+                face_quadrature_of(O, (unsigned)fO, tmp);
+                if (fout.w.size() + tmp.w.size() != fin.w.size())
+                  throw std::logic_error("interface lists of the two sides differ in length");
+                fout.w.insert(fout.w.end(), tmp.w.begin(), tmp.w.end());
+                F.face_in.push_back(loc[I]);
+                F.face_out.push_back(loc[O]);
+                F.face_sigma.push_back(sigma(var, I, O));
+              }
+            F.fq_ptr.push_back((int64_t)fin.w.size());
+          }
+      }
+    F.c.n_faces = (int32_t)F.face_in.size();
+    const size_t nft = fin.w.size();
+    F.fq_w = std::move(fin.w);
+    F.fq_w_out = std::move(fout.w);
+    F.fq_x.resize(nft * dim);
+    F.fq_n.resize(nft * dim);
+    for (size_t q = 0; q < nft; ++q)
+      for (int c = 0; c < dim; ++c)
+        {
+          F.fq_x[c * nft + q] = fin.x[q * dim + c];
+          F.fq_n[c * nft + q] = fin.n[q * dim + c];
+        }
+    // column numbering that orders a row
+    std::vector<int> colnum(nL);
+    for (int l = 0; l < nL; ++l)
+      colnum[l] = F.dof_offset[l];
+    if (epetra_columns)
+      {
+        std::vector<int> gh(glob.begin() + n_owned, glob.end());
+        std::sort(gh.begin(), gh.end(), [&](int a, int b) { return dof_offset[a] < dof_offset[b]; });
+        for (int l = 0; l < n_owned; ++l)
+          colnum[l] = dof_offset[glob[l]] - row_begin;
+        for (size_t g = 0; g < gh.size(); ++g)
+          colnum[loc[gh[g]]] = (row_end - row_begin) + (int)g * n;
+        F.col_offset.assign(colnum.begin(), colnum.end());
+      }
+    // pattern of the owned rows (create_agglomeration_sparsity_pattern restricted to locally_owned_dofs, :933-935)
+    const int nrow = row_end - row_begin;
+    F.rowptr.assign((size_t)nrow + 1, 0);
+    std::vector<std::vector<int>> blocks(n_owned);
+    for (int i = 0; i < n_owned; ++i)
+      {
+        const int P = glob[i];
+        auto &b = blocks[i];
+        b.push_back(i);
+        for (int Q : face_nbr[P])
+          if (Q != invalid_index)
+            b.push_back(loc[Q]);
+        std::sort(b.begin(), b.end(), [&](int x, int y) { return colnum[x] < colnum[y]; });
+        for (int r = 0; r < n; ++r)
+          F.rowptr[(size_t)(dof_offset[P] - row_begin) + r + 1] = (int64_t)b.size() * n;
+      }
+    for (int r = 0; r < nrow; ++r)
+      F.rowptr[r + 1] += F.rowptr[r];
+    if (with_colind)
+      {
+        F.colind.resize((size_t)F.rowptr[nrow]);
+        for (int i = 0; i < n_owned; ++i)
+          for (int r = 0; r < n; ++r)
+            {
+              const int row = dof_offset[glob[i]] + r;
+              int32_t *out = F.colind.data() + F.rowptr[row - row_begin];
+              const int own_col = colnum[i] + r;
+              if (diag_first)
+                *out++ = own_col;
+              for (int l : blocks[i])
+                for (int j = 0; j < n; ++j)
+                  if (!(diag_first && colnum[l] + j == own_col))
+                    *out++ = colnum[l] + j;
+            }
+      }
+    if (row_splits)
+      { // owning rank of every polytope: row_splits[r] <= dof_offset < row_splits[r+1]
+        F.agg_rank.resize(nL);
+        for (int l = 0; l < nL; ++l)
+          {
+            const auto it = std::upper_bound(row_splits->begin(), row_splits->end(), F.dof_offset[l]);
+            F.agg_rank[l] = (int)(it - row_splits->begin()) - 1;
+          }
+      }
+    if (local_of)
+      *local_of = glob;
     F.bind();
   }
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -197,9 +198,9 @@ extern "C" int pdh_create(pdh_ctx **out, int device_id)
                   "); this library has no CPU fallback");
   if (device_id < 0 || device_id >= ndev)
     return fail(nullptr, PDH_EINVAL, "pdh_create: device_id out of range");
+  PDH_HIP(nullptr, hipSetDevice(device_id));
   pdh_ctx *ctx = new pdh_ctx;
   ctx->device = device_id;
-  PDH_HIP(nullptr, hipSetDevice(device_id));
   if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
@@ -273,10 +274,19 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
   const int n = pdh::n_dofs_per_cell(dim, p->degree, p->basis);
   if (n > 64)
     return fail(ctx, PDH_EUNSUPPORTED, "more than 64 dofs per polytope are not supported by this build");
-  if ((int64_t)n * p->n_agg != p->n_rows)
-    return fail(ctx, PDH_EINVAL, "n_rows != dofs_per_cell * n_agg");
+  const bool local = p->local != 0;
+  if (!local && (int64_t)n * p->n_agg != p->n_rows)
+    return fail(ctx, PDH_EINVAL, "n_rows != dofs_per_cell * n_agg (global description)");
+  if (p->n_rows <= 0 || p->n_rows % n)
+    return fail(ctx, PDH_EINVAL, "n_rows must be a positive multiple of dofs_per_cell");
   if (row_begin < 0 || row_end > p->n_rows || row_begin > row_end || row_begin % n || row_end % n)
     return fail(ctx, PDH_EINVAL, "owned row range must be aligned to whole polytopes");
+  if (p->col_offset && p->diag_first)
+    return fail(ctx, PDH_EINVAL, "col_offset (Epetra column order) requires diag_first = 0");
+  // rowptr covers all rows (global description) or the owned rows only (rank-local description)
+  const int64_t rp_shift = local ? (int64_t)row_begin : 0;
+  if (p->rowptr[0] != 0)
+    return fail(ctx, PDH_EINVAL, "rowptr[0] must be 0");
   K.n = n;
   K.n1d = p->degree + 1;
   const int T = (n + 3) / 4;
@@ -297,11 +307,21 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
     K.midx[i] = (int32_t)mi[i];
 
   const int nA = p->n_agg, nF = p->n_faces;
+  // number that orders the blocks of a row: the global dof number, or the caller's column numbering (Epetra local ids)
+  auto colnum = [&](int a) { return p->col_offset ? p->col_offset[a] : p->dof_offset[a]; };
+  auto owned = [&](int a) { return p->dof_offset[a] >= row_begin && p->dof_offset[a] < row_end; };
+  if (p->vq_ptr[0] != 0 || (nF > 0 && p->fq_ptr[0] != 0))
+    return fail(ctx, PDH_EINVAL, "vq_ptr[0] and fq_ptr[0] must be 0");
   for (int a = 0; a < nA; ++a)
     {
       const int off = p->dof_offset[a];
       if (off < 0 || off % n || off + n > p->n_rows)
         return fail(ctx, PDH_EINVAL, "dof_offset must be a multiple of dofs_per_cell inside [0,n_rows)");
+      if (p->col_offset && (p->col_offset[a] < 0 || p->col_offset[a] % n))
+        return fail(ctx, PDH_EINVAL, "col_offset must be a non-negative multiple of dofs_per_cell");
+      for (int c = 0; c < 2 * dim; ++c)
+        if (!std::isfinite(p->bbox[(size_t)a * 2 * dim + c]))
+          return fail(ctx, PDH_EINVAL, "bounding box is not finite");
       if (p->vq_ptr[a + 1] < p->vq_ptr[a])
         return fail(ctx, PDH_EINVAL, "vq_ptr must be non-decreasing");
       for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q)
@@ -318,6 +338,8 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
       const int in = p->face_in[f], out = p->face_out[f];
       if (in < 0 || in >= nA || out < -1 || out >= nA || out == in)
         return fail(ctx, PDH_EINVAL, "face_in/face_out out of range");
+      if (!std::isfinite(p->face_sigma[f]))
+        return fail(ctx, PDH_EINVAL, "face_sigma is not finite");
       if (p->fq_ptr[f + 1] < p->fq_ptr[f])
         return fail(ctx, PDH_EINVAL, "fq_ptr must be non-decreasing");
       for (int64_t q = p->fq_ptr[f]; q < p->fq_ptr[f + 1]; ++q)
@@ -342,8 +364,8 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
 
   const int64_t nq_tot = p->vq_ptr[nA];
   const int64_t nqf_tot = nF ? p->fq_ptr[nF] : 0;
-  const int64_t val_base = p->rowptr[row_begin];
-  K.n_values = p->rowptr[row_end] - val_base;
+  const int64_t val_base = p->rowptr[row_begin - rp_shift];
+  K.n_values = p->rowptr[row_end - rp_shift] - val_base;
 
   // owned polytopes in polytope order
   K.vq_ptr.push_back(0);
@@ -357,26 +379,28 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
       const int slot = (int)K.own_agg.size();
       K.own_agg.push_back(a);
       K.own_row.push_back(off - row_begin);
-      // coupled blocks, ascending by dof offset (reference :954-975)
+      // coupled blocks, ascending by column number (reference :954-975)
+      const int ocol = colnum(a);
       blocks.clear();
-      blocks.emplace_back(off, a);
+      blocks.emplace_back(ocol, a);
       for (int64_t t = fptr[a]; t < fptr[a + 1]; ++t)
         {
           const int f = flist[t];
           const int other = (p->face_in[f] == a) ? p->face_out[f] : p->face_in[f];
           if (other >= 0)
-            blocks.emplace_back(p->dof_offset[other], other);
+            blocks.emplace_back(colnum(other), other);
         }
       std::sort(blocks.begin(), blocks.end());
       for (size_t t = 1; t < blocks.size(); ++t)
         if (blocks[t].first == blocks[t - 1].first)
           return fail(ctx, PDH_EINVAL, "two faces couple the same pair of polytopes (faces must be merged per neighbour)");
-      const int64_t r0 = p->rowptr[off];
-      const int64_t rl = p->rowptr[off + 1] - r0;
+      const int64_t *rp = p->rowptr + (off - rp_shift);
+      const int64_t r0 = rp[0];
+      const int64_t rl = rp[1] - r0;
       if (rl != (int64_t)blocks.size() * n)
         return fail(ctx, PDH_EINVAL, "row length does not match (1 + #neighbours) * dofs_per_cell for polytope " + std::to_string(a));
       for (int i = 1; i < n; ++i)
-        if (p->rowptr[off + i + 1] - p->rowptr[off + i] != rl)
+        if (rp[i + 1] - rp[i] != rl)
           return fail(ctx, PDH_EINVAL, "rows of one polytope must have equal length");
       K.row_base.push_back(r0 - val_base);
       K.row_len.push_back((int32_t)rl);
@@ -386,18 +410,24 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           own_rank = (int)t;
       K.diag_L.push_back(own_rank * n);
       if (p->colind)
-        { // verify the first row of the polytope against the canonical layout
-          const int32_t *ci = p->colind + r0;
-          for (size_t t = 0; t < blocks.size(); ++t)
-            for (int j = 0; j < n; j += (n > 1 ? n - 1 : 1))
-              {
-                const int col = blocks[t].first + j;
-                int64_t pos = (int64_t)t * n + j;
-                if (p->diag_first)
-                  pos = (col == off) ? 0 : (col < off ? pos + 1 : pos);
-                if (ci[pos] != col)
-                  return fail(ctx, PDH_EINVAL, "colind does not have the DG block layout expected for polytope " + std::to_string(a));
-              }
+        { // verify EVERY row of the polytope against the positions the kernels write to (each row carries its own
+          // diagonal-first shift); O(nnz) host work, once per problem
+          for (int i = 0; i < n; ++i)
+            {
+              const int32_t *ci = p->colind + r0 + (int64_t)i * rl;
+              const int dcol = ocol + i;
+              for (size_t t = 0; t < blocks.size(); ++t)
+                for (int j = 0; j < n; ++j)
+                  {
+                    const int col = blocks[t].first + j;
+                    int64_t pos = (int64_t)t * n + j;
+                    if (p->diag_first)
+                      pos = (col == dcol) ? 0 : (col < dcol ? pos + 1 : pos);
+                    if (ci[pos] != col)
+                      return fail(ctx, PDH_EINVAL, "colind does not have the DG block layout expected for polytope " +
+                                                     std::to_string(a) + " (row " + std::to_string(off + i) + ")");
+                  }
+            }
         }
       // volume points
       K.vq_src.push_back(p->vq_ptr[a]);
@@ -418,8 +448,8 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           K.run_bdry.push_back(other < 0 ? 1 : 0);
           if (other >= 0)
             {
-              const int ooff = p->dof_offset[other];
-              const bool other_owned = (ooff >= row_begin && ooff < row_end);
+              const int ooff = colnum(other);
+              const bool other_owned = owned(other);
               // one item per interior face: the owned side with the lower polytope id computes A[P,Q]
               // and also writes A[Q,P] = A[P,Q]^T when Q's rows are owned here too
               if (!other_owned || a < other)
@@ -433,7 +463,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
                     if (blocks[u].second == other)
                       rank = u;
                   int pos = (int)rank * n;
-                  if (p->diag_first && ooff < off)
+                  if (p->diag_first && ooff < ocol)
                     pos += 1;
                   K.it_pos.push_back(pos);
                   K.it_nbr_slot.push_back(other_owned ? other : -1); // polytope id for now, slot resolved below
@@ -473,14 +503,14 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
         if (q < 0)
           continue;
         const int pa = K.own_agg[K.it_own[it]];
-        const int poff = p->dof_offset[pa], qoff = p->dof_offset[q];
-        // rank of P's block among Q's coupled blocks = number of Q's blocks with a smaller dof offset
+        const int poff = colnum(pa), qoff = colnum(q);
+        // rank of P's block among Q's coupled blocks = number of Q's blocks with a smaller column number
         int rank = (qoff < poff) ? 1 : 0;
         for (int64_t t = fptr[q]; t < fptr[q + 1]; ++t)
           {
             const int f = flist[t];
             const int o = (p->face_in[f] == q) ? p->face_out[f] : p->face_in[f];
-            if (o >= 0 && o != pa && p->dof_offset[o] < poff)
+            if (o >= 0 && o != pa && colnum(o) < poff)
               ++rank;
           }
         int pos = rank * n;
@@ -640,12 +670,18 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   if (p->dim == 3 && K.n1d >= 2 && K.n1d <= 4)
     {
       const std::vector<double> mt = pdh::moment_tables(p->degree, p->basis);
-      if ((int)mt.size() != pdh_moment_table_doubles(K.n1d))
-        return fail(ctx, PDH_EDEVICE, "moment table size mismatch");
       void *dm = nullptr;
-      PDH_HIP(ctx, hipMalloc(&dm, mt.size() * sizeof(double)));
-      ctx->allocs.push_back(dm);
-      PDH_HIP(ctx, hipMemcpy(dm, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice));
+      hipError_t em = (int)mt.size() == pdh_moment_table_doubles(K.n1d) ? hipMalloc(&dm, mt.size() * sizeof(double)) : hipErrorInvalidValue;
+      if (em == hipSuccess)
+        {
+          ctx->allocs.push_back(dm);
+          em = hipMemcpy(dm, mt.data(), mt.size() * sizeof(double), hipMemcpyHostToDevice);
+        }
+      if (em != hipSuccess)
+        {
+          free_problem(ctx);
+          return fail(ctx, PDH_EDEVICE, std::string("moment tables: ") + hipGetErrorString(em));
+        }
       ctx->d_mtab = static_cast<double *>(dm);
     }
   ctx->has_problem = true;

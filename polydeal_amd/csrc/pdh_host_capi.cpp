@@ -23,7 +23,13 @@ struct HandlerH
     : ah(g)
   {}
   AgglomerationHandler ah;
+};
+// A flattened problem owns its arrays independently of the handler it came from: a second flatten() of the same
+// handler (another variant / layout / row range) must not invalidate views onto an earlier one.
+struct FlatH
+{
   FlatProblem flat;
+  std::vector<int> local_of; // rank-local descriptions: global polytope index of every local polytope
 };
 template <class F>
 int guarded(F &&f)
@@ -230,9 +236,9 @@ int64_t pdhh_sparsity(void *h, int diag_first, int64_t *rowptr, int32_t *colind)
     }
 }
 
-// Flatten into a pdh_problem owned by the handle (valid until the next flatten / destroy).
-const pdh_problem *pdhh_flatten(void *h, double penalty_constant, int owner_rule, int h_rule, int boundary,
-                                double reaction_c, int diag_first, int with_colind)
+// Flatten into a new, independently owned problem description; free it with pdhh_flat_destroy.
+void *pdhh_flatten(void *h, double penalty_constant, int owner_rule, int h_rule, int boundary, double reaction_c,
+                   int diag_first, int with_colind)
 {
   try
     {
@@ -242,9 +248,9 @@ const pdh_problem *pdhh_flatten(void *h, double penalty_constant, int owner_rule
       v.h_rule = h_rule;
       v.boundary = boundary;
       v.reaction_c = reaction_c;
-      HandlerH *H = static_cast<HandlerH *>(h);
-      H->ah.flatten(v, H->flat, diag_first != 0, with_colind != 0);
-      return &H->flat.c;
+      std::unique_ptr<FlatH> F(new FlatH);
+      AH.flatten(v, F->flat, diag_first != 0, with_colind != 0);
+      return F.release();
     }
   catch (const std::exception &e)
     {
@@ -252,14 +258,52 @@ const pdh_problem *pdhh_flatten(void *h, double penalty_constant, int owner_rule
       return nullptr;
     }
 }
-int64_t pdhh_flat_sizes(void *h, int64_t *out /*[4]: Nq_tot, Nqf_tot, nnz, n_faces*/)
+// Rank-local description of the dof rows [row_begin,row_end) (pdh_problem::local = 1).  row_splits (may be NULL):
+// [n_ranks+1] first row of every rank, fills agg_rank; epetra_columns: col_offset = Epetra local column ids.
+void *pdhh_flatten_local(void *h, double penalty_constant, int owner_rule, int h_rule, int boundary, double reaction_c,
+                         int diag_first, int with_colind, int row_begin, int row_end, const int32_t *row_splits, int n_ranks,
+                         int epetra_columns)
 {
-  HandlerH *H = static_cast<HandlerH *>(h);
+  try
+    {
+      SipVariant v;
+      v.penalty_constant = penalty_constant;
+      v.owner_rule = owner_rule;
+      v.h_rule = h_rule;
+      v.boundary = boundary;
+      v.reaction_c = reaction_c;
+      std::unique_ptr<FlatH> F(new FlatH);
+      std::vector<int> splits;
+      if (row_splits)
+        splits.assign(row_splits, row_splits + n_ranks + 1);
+      AH.flatten_local(v, F->flat, row_begin, row_end, diag_first != 0, with_colind != 0, &F->local_of,
+                       row_splits ? &splits : nullptr, epetra_columns != 0);
+      return F.release();
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return nullptr;
+    }
+}
+const pdh_problem *pdhh_flat_problem(void *fh) { return &static_cast<FlatH *>(fh)->flat.c; }
+void pdhh_flat_destroy(void *fh) { delete static_cast<FlatH *>(fh); }
+int64_t pdhh_flat_sizes(void *fh, int64_t *out /*[4]: Nq_tot, Nqf_tot, nnz, n_faces*/)
+{
+  FlatH *H = static_cast<FlatH *>(fh);
   out[0] = (int64_t)H->flat.vq_w.size();
   out[1] = (int64_t)H->flat.fq_w.size();
   out[2] = H->flat.rowptr.empty() ? 0 : H->flat.rowptr.back();
   out[3] = (int64_t)H->flat.face_in.size();
   return 0;
+}
+// global polytope index of every local polytope of a rank-local description (n_agg entries); 0 for global ones
+int pdhh_flat_local_of(void *fh, int32_t *out)
+{
+  FlatH *H = static_cast<FlatH *>(fh);
+  for (size_t i = 0; i < H->local_of.size(); ++i)
+    out[i] = H->local_of[i];
+  return (int)H->local_of.size();
 }
 
 // PolyUtilsHIP::assemble_dg_matrix through C: values must hold nnz doubles.

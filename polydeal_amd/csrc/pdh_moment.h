@@ -31,6 +31,9 @@
 #ifndef PDHM_EXP
 #define PDHM_EXP 0
 #endif
+#ifndef PDHM_OFF_FULL
+#define PDHM_OFF_FULL 0
+#endif
 #if PDHM_EXP == 4
 #define PDHM_STORE_OK (P.n < 0)
 #else
@@ -342,6 +345,200 @@ struct MomentAcc
         r[2 * NA + 4 * NAP] = 0.0;
         r[2 * NA + 4 * NAP + 1] = 0.0;
       }
+  }
+  // ---- full chunks: software-pipelined, fully unrolled step loops ------------------------------------------------------
+  // hipcc turns the prefetching loops below (volume_chunk / face_chunk) back into "load, wait, multiply, MFMA" with ten
+  // address computations per step (measured r02: the MFMA pipe of k_mdiag was busy 45 % of the time, 43 % of the wave
+  // cycles were issue stalls).  For full chunks every operand address is  per-lane base + compile-time step offset, so
+  // the bases are computed once per kernel and the reads are written as `ds_read_b64 ... offset:imm` in inline asm, one
+  // step ahead of the MFMAs that consume them; sched_barriers keep the compiler from undoing the order.  The rotated B
+  // operands come straight from LDS as well (an LDS read overlaps with the f64 MFMA, a DPP move does not).
+  unsigned adA0v[NFAM], adA1v[NFAM], adYv, adBv[2];     // volume records
+  unsigned adA0[NFAM], adA1[NFAM], adY, adB[NFB][4];    // face records
+  static constexpr int VSTEP = 4 * VREC * 8, FSTEP = 4 * REC * 8; // bytes per 4-point step
+  static_assert(VSTEP * (VCH / 4) < 65536 && FSTEP * (CH / 4) < 65536, "ds_read immediate offsets");
+  __device__ __forceinline__ void init_addr(const double *rec, int lane)
+  {
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    const unsigned base = (unsigned)(uintptr_t)(lds_cchar *)reinterpret_cast<const char *>(rec);
+    const int kq = lane >> 4, blk = (lane >> 2) & 3, idx = lane & 3;
+    const unsigned bv = base + kq * VREC * 8, bf = base + kq * REC * 8;
+    static_for<0, NFAM>([&](auto a_) {
+      constexpr int a = a_;
+      adA0v[a] = bv + offA0v[a];
+      adA1v[a] = bv + offA1v[a];
+      adA0[a] = bf + offA0[a];
+      adA1[a] = bf + offA1[a];
+    });
+    adYv = bv + offY0v;
+    adY = bf + offY0;
+    static_for<0, 2>([&](auto r_) {
+      constexpr int r = r_;
+      const int a2 = 4 * ((blk + r) & 1) + idx;
+      adBv[r] = bv + (a2 < NA ? (2 * NA + a2) * 8 : VZERO);
+    });
+    static_for<0, NFB>([&](auto b_) {
+      constexpr int b = b_;
+      static_for<0, 4>([&](auto r_) {
+        constexpr int r = r_;
+        const int a2 = 4 * b + ((blk + r) & 3);
+        adB[b][r] = bf + (a2 < NA ? (2 * NA + idx * NAP + a2) * 8 : ZERO);
+      });
+    });
+  }
+  template <int IMM>
+  static __device__ __forceinline__ void lds_read(double &dst, unsigned addr)
+  {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM));
+  }
+  struct VBuf
+  {
+    double r0[NFAM], r1[NFAM], y0, y1, b0, b1;
+  };
+  struct FBuf
+  {
+    double r0[NFAM], r1[NFAM], y0, y1, b[NFB][4];
+  };
+  template <int STEP>
+  __device__ __forceinline__ void vload(VBuf &v) const
+  {
+    constexpr int imm = STEP * VSTEP;
+    static_for<0, NFAM>([&](auto a_) {
+      constexpr int a = a_;
+      lds_read<imm>(v.r0[a], adA0v[a]);
+      lds_read<imm>(v.r1[a], adA1v[a]);
+    });
+    if constexpr (LAST_ROW)
+      {
+        lds_read<imm>(v.y0, adYv);
+        lds_read<imm + NA * 8>(v.y1, adYv);
+      }
+    lds_read<imm>(v.b0, adBv[0]);
+    lds_read<imm>(v.b1, adBv[1]);
+  }
+  template <int STEP>
+  __device__ __forceinline__ void fload(FBuf &v) const
+  {
+    constexpr int imm = STEP * FSTEP;
+    static_for<0, NFAM>([&](auto a_) {
+      constexpr int a = a_;
+      lds_read<imm>(v.r0[a], adA0[a]);
+      lds_read<imm>(v.r1[a], adA1[a]);
+    });
+    if constexpr (LAST_ROW)
+      {
+        lds_read<imm>(v.y0, adY);
+        lds_read<imm + NA * 8>(v.y1, adY);
+      }
+    static_for<0, NFB>([&](auto b_) {
+      constexpr int b = b_;
+      static_for<0, 4>([&](auto r_) {
+        constexpr int r = r_;
+        lds_read<imm>(v.b[b][r], adB[b][r]);
+      });
+    });
+  }
+  // s_waitcnt lgkmcnt(0) that the consumers of the buffer depend on (the compiler does not track the asm reads)
+  static __device__ __forceinline__ void vwait(VBuf &v)
+  {
+    static_assert(NFAM <= 3, "operand list written for at most three regular A fragments");
+    if constexpr (NFAM == 3)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(v.r0[0]), "+v"(v.r1[0]), "+v"(v.r0[1]), "+v"(v.r1[1]), "+v"(v.r0[NFAM - 1]), "+v"(v.r1[NFAM - 1]), "+v"(v.y0),
+                     "+v"(v.y1), "+v"(v.b0), "+v"(v.b1));
+    else if constexpr (NFAM == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.r0[0]), "+v"(v.r1[0]), "+v"(v.r0[NFAM - 1]), "+v"(v.r1[NFAM - 1]), "+v"(v.y0), "+v"(v.y1), "+v"(v.b0), "+v"(v.b1));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.r0[0]), "+v"(v.r1[0]), "+v"(v.y0), "+v"(v.y1), "+v"(v.b0), "+v"(v.b1));
+  }
+  static __device__ __forceinline__ void fwait(FBuf &v)
+  {
+    static_assert(NFB <= 2, "operand list written for at most two B fragments");
+    if constexpr (NFAM == 3)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(v.r0[0]), "+v"(v.r1[0]), "+v"(v.r0[1]), "+v"(v.r1[1]), "+v"(v.r0[NFAM - 1]), "+v"(v.r1[NFAM - 1]), "+v"(v.y0),
+                     "+v"(v.y1));
+    else if constexpr (NFAM == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.r0[0]), "+v"(v.r1[0]), "+v"(v.r0[NFAM - 1]), "+v"(v.r1[NFAM - 1]), "+v"(v.y0), "+v"(v.y1));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v.r0[0]), "+v"(v.r1[0]), "+v"(v.y0), "+v"(v.y1));
+    if constexpr (NFB == 2)
+      asm volatile("" : "+v"(v.b[0][0]), "+v"(v.b[0][1]), "+v"(v.b[0][2]), "+v"(v.b[0][3]), "+v"(v.b[NFB - 1][0]), "+v"(v.b[NFB - 1][1]),
+                   "+v"(v.b[NFB - 1][2]), "+v"(v.b[NFB - 1][3]));
+    else
+      asm volatile("" : "+v"(v.b[0][0]), "+v"(v.b[0][1]), "+v"(v.b[0][2]), "+v"(v.b[0][3]));
+  }
+  __device__ __forceinline__ void vstep(const VBuf &v)
+  {
+    double A[NFA];
+    static_for<0, NFAM>([&](auto a_) {
+      constexpr int a = a_;
+      A[a] = v.r0[a] * v.r1[a];
+    });
+    static_for<0, NFAM>([&](auto a_) {
+      constexpr int a = a_;
+      accv[a][0] = pdh::mfma4(A[a], v.b0, accv[a][0]);
+      accv[a][1] = pdh::mfma4(A[a], v.b1, accv[a][1]);
+    });
+    if constexpr (LAST_ROW)
+      accyv = pdh::mfma4(v.b0, v.y0 * v.y1, accyv);
+  }
+  __device__ __forceinline__ void fstep(const FBuf &v)
+  {
+    double A[NFA];
+    static_for<0, NFAM>([&](auto a_) {
+      constexpr int a = a_;
+      A[a] = v.r0[a] * v.r1[a];
+    });
+    static_for<0, NFAM>([&](auto a_) {
+      constexpr int a = a_;
+      static_for<0, NFB>([&](auto b_) {
+        constexpr int b = b_;
+        static_for<0, 4>([&](auto r_) {
+          constexpr int r = r_;
+          accf[a][b][r] = pdh::mfma4(A[a], v.b[b][r], accf[a][b][r]);
+        });
+      });
+    });
+    if constexpr (LAST_ROW)
+      {
+        const double Y = v.y0 * v.y1;
+        static_for<0, NFB>([&](auto b_) {
+          constexpr int b = b_;
+          accyf[b] = pdh::mfma4(v.b[b][0], Y, accyf[b]);
+        });
+      }
+  }
+  // all VCH points of a chunk (dead points carry zero weights)
+  __device__ __forceinline__ void volume_chunk_full()
+  {
+    constexpr int NS = VCH / 4;
+    VBuf buf[2];
+    vload<0>(buf[0]);
+    static_for<0, NS>([&](auto s_) {
+      constexpr int s = s_;
+      vwait(buf[s & 1]);
+      if constexpr (s + 1 < NS)
+        vload<s + 1>(buf[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      vstep(buf[s & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  __device__ __forceinline__ void face_chunk_full()
+  {
+    constexpr int NS = CH / 4;
+    FBuf buf[2];
+    fload<0>(buf[0]);
+    static_for<0, NS>([&](auto s_) {
+      constexpr int s = s_;
+      fwait(buf[s & 1]);
+      if constexpr (s + 1 < NS)
+        fload<s + 1>(buf[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      fstep(buf[s & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
   static __device__ __forceinline__ double ld(const char *rb, int off) { return *reinterpret_cast<const double *>(rb + off); }
   // One step = 4 points.  The LDS factors of the next step are requested before the MFMAs of the current one.
@@ -668,6 +865,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
   using Acc = MomentAcc<N1D>;
   Acc ma;
   ma.init(lane);
+  ma.init_addr(work, lane);
   // Point data of a chunk is loaded one chunk ahead (registers) so that the global-load latency sits behind the MFMA
   // loop of the previous chunk: measured, the record phase of this kernel was 0.53 of its 2.14 ms, mostly waiting.
   // ---- volume moments -----------------------------------------------------------------------------------
@@ -704,7 +902,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
         }
         __syncthreads();
 #if PDHM_EXP != 6
-        ma.volume_chunk(work, cnt, lane);
+        if (cnt == Acc::VCH)
+          ma.volume_chunk_full();
+        else
+          ma.volume_chunk(work, cnt, lane);
 #endif
       }
   }
@@ -770,7 +971,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
         }
         __syncthreads();
 #if PDHM_EXP != 6
-        ma.face_chunk(work, cnt, lane);
+        if (cnt == Acc::CH)
+          ma.face_chunk_full();
+        else
+          ma.face_chunk(work, cnt, lane);
 #endif
       }
   }
@@ -1079,6 +1283,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
   using Acc = MomentAcc<N1D>;
   Acc ma;
   ma.init(lane);
+  ma.init_addr(work, lane);
   {
     const int64_t pb = P.it_pbeg[item], pe = pb + P.it_pcnt[item];
 #if PDHM_EXP == 2
@@ -1111,7 +1316,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
           Acc::write_face_record_half(work + pt * Acc::REC, half, xa, xb, s);
         }
         __syncthreads();
-        ma.face_chunk(work, cnt, lane);
+#if PDHM_OFF_FULL
+        if (cnt == Acc::CH)
+          ma.face_chunk_full();
+        else
+#endif
+          ma.face_chunk(work, cnt, lane);
       }
   }
   double accS[NAP], accN[DIM][NAP];

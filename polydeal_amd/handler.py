@@ -52,7 +52,15 @@ def _lib():
         lib.pdhh_sparsity.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.pdhh_sparsity.restype = C.c_int64
         lib.pdhh_flatten.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
-        lib.pdhh_flatten.restype = C.POINTER(pdh_problem)
+        lib.pdhh_flatten.restype = C.c_void_p
+        lib.pdhh_flatten_local.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        lib.pdhh_flatten_local.restype = C.c_void_p
+        lib.pdhh_flat_problem.argtypes = [C.c_void_p]
+        lib.pdhh_flat_problem.restype = C.POINTER(pdh_problem)
+        lib.pdhh_flat_destroy.argtypes = [C.c_void_p]
+        lib.pdhh_flat_destroy.restype = None
+        lib.pdhh_flat_local_of.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdhh_flat_sizes.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdhh_flat_sizes.restype = C.c_int64
         lib.pdhh_assemble_dg_matrix.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
@@ -164,21 +172,51 @@ class BackgroundGrid:
             pass
 
 
-class FlatView:
-    """NumPy views onto the pdh_problem a handler flattened (owned by the C++ handle)."""
+class _FlatOwner:
+    """Owns one flattened problem of the C++ host mirror (independent of the handler and of later flatten() calls)."""
 
-    def __init__(self, handler, cptr):
-        self.handler = handler  # keeps the owner alive
-        self.c = cptr.contents
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib().pdhh_flat_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class FlatView:
+    """A flattened problem (pdh_problem + its arrays) produced by AgglomerationHandler.flatten / flatten_local.
+    Every view owns its description; the NumPy arrays returned by arrays() keep it alive."""
+
+    def __init__(self, fh):
+        self._own = _FlatOwner(fh)
+        self.c = _lib().pdhh_flat_problem(fh).contents
         sizes = (C.c_int64 * 4)()
-        _lib().pdhh_flat_sizes(handler.h, sizes)
+        _lib().pdhh_flat_sizes(fh, sizes)
         self.nq_tot, self.nqf_tot, self.nnz, self.n_faces = [int(x) for x in sizes]
+        self.local = bool(self.c.local)
+
+    @property
+    def n_local_rows(self):
+        """Rows covered by rowptr: all of them for a global description, the owned ones for a rank-local one."""
+        return self._n_local_rows if self.local else self.c.n_rows
+
+    def local_of(self):
+        """Global polytope index of every local polytope (rank-local descriptions)."""
+        out = np.zeros(self.c.n_agg, dtype=np.int32)
+        n = _lib().pdhh_flat_local_of(self._own.h, out.ctypes.data)
+        return out[:n]
 
     def _arr(self, field, ctype, n):
         p = getattr(self.c, field)
         if not p or n == 0:
             return None
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n,))
+        buf = (ctype * n).from_address(p)
+        buf._owner = self._own  # the array's base chain ends here: the C++ storage outlives every view of it
+        return np.frombuffer(buf, dtype=np.dtype(ctype))
 
     def arrays(self):
         c, d = self.c, self.c.dim
@@ -191,7 +229,8 @@ class FlatView:
             fq_n=self._arr("fq_n", C.c_double, d * self.nqf_tot), fq_w=self._arr("fq_w", C.c_double, self.nqf_tot),
             fq_w_out=self._arr("fq_w_out", C.c_double, self.nqf_tot),
             face_sigma=self._arr("face_sigma", C.c_double, c.n_faces),
-            rowptr=self._arr("rowptr", C.c_int64, c.n_rows + 1), colind=self._arr("colind", C.c_int32, self.nnz),
+            rowptr=self._arr("rowptr", C.c_int64, self.n_local_rows + 1), colind=self._arr("colind", C.c_int32, self.nnz),
+            col_offset=self._arr("col_offset", C.c_int32, c.n_agg), agg_rank=self._arr("agg_rank", C.c_int32, c.n_agg),
         )
 
 
@@ -310,7 +349,24 @@ class AgglomerationHandler:
                                 variant.boundary, variant.reaction_c, int(diag_first), int(with_colind))
         if not p:
             _raise()
-        return FlatView(self, p)
+        return FlatView(p)
+
+    def flatten_local(self, variant: SipVariant, row_begin, row_end, diag_first=True, with_colind=False, row_splits=None,
+                      epetra_columns=False) -> FlatView:
+        """Rank-local description (pdh_problem.local = 1) of the dof rows [row_begin,row_end): the owned polytopes plus
+        their ghost neighbours, global dof numbers, rowptr/colind of the owned rows only - what one MPI rank of the
+        reference holds (source/agglomeration_handler.cc:1026-1091).  row_splits [n_ranks+1] (first row of every rank)
+        fills agg_rank; epetra_columns orders rows by Epetra local column ids (owned first, ghosts behind)."""
+        rs = None if row_splits is None else np.ascontiguousarray(row_splits, dtype=np.int32)
+        p = _lib().pdhh_flatten_local(self.h, variant.penalty_constant, variant.owner_rule, variant.h_rule, variant.boundary,
+                                      variant.reaction_c, int(diag_first), int(with_colind), int(row_begin), int(row_end),
+                                      None if rs is None else rs.ctypes.data, 0 if rs is None else len(rs) - 1,
+                                      int(epetra_columns))
+        if not p:
+            _raise()
+        fv = FlatView(p)
+        fv._n_local_rows = int(row_end) - int(row_begin)
+        return fv
 
     def __del__(self):
         try:

@@ -52,6 +52,27 @@ def main():
     assert int(st[4]) == int(rp[r1] - rp[r0])
     # a misaligned range must be rejected
     assert lib.pdh_check_problem(C.byref(flat.c), r0 + 1, r1, st) != 0
+    # RANK-LOCAL description (owned + ghost polytopes only, global dof numbers, rowptr/colind of the owned rows): what an
+    # MPI rank of the reference holds (source/agglomeration_handler.cc:1026-1091).  Packs to the same counts as the
+    # global description restricted to the range, and its pattern is the slice of the global one.
+    import numpy as np
+    splits = [row_range(ah.n_agglomerates, n, r, world)[0] for r in range(world)] + [flat.c.n_rows]
+    loc = ah.flatten_local(pa.SipVariant.diffusion_reaction(fe), r0, r1, True, True, row_splits=splits)
+    assert loc.c.local == 1 and loc.c.n_rows == flat.c.n_rows and loc.c.n_agg < flat.c.n_agg or world == 1
+    sl = (C.c_int64 * 8)()
+    rc = lib.pdh_check_problem(C.byref(loc.c), r0, r1, sl)
+    assert rc == 0, lib.pdh_last_error(None)
+    assert list(sl) == list(st), (list(sl), list(st))
+    ga, la = flat.arrays(), loc.arrays()
+    assert np.array_equal(la["rowptr"], ga["rowptr"][r0:r1 + 1] - ga["rowptr"][r0])
+    assert np.array_equal(la["colind"], ga["colind"][ga["rowptr"][r0]:ga["rowptr"][r1]])
+    lof = loc.local_of()
+    assert np.array_equal(la["dof_offset"], ga["dof_offset"][lof])
+    assert np.array_equal(la["agg_rank"] == rank, (la["dof_offset"] >= r0) & (la["dof_offset"] < r1))
+    # the local description must not be accepted for another rank's range
+    if world > 1:
+        o0, o1 = row_range(ah.n_agglomerates, n, (rank + 1) % world, world)
+        assert lib.pdh_check_problem(C.byref(loc.c), o0, o1, sl) != 0
     dist.barrier()
     if rank == 0:
         print("DIST_OK world=%d" % world)

@@ -701,3 +701,124 @@ def test_moment_form_with_neighbours_of_very_different_size(r, lg):
     vd, _ = _values(kw, "direct")
     vm, _ = _values(kw, "moment")
     assert np.max(np.abs(vm - vd)) <= 1e-12 * np.max(np.abs(vd))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The PRODUCT's own chain (C++ host mirror -> pdh_problem -> HIP kernels) against the oracle, entry by entry: the cases
+# above feed the kernels from the oracle's flattening (identical inputs); here nothing of the oracle is on the input side.
+# ---------------------------------------------------------------------------------------------------------------------
+def _mirror_pair(dim, lg, b, basis, p, nq, vname, dist, groups=None):
+    """(product handler, product variant, oracle handler, oracle variant) on the same (possibly distorted) grid."""
+    import polydeal_amd as pa
+
+    grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, lg)
+    if dist:
+        grid.distort(dist, seed=5)
+    og = po.hyper_cube_refined(dim, 0.0, 1.0, lg)
+    for c in range(og.n_cells):
+        og.vertices[c] = grid.cell_vertices(c)
+    ah, oah = pa.AgglomerationHandler(grid), po.AgglomerationHandler(og)
+    if groups is None:
+        ah.define_block_agglomerates(b)
+        for g in po.block_agglomerates(og, b):
+            oah.define_agglomerate(g)
+    else:
+        for g in groups:
+            ah.define_agglomerate(g)
+            oah.define_agglomerate(g)
+    fe = (pa.FE_DGQ if basis == "dgq" else pa.FE_AggloDGP)(dim, p)
+    ofe = (po.FE_DGQ if basis == "dgq" else po.FE_AggloDGP)(dim, p)
+    for h, f in ((ah, fe), (oah, ofe)):
+        h.initialize_fe_values(nq, nq)
+        h.distribute_agglomerated_dofs(f)
+    pvar = {"test": pa.SipVariant.minimal_sip_test, "adm": pa.SipVariant.assemble_dg_matrix,
+            "poisson": lambda: pa.SipVariant.poisson_example(fe), "dr": lambda: pa.SipVariant.diffusion_reaction(fe),
+            "minsip": pa.SipVariant.minimal_sip_example}[vname]()
+    return grid, ah, fe, pvar, oah, variant(vname, ofe)
+
+
+MIRROR_CASES = [
+    (2, 3, 2, "dgq", 1, 3, "minsip", 0.0), (2, 3, 2, "dgp", 2, 3, "poisson", 0.2), (2, 3, 4, "dgq", 3, 4, "adm", 0.1),
+    (3, 2, 2, "dgq", 1, 2, "test", 0.0), (3, 2, 2, "dgp", 3, 4, "poisson", 0.15), (3, 2, 2, "dgq", 2, 3, "dr", 0.1),
+    (3, 2, 2, "dgq", 3, 4, "poisson", 0.0), (3, 2, 2, "dgq", 3, 4, "dr", 0.2), (3, 3, 2, "dgq", 2, 3, "adm", 0.0),
+]
+
+
+@pytest.mark.parametrize("case", MIRROR_CASES, ids=lambda c: "%dD_n%d_b%d_%s%d_%s_d%g" % (c[0], 2 ** c[1], c[2], c[3], c[4], c[6], c[7]))
+@pytest.mark.parametrize("diag_first", [True, False])
+def test_product_mirror_to_gpu_against_oracle(case, diag_first):
+    import polydeal_amd as pa
+
+    grid, ah, fe, pvar, oah, ovar = _mirror_pair(*case)
+    rp, ci, vals = pa.assemble_dg_matrix(fe, ah, pvar, diag_first=diag_first)
+    orp, oci, ref = po.assemble_csr(oah, ovar, diag_first=diag_first)
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+    # per block-scale as well as against the global maximum
+    assert np.max(np.abs(vals - ref)) <= TOL * np.max(np.abs(ref))
+    n = fe.n_dofs_per_cell
+    blk = np.abs(ref).reshape(-1, n).max(axis=1)
+    err = np.abs(vals - ref).reshape(-1, n).max(axis=1)
+    assert np.all(err <= 1e-11 * np.maximum(blk, 1e-3 * np.max(blk)))
+
+
+def _rows_dense(rowptr, cols, vals, n_cols):
+    out = np.zeros((len(rowptr) - 1, n_cols))
+    for r in range(len(rowptr) - 1):
+        out[r, cols[rowptr[r]:rowptr[r + 1]]] = vals[rowptr[r]:rowptr[r + 1]]
+    return out
+
+
+@pytest.mark.parametrize("basis,p,vname,dist,world", [("dgq", 2, "dr", 0.1, 3), ("dgq", 3, "poisson", 0.0, 2),
+                                                      ("dgp", 2, "adm", 0.15, 4)])
+def test_rank_local_descriptions_reproduce_the_global_rows(basis, p, vname, dist, world):
+    """Every 'rank' gets ONLY its local + ghost description (pdh_problem.local = 1: owned and ghost polytopes, global dof
+    numbers, rowptr/colind of its own rows - what an MPI rank of the reference holds, source/agglomeration_handler.cc:
+    1026-1091) and reproduces its rows of the global assembly; also in the Epetra local-column order of
+    TrilinosWrappers::SparseMatrix (ghost columns behind the owned ones)."""
+    import polydeal_amd as pa
+    from polydeal_amd.partition import row_range
+
+    grid, ah, fe, pvar, oah, ovar = _mirror_pair(3, 3 if p < 3 else 2, 2, basis, p, p + 1, vname, dist)
+    n, nA, N = fe.n_dofs_per_cell, ah.n_agglomerates, ah.n_dofs
+    _, _, ref = po.assemble_csr(oah, ovar, diag_first=False)
+    orp, oci = oah.sparsity_pattern(False)
+    dense_ref = _rows_dense(orp, oci, ref, N)
+    splits = [row_range(nA, n, r, world)[0] for r in range(world)] + [N]
+    for diag_first in (True, False):
+        gflat = ah.flatten(pvar, diag_first, True)
+        ctx = pa.Context(0)
+        ctx.set_problem(gflat)
+        gvals = ctx.assemble()
+        ctx.close()
+        grp = gflat.arrays()["rowptr"]
+        for r in range(world):
+            r0, r1 = splits[r], splits[r + 1]
+            loc = ah.flatten_local(pvar, r0, r1, diag_first, True, row_splits=splits)
+            assert loc.c.n_agg < nA
+            ctx = pa.Context(0)
+            ctx.set_problem(loc, r0, r1)
+            v = ctx.assemble()
+            ctx.close()
+            want = gvals[grp[r0]:grp[r1]]
+            assert v.shape == want.shape
+            assert np.max(np.abs(v - want)) <= 1e-14 * np.max(np.abs(gvals))
+    # Epetra order: rows sorted by local column id
+    for r in range(world):
+        r0, r1 = splits[r], splits[r + 1]
+        loc = ah.flatten_local(pvar, r0, r1, False, True, row_splits=splits, epetra_columns=True)
+        la = loc.arrays()
+        ctx = pa.Context(0)
+        ctx.set_problem(loc, r0, r1)
+        v = ctx.assemble()
+        ctx.close()
+        # local column id -> global column
+        n_loc_cols = int(la["col_offset"].max()) + n
+        l2g = np.zeros(n_loc_cols, dtype=np.int64)
+        for a in range(loc.c.n_agg):
+            l2g[la["col_offset"][a]:la["col_offset"][a] + n] = la["dof_offset"][a] + np.arange(n)
+        rp_l, ci_l = la["rowptr"], la["colind"]
+        assert all(np.all(np.diff(ci_l[rp_l[i]:rp_l[i + 1]]) > 0) for i in range(r1 - r0))  # rows ascending in LOCAL ids
+        got = _rows_dense(rp_l, l2g[ci_l], v, N)
+        assert np.max(np.abs(got - dense_ref[r0:r1])) <= TOL * np.max(np.abs(ref))
+        if r > 0:  # a ghost block with a smaller global number sits behind the owned blocks
+            assert any(np.any(np.diff(l2g[ci_l[rp_l[i]:rp_l[i + 1]]]) < 0) for i in range(r1 - r0))
