@@ -156,6 +156,37 @@ int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values);
 int pdh_synchronize(pdh_ctx *ctx);
 void *pdh_stream(pdh_ctx *ctx); /* hipStream_t the kernels are launched on */
 
+/* Multi-GPU, two realisations of the one exchange step of the path:
+ *   PDH_EXCHANGE_NONE  (default) owner-computes-rows: a face cut by the partition is contracted on BOTH ranks, each writing
+ *                      only its own rows - no matrix traffic at all (the reference's compress(VectorOperation::add),
+ *                      include/poly_utils.h:2194, disappears).
+ *   PDH_EXCHANGE_GHOST the reference's scheme (include/poly_utils.h:1930-1992, 2134-2194; examples/diffusion_reaction.cc:
+ *                      615-692): the rank owning side 0 of a cut face assembles all four blocks, keeps M11/M12 and ships
+ *                      M21 (one n x n block per face) and M22 (summed per remote polytope) to the owner of those rows.
+ *                      Needs problem->agg_rank.  A step is then
+ *                         pdh_assemble_device(ctx);                 owned rows minus the foreign faces + outgoing blocks
+ *                         pdh_exchange_get_send(ctx, d_send);       [sum send_count] doubles, peer by peer in rank order
+ *                         <caller moves them: grouped ncclSend/ncclRecv or all-to-all-v over RCCL/xGMI, d_send -> peers' d_recv>
+ *                         pdh_exchange_apply(ctx, d_recv);          stores the M21 blocks, adds the M22 sums
+ *                      The library stays transport-free (no RCCL/MPI dependency in the C ABI); bench.py drives it with
+ *                      torch.distributed (RCCL).  Both ranks derive the block order of a peer buffer from the global dof
+ *                      numbers of the cut faces, so no index lists are exchanged.  Results equal PDH_EXCHANGE_NONE up to
+ *                      rounding (1e-14 relative).  Mode changes take effect at the next pdh_set_problem*.              */
+#define PDH_EXCHANGE_NONE 0
+#define PDH_EXCHANGE_GHOST 1
+int pdh_set_exchange_mode(pdh_ctx *ctx, int mode);
+int pdh_exchange_layout(pdh_ctx *ctx, int n_ranks, int64_t *send_count /* [n_ranks] doubles */, int64_t *recv_count);
+int pdh_exchange_get_send(pdh_ctx *ctx, double *d_send /* device memory */);
+int pdh_exchange_apply(pdh_ctx *ctx, const double *d_recv /* device memory */);
+/* Launch everything on a stream of the caller (hipStream_t; NULL = the context's own): collectives issued on that
+ * stream are then ordered with the kernels without host synchronisation.                                       */
+int pdh_set_stream(pdh_ctx *ctx, void *stream);
+/* Host-only (no GPU): the per-peer sizes pdh_exchange_layout would report for this description and row range. */
+int pdh_check_exchange(const pdh_problem *problem, int32_t row_begin, int32_t row_end, int n_ranks, int64_t *send_count,
+                       int64_t *recv_count);
+/* Copy of the owned rows' values as they stand in HBM (after pdh_assemble_device / pdh_exchange_apply). */
+int pdh_copy_values(pdh_ctx *ctx, double *values);
+
 /* Two algebraically identical forms of the same sums exist (results differ by rounding only, both are tested against
  * the oracle): DIRECT contracts basis values over the quadrature points for all n^2 pairs (f64 MFMA, pdh_kernels.h);
  * MOMENT first reduces the quadrature to (2p+1)^3 Legendre moments per polytope / face and obtains the blocks by sum

@@ -45,6 +45,8 @@ EXPORTS = [
     "pdh_assemble_device", "pdh_assemble", "pdh_assemble_sip", "pdh_assemble_sip_local",
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
     "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values", "pdh_set_algorithm", "pdh_algorithm_in_use", "pdh_set_overlap",
+    "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
+    "pdh_check_exchange", "pdh_copy_values",
 ]
 
 _lib = None
@@ -68,6 +70,13 @@ def _bind(lib):
     lib.pdh_set_algorithm.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_set_overlap.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_algorithm_in_use.argtypes = [C.c_void_p]
+    lib.pdh_set_exchange_mode.argtypes = [C.c_void_p, C.c_int]
+    lib.pdh_exchange_layout.argtypes = [C.c_void_p, C.c_int, P(C.c_int64), P(C.c_int64)]
+    lib.pdh_exchange_get_send.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdh_exchange_apply.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdh_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdh_check_exchange.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, C.c_int, P(C.c_int64), P(C.c_int64)]
+    lib.pdh_copy_values.argtypes = [C.c_void_p, C.c_void_p]
     lib.pdh_shape_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
@@ -177,6 +186,12 @@ class Context:
         self._chk(self.lib.pdh_assemble(self.h, out.ctypes.data))
         return out
 
+    def values(self):
+        """The CSR values as they stand in HBM (no re-assembly)."""
+        out = np.empty(self.n_values, dtype=np.float64)
+        self._chk(self.lib.pdh_copy_values(self.h, out.ctypes.data))
+        return out
+
     def assemble_rhs(self, f_vol=None, g_bdry=None):
         """rhs of the owned rows; f_vol / g_bdry sampled at the caller's volume / face quadrature points."""
         n_rows = self.stats()["n_owned_agg"] * self.stats()["dofs_per_cell"]
@@ -219,6 +234,28 @@ class Context:
     def set_algorithm(self, alg):
         """'auto' | 'direct' (MFMA contraction over the points) | 'moment' (Legendre moments + sum factorisation)."""
         self._chk(self.lib.pdh_set_algorithm(self.h, {"auto": 0, "direct": 1, "moment": 2}[alg]))
+
+    def set_exchange_mode(self, mode):
+        """'none': owner-computes-rows (no matrix traffic); 'ghost': the reference's scheme - the owner of a cut face ships
+        M21 / M22 to the owner of those rows (needs agg_rank in the problem).  Takes effect at the next set_problem."""
+        self._chk(self.lib.pdh_set_exchange_mode(self.h, {"none": 0, "ghost": 1}[mode]))
+
+    def exchange_layout(self, n_ranks):
+        """(send_count, recv_count): doubles per peer rank of the ghost-block exchange."""
+        s = (C.c_int64 * n_ranks)()
+        r = (C.c_int64 * n_ranks)()
+        self._chk(self.lib.pdh_exchange_layout(self.h, n_ranks, s, r))
+        return [int(x) for x in s], [int(x) for x in r]
+
+    def exchange_get_send(self, d_send_ptr):
+        self._chk(self.lib.pdh_exchange_get_send(self.h, C.c_void_p(d_send_ptr)))
+
+    def exchange_apply(self, d_recv_ptr):
+        self._chk(self.lib.pdh_exchange_apply(self.h, C.c_void_p(d_recv_ptr)))
+
+    def set_stream(self, stream_handle):
+        """Launch on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); None: own stream."""
+        self._chk(self.lib.pdh_set_stream(self.h, C.c_void_p(stream_handle or 0)))
 
     def set_overlap(self, on=True):
         """Run the two kernels of a step concurrently on large problems (default) or strictly one after the other."""

@@ -84,7 +84,7 @@ static int combo_group(int dim, int n1d, int nt, int lb)
 struct pdh_ctx
 {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, own_stream = nullptr; // stream = the one in use (own_stream unless pdh_set_stream)
   std::string err;
   bool has_problem = false;
   std::vector<void *> allocs;
@@ -99,6 +99,14 @@ struct pdh_ctx
   int64_t n_rows_owned = 0;
   int32_t n_agg_total = 0;
   int64_t mfma_diag = 0, mfma_offdiag = 0; // MFMA instructions per launch
+  // ghost-block exchange variant (pdh_set_exchange_mode); n_diag_slots = n_owned + pseudo slots of the outgoing M22 sums
+  int exchange_mode = PDH_EXCHANGE_NONE;
+  bool problem_ghost = false;
+  int n_diag_slots = 0, n_r21 = 0, n_r22 = 0;
+  int64_t n_send = 0, n_recv = 0;
+  std::vector<int64_t> send_count, recv_count;
+  const int64_t *d_r21_src = nullptr, *d_r21_dst = nullptr, *d_r22_ptr = nullptr, *d_r22_src = nullptr;
+  const int32_t *d_r21_rlen = nullptr, *d_r22_slot = nullptr;
   // moment form (pdh_moment.h): available for 3-D bases of degree <= 3; `algorithm` = caller's choice
   int algorithm = PDH_ALG_AUTO;
   int basis = 0;
@@ -123,7 +131,7 @@ struct pdh_ctx
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int overlap = 1; // pdh_set_overlap
-  bool overlapped() const { return overlap && stream2 && (int64_t)n_owned + n_items >= 8192; }
+  bool overlapped() const { return overlap && stream2 && (int64_t)n_diag_slots + n_items >= 8192; }
   bool profiling = false;
   std::vector<hipEvent_t> events; // 4 per profiled launch: before / after the diagonal kernel, before / after the coupling kernel
   size_t ev_used = 0;
@@ -208,11 +216,12 @@ extern "C" int pdh_create(pdh_ctx **out, int device_id)
       delete ctx;
       return fail(nullptr, PDH_EDEVICE, "pdh_create: second stream / events");
     }
-  if (hipStreamCreate(&ctx->stream) != hipSuccess)
+  if (hipStreamCreate(&ctx->own_stream) != hipSuccess)
     {
       delete ctx;
       return fail(nullptr, PDH_EDEVICE, "pdh_create: hipStreamCreate failed");
     }
+  ctx->stream = ctx->own_stream;
   *out = ctx;
   return PDH_OK;
 }
@@ -227,7 +236,7 @@ extern "C" void pdh_destroy(pdh_ctx *ctx)
   for (auto &ev : ctx->events)
     if (ev)
       (void)hipEventDestroy(ev);
-  (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->stream2)
     (void)hipStreamDestroy(ctx->stream2);
   if (ctx->ev_fork)
@@ -252,9 +261,15 @@ struct Packed
   std::vector<int64_t> vq_src, run_ap, run_fq;
   std::vector<int32_t> run_cnt, run_bdry;
   int64_t n_values = 0;
+  int n_owned = 0; // own_agg / ap_ptr / ... may carry pseudo slots behind the owned ones (ghost-block exchange)
+  // ghost-block exchange (PDH_EXCHANGE_GHOST): doubles per peer rank, and where the received blocks go
+  std::vector<int64_t> send_count, recv_count;
+  int64_t n_send = 0, n_recv = 0;
+  std::vector<int32_t> r21_face, r21_rlen, r22_slot;
+  std::vector<int64_t> r21_src, r21_dst, r22_ptr, r22_src;
 };
 
-static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end, Packed &K)
+static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end, Packed &K, int exchange_mode = PDH_EXCHANGE_NONE)
 {
   if (!p)
     return fail(ctx, PDH_EINVAL, "problem is NULL");
@@ -367,16 +382,119 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
   const int64_t val_base = p->rowptr[row_begin - rp_shift];
   K.n_values = p->rowptr[row_end - rp_shift] - val_base;
 
-  // owned polytopes in polytope order
+  // ---- ghost-block exchange variant (pdh_set_exchange_mode): which faces are cut by the partition ------------------
+  // A face whose sides live on different ranks is assembled by the rank that owns side 0 (the caller lists every face from
+  // its owner side: the reference's `id() < neighbor->id()` rule, include/poly_utils.h:2089, 2134-2190): that rank adds
+  // M11, M12 to its own rows and ships M21 (one block per face) and M22 (summed per remote polytope) to the other rank.
+  const bool ghost = exchange_mode == PDH_EXCHANGE_GHOST;
+  int my_rank = -1, n_ranks = 1;
+  if (ghost)
+    {
+      if (!p->agg_rank)
+        return fail(ctx, PDH_EINVAL, "the ghost-block exchange needs agg_rank (owning rank of every polytope)");
+      for (int a = 0; a < nA; ++a)
+        {
+          if (p->agg_rank[a] < 0)
+            return fail(ctx, PDH_EINVAL, "agg_rank must be non-negative");
+          n_ranks = std::max(n_ranks, p->agg_rank[a] + 1);
+          if (owned(a))
+            {
+              if (my_rank >= 0 && p->agg_rank[a] != my_rank)
+                return fail(ctx, PDH_EINVAL, "owned polytopes carry different ranks in agg_rank");
+              my_rank = p->agg_rank[a];
+            }
+        }
+      for (int a = 0; a < nA; ++a)
+        if (!owned(a) && p->agg_rank[a] == my_rank)
+          return fail(ctx, PDH_EINVAL, "a polytope outside the owned row range carries the owner's rank in agg_rank");
+    }
+  struct Cut { int peer, dof_in, dof_out, f; };
+  std::vector<Cut> cut_send, cut_recv; // faces owned here with a remote side 1 / owned remotely with side 1 here
+  if (ghost)
+    for (int f = 0; f < nF; ++f)
+      {
+        const int in = p->face_in[f], out = p->face_out[f];
+        if (out < 0)
+          continue;
+        if (owned(in) && !owned(out))
+          cut_send.push_back({p->agg_rank[out], p->dof_offset[in], p->dof_offset[out], f});
+        else if (!owned(in) && owned(out))
+          cut_recv.push_back({p->agg_rank[in], p->dof_offset[in], p->dof_offset[out], f});
+      }
+  auto cut_less = [](const Cut &x, const Cut &y) {
+    return x.peer != y.peer ? x.peer < y.peer : (x.dof_in != y.dof_in ? x.dof_in < y.dof_in : x.dof_out < y.dof_out);
+  };
+  std::sort(cut_send.begin(), cut_send.end(), cut_less);
+  std::sort(cut_recv.begin(), cut_recv.end(), cut_less);
+  // per peer: M21 blocks in the order above, then one M22 block per distinct side-1 polytope, ascending by its dof
+  std::vector<int64_t> send_block_of_face(ghost ? nF : 0, -1); // block index (units of n^2 doubles) of a face's M21
+  std::vector<std::pair<int, int>> send22; // (peer, remote polytope), sorted; block index follows
+  std::vector<int64_t> send22_block;
+  K.send_count.assign(n_ranks, 0);
+  K.recv_count.assign(n_ranks, 0);
+  {
+    int64_t blk = 0;
+    size_t i = 0;
+    while (i < cut_send.size())
+      {
+        const int peer = cut_send[i].peer;
+        const int64_t blk0 = blk;
+        std::vector<std::pair<int, int>> outs; // (dof, polytope)
+        for (; i < cut_send.size() && cut_send[i].peer == peer; ++i)
+          {
+            send_block_of_face[cut_send[i].f] = blk++;
+            outs.emplace_back(cut_send[i].dof_out, p->face_out[cut_send[i].f]);
+          }
+        std::sort(outs.begin(), outs.end());
+        outs.erase(std::unique(outs.begin(), outs.end()), outs.end());
+        for (const auto &o : outs)
+          {
+            send22.emplace_back(peer, o.second);
+            send22_block.push_back(blk++);
+          }
+        K.send_count[peer] = (blk - blk0) * (int64_t)n * n;
+      }
+    K.n_send = blk * (int64_t)n * n;
+  }
+
+  // owned polytopes in polytope order; in ghost mode followed by one pseudo slot per remote polytope that receives an M22
   K.vq_ptr.push_back(0);
   K.ap_ptr.push_back(0);
-  std::vector<std::pair<int32_t, int32_t>> blocks; // (dof offset, polytope)
+  struct Run { int a, f; }; // own-side points of face f seen from polytope a
+  std::vector<Run> runs;
+  std::vector<int64_t> run_slot_end; // runs.size() after every slot
+  std::vector<std::pair<int32_t, int32_t>> blocks; // (column number, polytope)
+  std::vector<int32_t> slot_of(nA, -1);
+  auto append_run_points = [&](int a, int f) {
+    const bool side0 = (p->face_in[f] == a);
+    const int other = side0 ? p->face_out[f] : p->face_in[f];
+    const double sig = p->face_sigma[f];
+    for (int64_t q = p->fq_ptr[f]; q < p->fq_ptr[f + 1]; ++q)
+      {
+        const double w_in = p->fq_w[q];
+        const double w_out = p->fq_w_out ? p->fq_w_out[q] : w_in;
+        if (other < 0)
+          { // Nitsche boundary: same form with 2 JxW and sigma / 2 (exact scalings)
+            K.ap_wself.push_back(2.0 * w_in);
+            K.ap_wcross.push_back(0.0);
+            K.ap_sig.push_back(0.5 * sig);
+          }
+        else
+          {
+            K.ap_wself.push_back(side0 ? w_in : w_out); // M11 uses JxW_0, M22 JxW_1 (poly_utils.h:1898, 1922)
+            K.ap_wcross.push_back(w_out);               // M12, M21 use JxW_1 (poly_utils.h:1906, 1914)
+            K.ap_sig.push_back(sig);
+          }
+      }
+    runs.push_back({a, f});
+  };
   for (int a = 0; a < nA; ++a)
     {
       const int off = p->dof_offset[a];
       if (off < row_begin || off >= row_end)
         continue;
       const int slot = (int)K.own_agg.size();
+      slot_of[a] = slot;
       K.own_agg.push_back(a);
       K.own_row.push_back(off - row_begin);
       // coupled blocks, ascending by column number (reference :954-975)
@@ -441,7 +559,21 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           const bool side0 = (p->face_in[f] == a);
           const int other = side0 ? p->face_out[f] : p->face_in[f];
           const int64_t qb = p->fq_ptr[f], qe = p->fq_ptr[f + 1];
-          const double sig = p->face_sigma[f];
+          const bool cut = other >= 0 && !owned(other);
+          if (ghost && cut && !side0)
+            { // owned by the other rank: its M21 and M22 arrive through the exchange
+              size_t rank = 0;
+              for (size_t u = 0; u < blocks.size(); ++u)
+                if (blocks[u].second == other)
+                  rank = u;
+              int pos = (int)rank * n;
+              if (p->diag_first && colnum(other) < ocol)
+                pos += 1;
+              K.r21_face.push_back(f);
+              K.r21_dst.push_back(K.row_base[slot] + pos);
+              K.r21_rlen.push_back((int32_t)rl);
+              continue;
+            }
           K.run_ap.push_back((int64_t)K.ap_wself.size());
           K.run_fq.push_back(qb);
           K.run_cnt.push_back((int32_t)(qe - qb));
@@ -466,42 +598,55 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
                   if (p->diag_first && ooff < ocol)
                     pos += 1;
                   K.it_pos.push_back(pos);
-                  K.it_nbr_slot.push_back(other_owned ? other : -1); // polytope id for now, slot resolved below
+                  // polytope id for now (slot resolved below); ghost mode: -2 - f marks "M21 of face f goes to the send region"
+                  K.it_nbr_slot.push_back(other_owned ? other : (ghost ? -2 - f : -1));
                   K.it_pos_t.push_back(0);
                 }
             }
-          for (int64_t q = qb; q < qe; ++q)
-            {
-              const double w_in = p->fq_w[q];
-              const double w_out = p->fq_w_out ? p->fq_w_out[q] : w_in;
-              if (other < 0)
-                { // Nitsche boundary: same form with 2 JxW and sigma / 2 (exact scalings)
-                  K.ap_wself.push_back(2.0 * w_in);
-                  K.ap_wcross.push_back(0.0);
-                  K.ap_sig.push_back(0.5 * sig);
-                }
-              else
-                {
-                  K.ap_wself.push_back(side0 ? w_in : w_out); // M11 uses JxW_0, M22 JxW_1 (poly_utils.h:1898, 1922)
-                  K.ap_wcross.push_back(w_out);               // M12, M21 use JxW_1 (poly_utils.h:1906, 1914)
-                  K.ap_sig.push_back(sig);
-                }
-            }
+          append_run_points(a, f);
         }
       K.ap_ptr.push_back((int64_t)K.ap_wself.size());
+      run_slot_end.push_back((int64_t)runs.size());
     }
   if ((int64_t)K.own_agg.size() * n != (int64_t)(row_end - row_begin))
     return fail(ctx, PDH_EINVAL, "dof_offset values do not tile the owned row range");
+  K.n_owned = (int)K.own_agg.size();
+  // pseudo slots: the M22 sums for remote polytopes (side 1 of cut faces owned here), computed by the diagonal-block kernel
+  // from the points of those faces seen from side 1 and written as plain n x n blocks into the send region
+  for (size_t j = 0; j < send22.size(); ++j)
+    {
+      const int q = send22[j].second;
+      K.own_agg.push_back(q);
+      K.own_row.push_back(0);
+      K.row_base.push_back(K.n_values + send22_block[j] * (int64_t)n * n);
+      K.row_len.push_back(n);
+      K.diag_L.push_back(0);
+      K.vq_ptr.push_back((int64_t)K.vq_w.size());
+      for (int64_t t = fptr[q]; t < fptr[q + 1]; ++t)
+        {
+          const int f = flist[t];
+          if (p->face_out[f] == q && owned(p->face_in[f]))
+            append_run_points(q, f);
+        }
+      K.ap_ptr.push_back((int64_t)K.ap_wself.size());
+      run_slot_end.push_back((int64_t)runs.size());
+    }
   {
     // resolve the neighbour's owned slot and the position of P's block inside Q's rows
-    std::vector<int32_t> slot_of(nA, -1);
-    for (size_t sl = 0; sl < K.own_agg.size(); ++sl)
-      slot_of[K.own_agg[sl]] = (int32_t)sl;
     for (size_t it = 0; it < K.it_own.size(); ++it)
       {
         const int q = K.it_nbr_slot[it];
-        if (q < 0)
+        if (q == -1)
           continue;
+        if (q <= -2)
+          { // ghost mode: plain n x n block of the send region, addressed like a row range through a pseudo entry
+            const int f = -2 - q;
+            K.it_nbr_slot[it] = (int32_t)K.row_base.size();
+            K.row_base.push_back(K.n_values + send_block_of_face[f] * (int64_t)n * n);
+            K.row_len.push_back(n);
+            K.it_pos_t[it] = 0;
+            continue;
+          }
         const int pa = K.own_agg[K.it_own[it]];
         const int poff = colnum(pa), qoff = colnum(q);
         // rank of P's block among Q's coupled blocks = number of Q's blocks with a smaller column number
@@ -520,6 +665,52 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
         K.it_nbr_slot[it] = slot_of[q];
       }
   }
+  // receive side of the exchange: where the incoming blocks go
+  if (ghost)
+    {
+      std::vector<int64_t> recv_block_of_face(nF, -1);
+      std::vector<std::pair<std::pair<int, int>, int64_t>> recv22; // ((peer, own polytope), block)
+      int64_t blk = 0;
+      size_t i = 0;
+      while (i < cut_recv.size())
+        {
+          const int peer = cut_recv[i].peer;
+          const int64_t blk0 = blk;
+          std::vector<std::pair<int, int>> outs;
+          for (; i < cut_recv.size() && cut_recv[i].peer == peer; ++i)
+            {
+              recv_block_of_face[cut_recv[i].f] = blk++;
+              outs.emplace_back(cut_recv[i].dof_out, p->face_out[cut_recv[i].f]);
+            }
+          std::sort(outs.begin(), outs.end());
+          outs.erase(std::unique(outs.begin(), outs.end()), outs.end());
+          for (const auto &o : outs)
+            recv22.push_back({{peer, o.second}, blk++});
+          K.recv_count[peer] = (blk - blk0) * (int64_t)n * n;
+        }
+      K.n_recv = blk * (int64_t)n * n;
+      for (size_t k = 0; k < K.r21_face.size(); ++k)
+        K.r21_src.push_back(recv_block_of_face[K.r21_face[k]] * (int64_t)n * n);
+      // M22: grouped by destination polytope so that one wave adds all contributions of a polytope, in a fixed order
+      std::sort(recv22.begin(), recv22.end(), [&](const auto &x, const auto &y) {
+        return x.first.second != y.first.second ? x.first.second < y.first.second : x.first.first < y.first.first;
+      });
+      K.r22_ptr.push_back(0);
+      for (size_t k = 0; k < recv22.size(); ++k)
+        {
+          const int a = recv22[k].first.second;
+          if (k == 0 || recv22[k - 1].first.second != a)
+            {
+              if (k)
+                K.r22_ptr.push_back((int64_t)K.r22_src.size());
+              K.r22_slot.push_back(slot_of[a]);
+            }
+          K.r22_src.push_back(recv22[k].second * (int64_t)n * n);
+        }
+      K.r22_ptr.push_back((int64_t)K.r22_src.size());
+      if (K.r22_slot.empty())
+        K.r22_ptr.assign(1, 0);
+    }
 
   // second pass: coordinates / normals in SoA with the final strides
   const int64_t nvq = (int64_t)K.vq_w.size(), nap = (int64_t)K.ap_wself.size();
@@ -527,22 +718,22 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
   K.ap_x.resize((size_t)dim * nap);
   K.ap_n.resize((size_t)dim * nap);
   int64_t vq = 0, ap = 0;
-  for (int a : K.own_agg)
+  for (int sl = 0; sl < K.n_owned; ++sl)
     {
+      const int a = K.own_agg[sl];
       for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q, ++vq)
         for (int c = 0; c < dim; ++c)
           K.vq_x[c * nvq + vq] = p->vq_x[c * nq_tot + q];
-      for (int64_t t = fptr[a]; t < fptr[a + 1]; ++t)
-        {
-          const int f = flist[t];
-          const double sgn = (p->face_in[f] == a) ? 1.0 : -1.0;
-          for (int64_t q = p->fq_ptr[f]; q < p->fq_ptr[f + 1]; ++q, ++ap)
-            for (int c = 0; c < dim; ++c)
-              {
-                K.ap_x[c * nap + ap] = p->fq_x[c * nqf_tot + q];
-                K.ap_n[c * nap + ap] = sgn * p->fq_n[c * nqf_tot + q];
-              }
-        }
+    }
+  for (const Run &r : runs)
+    {
+      const double sgn = (p->face_in[r.f] == r.a) ? 1.0 : -1.0;
+      for (int64_t q = p->fq_ptr[r.f]; q < p->fq_ptr[r.f + 1]; ++q, ++ap)
+        for (int c = 0; c < dim; ++c)
+          {
+            K.ap_x[c * nap + ap] = p->fq_x[c * nqf_tot + q];
+            K.ap_n[c * nap + ap] = sgn * p->fq_n[c * nqf_tot + q];
+          }
     }
   return PDH_OK;
 }
@@ -555,7 +746,7 @@ extern "C" int pdh_check_problem(const pdh_problem *p, int32_t row_begin, int32_
   const int rc = pack_problem(nullptr, p, row_begin, row_end, K);
   if (rc == PDH_OK && stats)
     {
-      stats[0] = (int64_t)K.own_agg.size();
+      stats[0] = (int64_t)K.n_owned;
       stats[1] = (int64_t)K.it_own.size();
       stats[2] = (int64_t)K.vq_w.size();
       stats[3] = (int64_t)K.ap_wself.size();
@@ -567,6 +758,26 @@ extern "C" int pdh_check_problem(const pdh_problem *p, int32_t row_begin, int32_
   return rc;
 }
 
+// Host-only: per-peer sizes of the ghost-block exchange of a description (what pdh_exchange_layout reports after
+// pdh_set_problem_local in PDH_EXCHANGE_GHOST mode) - lets the multi-rank logic be checked on machines without a GPU.
+extern "C" int pdh_check_exchange(const pdh_problem *p, int32_t row_begin, int32_t row_end, int n_ranks, int64_t *send_count,
+                                  int64_t *recv_count)
+{
+  Packed K;
+  g_err_noctx.clear();
+  const int rc = pack_problem(nullptr, p, row_begin, row_end, K, PDH_EXCHANGE_GHOST);
+  if (rc != PDH_OK)
+    return rc;
+  if (n_ranks < (int)K.send_count.size() || !send_count || !recv_count)
+    return fail(nullptr, PDH_EINVAL, "n_ranks is smaller than the number of ranks in agg_rank, or an output is NULL");
+  for (int r = 0; r < n_ranks; ++r)
+    {
+      send_count[r] = r < (int)K.send_count.size() ? K.send_count[r] : 0;
+      recv_count[r] = r < (int)K.recv_count.size() ? K.recv_count[r] : 0;
+    }
+  return PDH_OK;
+}
+
 extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end)
 {
   if (!ctx)
@@ -575,7 +786,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_problem(ctx);
   Packed K;
-  int rc = pack_problem(ctx, p, row_begin, row_end, K);
+  int rc = pack_problem(ctx, p, row_begin, row_end, K, ctx->exchange_mode);
   if (rc != PDH_OK)
     return rc;
 
@@ -618,10 +829,28 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   PDH_UP(K.it_nbr_slot, it_nbr_slot)
   PDH_UP(K.it_pos_t, it_pos_t)
 #undef PDH_UP
+  ctx->problem_ghost = ctx->exchange_mode == PDH_EXCHANGE_GHOST;
+  ctx->n_send = K.n_send;
+  ctx->n_recv = K.n_recv;
+  ctx->send_count = K.send_count;
+  ctx->recv_count = K.recv_count;
+  ctx->n_r21 = (int)K.r21_src.size();
+  ctx->n_r22 = (int)K.r22_slot.size();
+  if (ctx->problem_ghost)
+    {
+      if ((rc = upload(ctx, K.r21_src, &ctx->d_r21_src)) != PDH_OK || (rc = upload(ctx, K.r21_dst, &ctx->d_r21_dst)) != PDH_OK ||
+          (rc = upload(ctx, K.r21_rlen, &ctx->d_r21_rlen)) != PDH_OK || (rc = upload(ctx, K.r22_ptr, &ctx->d_r22_ptr)) != PDH_OK ||
+          (rc = upload(ctx, K.r22_src, &ctx->d_r22_src)) != PDH_OK || (rc = upload(ctx, K.r22_slot, &ctx->d_r22_slot)) != PDH_OK)
+        {
+          free_problem(ctx);
+          return rc;
+        }
+    }
   D.vq_stride = (int64_t)K.vq_w.size();
   D.ap_stride = (int64_t)K.ap_wself.size();
   void *dv = nullptr;
-  hipError_t e = hipMalloc(&dv, std::max<int64_t>(K.n_values, 1) * sizeof(double));
+  // the send region of the ghost-block exchange sits behind the values: the kernels address it like more rows
+  hipError_t e = hipMalloc(&dv, std::max<int64_t>(K.n_values + K.n_send, 1) * sizeof(double));
   if (e != hipSuccess)
     {
       free_problem(ctx);
@@ -630,7 +859,8 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   ctx->allocs.push_back(dv);
   D.values = static_cast<double *>(dv);
   ctx->n_values = K.n_values;
-  ctx->n_owned = (int)K.own_agg.size();
+  ctx->n_owned = K.n_owned;
+  ctx->n_diag_slots = (int)K.own_agg.size();
   ctx->n_items = (int)K.it_own.size();
   ctx->n_vq = (int64_t)K.vq_w.size();
   ctx->n_ap = (int64_t)K.ap_wself.size();
@@ -643,7 +873,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   ctx->face_runs.clear();
   for (size_t r = 0; r < K.run_ap.size(); ++r)
     ctx->face_runs.push_back({K.run_ap[r], K.run_fq[r], K.run_cnt[r], K.run_bdry[r]});
-  ctx->n_rows_owned = (int64_t)K.own_agg.size() * K.n;
+  ctx->n_rows_owned = (int64_t)K.n_owned * K.n;
   ctx->n_agg_total = p->n_agg;
   {
     // executed work: k-steps of 4 points per chunk (64 points in k_diag for NT >= 3, else 32; 32 in k_offdiag)
@@ -746,9 +976,9 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(e0, sd));
   if (ctx->use_moment(0))
-    PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_owned, sd));
+    PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_diag_slots, sd));
   else
-    PDH_HIP(ctx, fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_owned, ctx->lds_diag, sd));
+    PDH_HIP(ctx, fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_diag_slots, ctx->lds_diag, sd));
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(e1, sd));
   // coupling blocks
@@ -765,6 +995,76 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
       PDH_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
       PDH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
+  return PDH_OK;
+}
+
+extern "C" hipError_t pdh_launch_ghost_apply(const PdhDev *P, const double *recv, int n_r21, const int64_t *r21_src,
+                                             const int64_t *r21_dst, const int32_t *r21_rlen, int n_r22, const int64_t *r22_ptr,
+                                             const int64_t *r22_src, const int32_t *r22_slot, hipStream_t stream);
+
+extern "C" int pdh_set_exchange_mode(pdh_ctx *ctx, int mode)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (mode != PDH_EXCHANGE_NONE && mode != PDH_EXCHANGE_GHOST)
+    return fail(ctx, PDH_EINVAL, "mode must be PDH_EXCHANGE_NONE or PDH_EXCHANGE_GHOST");
+  ctx->exchange_mode = mode; // takes effect at the next pdh_set_problem*
+  return PDH_OK;
+}
+
+extern "C" int pdh_exchange_layout(pdh_ctx *ctx, int n_ranks, int64_t *send_count, int64_t *recv_count)
+{
+  if (!ctx || !ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "no problem resident");
+  if (!ctx->problem_ghost)
+    return fail(ctx, PDH_ESTATE, "the resident problem was not set in PDH_EXCHANGE_GHOST mode");
+  if (n_ranks < (int)ctx->send_count.size() || !send_count || !recv_count)
+    return fail(ctx, PDH_EINVAL, "n_ranks is smaller than the number of ranks in agg_rank, or an output is NULL");
+  for (int r = 0; r < n_ranks; ++r)
+    {
+      send_count[r] = r < (int)ctx->send_count.size() ? ctx->send_count[r] : 0;
+      recv_count[r] = r < (int)ctx->recv_count.size() ? ctx->recv_count[r] : 0;
+    }
+  return PDH_OK;
+}
+
+extern "C" int pdh_exchange_get_send(pdh_ctx *ctx, double *d_send)
+{
+  if (!ctx || !ctx->has_problem || !ctx->problem_ghost)
+    return fail(ctx, PDH_ESTATE, "no problem resident in PDH_EXCHANGE_GHOST mode");
+  if (ctx->n_send == 0)
+    return PDH_OK;
+  if (!d_send)
+    return fail(ctx, PDH_EINVAL, "d_send is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, hipMemcpyAsync(d_send, ctx->dev.values + ctx->n_values, ctx->n_send * sizeof(double), hipMemcpyDeviceToDevice,
+                              ctx->stream));
+  return PDH_OK;
+}
+
+extern "C" int pdh_exchange_apply(pdh_ctx *ctx, const double *d_recv)
+{
+  if (!ctx || !ctx->has_problem || !ctx->problem_ghost)
+    return fail(ctx, PDH_ESTATE, "no problem resident in PDH_EXCHANGE_GHOST mode");
+  if (ctx->n_recv == 0)
+    return PDH_OK;
+  if (!d_recv)
+    return fail(ctx, PDH_EINVAL, "d_recv is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, pdh_launch_ghost_apply(&ctx->dev, d_recv, ctx->n_r21, ctx->d_r21_src, ctx->d_r21_dst, ctx->d_r21_rlen, ctx->n_r22,
+                                      ctx->d_r22_ptr, ctx->d_r22_src, ctx->d_r22_slot, ctx->stream));
+  return PDH_OK;
+}
+
+// Run the kernels on a stream of the caller (e.g. the framework's current stream, so that collectives issued there are
+// ordered with the assembly without host synchronisation).  NULL restores the context's own stream.
+extern "C" int pdh_set_stream(pdh_ctx *ctx, void *stream)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
   return PDH_OK;
 }
 
@@ -794,6 +1094,19 @@ extern "C" int pdh_assemble(pdh_ctx *ctx, double *values)
   int rc = pdh_assemble_device(ctx);
   if (rc != PDH_OK)
     return rc;
+  PDH_HIP(ctx, hipMemcpyAsync(values, ctx->dev.values, ctx->n_values * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PDH_OK;
+}
+
+// Copy of the CSR values as they stand in HBM (after pdh_assemble_device / pdh_exchange_apply), without re-assembling.
+extern "C" int pdh_copy_values(pdh_ctx *ctx, double *values)
+{
+  if (!ctx || !ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "no problem resident");
+  if (!values)
+    return fail(ctx, PDH_EINVAL, "values is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
   PDH_HIP(ctx, hipMemcpyAsync(values, ctx->dev.values, ctx->n_values * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PDH_OK;

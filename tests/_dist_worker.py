@@ -69,6 +69,18 @@ def main():
     lof = loc.local_of()
     assert np.array_equal(la["dof_offset"], ga["dof_offset"][lof])
     assert np.array_equal(la["agg_rank"] == rank, (la["dof_offset"] >= r0) & (la["dof_offset"] < r1))
+    # ghost-block exchange variant: what this rank sends to a peer is what the peer expects from it (block order is derived
+    # on both sides from the global dof numbers of the cut faces; only the sizes can be checked without a GPU)
+    sc, rc_ = (C.c_int64 * world)(), (C.c_int64 * world)()
+    assert lib.pdh_check_exchange(C.byref(loc.c), r0, r1, world, sc, rc_) == 0, lib.pdh_last_error(None)
+    send = torch.tensor(list(sc), dtype=torch.int64)
+    expect_recv = torch.zeros(world, dtype=torch.int64)
+    dist.all_to_all_single(expect_recv, send)
+    assert torch.equal(expect_recv, torch.tensor(list(rc_), dtype=torch.int64)), (expect_recv, list(rc_))
+    tot_sent = send.sum().clone()
+    dist.all_reduce(tot_sent)  # (with the id() < id() rule every cut face is owned by the lower rank: the last rank sends nothing)
+    assert int(send[rank]) == 0 and (world == 1 or int(tot_sent) > 0)
+    assert int(send.sum()) % (n * n) == 0
     # the local description must not be accepted for another rank's range
     if world > 1:
         o0, o1 = row_range(ah.n_agglomerates, n, (rank + 1) % world, world)

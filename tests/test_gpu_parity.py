@@ -794,14 +794,15 @@ def test_rank_local_descriptions_reproduce_the_global_rows(basis, p, vname, dist
         for r in range(world):
             r0, r1 = splits[r], splits[r + 1]
             loc = ah.flatten_local(pvar, r0, r1, diag_first, True, row_splits=splits)
-            assert loc.c.n_agg < nA
+            assert loc.c.n_agg <= nA and loc.c.local == 1
             ctx = pa.Context(0)
             ctx.set_problem(loc, r0, r1)
             v = ctx.assemble()
             ctx.close()
             want = gvals[grp[r0]:grp[r1]]
             assert v.shape == want.shape
-            assert np.max(np.abs(v - want)) <= 1e-14 * np.max(np.abs(gvals))
+            # blocks of cut faces are contracted from the other side (and faces may be visited in another order): rounding
+            assert np.max(np.abs(v - want)) <= 1e-13 * np.max(np.abs(gvals))
     # Epetra order: rows sorted by local column id
     for r in range(world):
         r0, r1 = splits[r], splits[r + 1]
@@ -822,3 +823,68 @@ def test_rank_local_descriptions_reproduce_the_global_rows(basis, p, vname, dist
         assert np.max(np.abs(got - dense_ref[r0:r1])) <= TOL * np.max(np.abs(ref))
         if r > 0:  # a ghost block with a smaller global number sits behind the owned blocks
             assert any(np.any(np.diff(l2g[ci_l[rp_l[i]:rp_l[i + 1]]]) < 0) for i in range(r1 - r0))
+
+
+@pytest.mark.parametrize("basis,p,vname,dist,world,alg", [("dgq", 2, "dr", 0.1, 3, "auto"), ("dgq", 3, "poisson", 0.0, 2, "moment"),
+                                                          ("dgq", 3, "adm", 0.1, 4, "direct"), ("dgp", 2, "poisson", 0.15, 4, "auto")])
+def test_ghost_block_exchange_equals_owner_computes_rows(basis, p, vname, dist, world, alg):
+    """The reference's distributed scheme (include/poly_utils.h:1930-1992, 2134-2194: the owner of a cut face assembles M11,
+    M12, M21, M22 and ships M21 / M22) as a selectable variant: W contexts on one device play the ranks, the transport is a
+    device-to-device copy here (bench.py uses RCCL all-to-all).  Rows must equal owner-computes-rows and the oracle."""
+    import torch
+    import polydeal_amd as pa
+    from polydeal_amd.partition import row_range
+
+    grid, ah, fe, pvar, oah, ovar = _mirror_pair(3, 3 if p < 3 else 2, 2, basis, p, p + 1, vname, dist)
+    n, nA, N = fe.n_dofs_per_cell, ah.n_agglomerates, ah.n_dofs
+    orp, oci, ref = po.assemble_csr(oah, ovar, diag_first=True)
+    splits = [row_range(nA, n, r, world)[0] for r in range(world)] + [N]
+    for diag_first in (True, False):
+        if not diag_first:
+            orp, oci, ref = po.assemble_csr(oah, ovar, diag_first=False)
+        ctxs, sends, recvs, lay = [], [], [], []
+        for r in range(world):
+            loc = ah.flatten_local(pvar, splits[r], splits[r + 1], diag_first, False, row_splits=splits)
+            c = pa.Context(0)
+            c.set_algorithm(alg)
+            c.set_exchange_mode("ghost")
+            c.set_problem(loc, splits[r], splits[r + 1])
+            sc, rc = c.exchange_layout(world)
+            lay.append((sc, rc))
+            sends.append(torch.zeros(max(sum(sc), 1), dtype=torch.float64, device="cuda"))
+            recvs.append(torch.full((max(sum(rc), 1),), np.nan, dtype=torch.float64, device="cuda"))
+            ctxs.append(c)
+        n_cut_blocks = sum(sum(l[0]) for l in lay) // (n * n)
+        assert n_cut_blocks > 0
+        for r in range(world):
+            for s_ in range(world):
+                assert lay[r][0][s_] == lay[s_][1][r]  # what r sends to s is what s expects from r
+        for r, c in enumerate(ctxs):
+            c.assemble_device()
+            c.exchange_get_send(sends[r].data_ptr())
+            c.synchronize()
+        for r in range(world):  # the transport: segment (r -> s) of r's send buffer becomes segment (from r) of s's recv buffer
+            so = np.concatenate([[0], np.cumsum(lay[r][0])])
+            for s_ in range(world):
+                ro = np.concatenate([[0], np.cumsum(lay[s_][1])])
+                if lay[r][0][s_]:
+                    recvs[s_][ro[r]:ro[r + 1]] = sends[r][so[s_]:so[s_ + 1]]
+        torch.cuda.synchronize()
+        got = []
+        for r, c in enumerate(ctxs):
+            c.exchange_apply(recvs[r].data_ptr())
+            got.append(c.values())
+            c.close()
+        got = np.concatenate(got)
+        assert got.shape == ref.shape
+        assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref))
+        # against owner-computes-rows on the same descriptions
+        own = []
+        for r in range(world):
+            loc = ah.flatten_local(pvar, splits[r], splits[r + 1], diag_first, False, row_splits=splits)
+            c = pa.Context(0)
+            c.set_algorithm(alg)
+            c.set_problem(loc, splits[r], splits[r + 1])
+            own.append(c.assemble())
+            c.close()
+        assert np.max(np.abs(got - np.concatenate(own))) <= 1e-13 * np.max(np.abs(ref))
