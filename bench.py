@@ -75,12 +75,18 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     t0 = time.time()
     grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1)
     var = make_variant(pa, args.variant, fe)
-    flat = ah.flatten(var, diag_first=True, with_colind=False)
     n = fe.n_dofs_per_cell
     n_agg = ah.n_agglomerates
     # contiguous dof-row ranges of whole polytopes per rank (strong scaling)
     from polydeal_amd.partition import row_range
     r0, r1 = row_range(n_agg, n, rank, world)
+    splits = [row_range(n_agg, n, r, world)[0] for r in range(world)] + [n_agg * n]
+    if world > 1:
+        # every rank describes ONLY its own polytopes + their ghost neighbours (pdh_problem.local = 1), like an MPI rank of
+        # the reference (source/agglomeration_handler.cc:1026-1091)
+        flat = ah.flatten_local(var, r0, r1, diag_first=True, with_colind=False, row_splits=splits)
+    else:
+        flat = ah.flatten(var, diag_first=True, with_colind=False)
     ctx = pa.Context(local_rank)
     ctx.set_algorithm(alg)
     # The library overlaps its two kernels on large problems (two streams, ~3 % faster).  The timed region runs them one
@@ -134,8 +140,74 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     vals = ctx.assemble() if stats["n_values"] <= 64_000_000 else None
     chk = float(np.sum(vals)) if vals is not None else None
     ctx.close()
+    ghost = None
+    if world > 1 and args.exchange_extra and alg == "auto":
+        try:
+            ghost = run_ghost_exchange(pa, torch, dist, args, flat, r0, r1, rank, world, local_rank, steps, warmup, vals)
+        except Exception as exc:  # the measured default path above must not be lost to a failure of the extra variant
+            ghost = {"error": repr(exc)}
     return dict(n_dofs=ah.n_dofs, n_agg=n_agg, n=n, dt=dt, kms=kms, nl=nl, stats=stats, work=work, mfma=mfma,
-                t_setup=t_setup, nnz=flat.nnz, checksum=chk, alg=alg_used, dt_overlap=dt_overlap)
+                t_setup=t_setup, nnz=flat.nnz if world == 1 else None, checksum=chk, alg=alg_used, dt_overlap=dt_overlap,
+                ghost=ghost, local=world > 1)
+
+
+def run_ghost_exchange(pa, torch, dist, args, flat, r0, r1, rank, world, local_rank, steps, warmup, ref_vals):
+    """The same step in the reference's distributed form (include/poly_utils.h:1930-1992, 2134-2194): the owner of a face cut
+    by the partition computes M21 / M22 and ships them; transport = one all-to-all-v over RCCL (xGMI) per step."""
+    import numpy as np
+    on_cpu = args.rehearse_on_one_gpu  # gloo rehearsal: the transport goes through host memory
+    ctx = pa.Context(local_rank)
+    ctx.set_overlap(False)
+    ctx.set_exchange_mode("ghost")
+    # one stream for kernels and collective: the library launches on a torch stream, the all-to-all is issued under it
+    tstream = torch.cuda.Stream()
+    if not on_cpu:
+        ctx.set_stream(tstream.cuda_stream)
+    ctx.set_problem(flat, r0, r1)
+    sc, rc = ctx.exchange_layout(world)
+    send = torch.zeros(max(sum(sc), 1), dtype=torch.float64, device="cuda")
+    recv = torch.zeros(max(sum(rc), 1), dtype=torch.float64, device="cuda")
+
+    def step():
+        ctx.assemble_device()
+        ctx.exchange_get_send(send.data_ptr())
+        if on_cpu:
+            ctx.synchronize()
+            hs, hr = send[:sum(sc)].cpu(), torch.zeros(sum(rc), dtype=torch.float64)
+            dist.all_to_all_single(hr, hs, output_split_sizes=rc, input_split_sizes=sc)
+            recv[:sum(rc)].copy_(hr)
+            torch.cuda.synchronize()
+        else:
+            with torch.cuda.stream(tstream):
+                dist.all_to_all_single(recv[:sum(rc)], send[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc)
+        ctx.exchange_apply(recv.data_ptr())
+
+    for _ in range(max(1, warmup)):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    err = None
+    if ref_vals is not None:
+        got = ctx.values()
+        err = float(np.max(np.abs(got - ref_vals)) / max(np.max(np.abs(ref_vals)), 1e-300))
+    tot = torch.tensor([float(sum(sc))], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
+    dist.all_reduce(tot)
+    ctx.close()
+    return {"ms_per_step": 1e3 * float(t.item()) / steps, "bytes_exchanged_per_step": 8.0 * float(tot.item()),
+            "max_rel_diff_vs_owner_computes_rows": err,
+            "transport": "gloo through host memory (rehearsal)" if on_cpu else "torch.distributed all_to_all_single (RCCL)"}
 
 
 def effective_cpus():
@@ -210,6 +282,8 @@ def main():
                          "(roofline.overlapped_ms_per_step); off by default so that a rocprofv3 trace of the default command "
                          "contains serialised launches only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exchange-extra", dest="exchange_extra", action="store_false",
+                    help="N>1: skip the second measurement with the reference's ghost-block exchange (M21/M22 shipped over RCCL)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses device 0 and the gloo backend "
                          "(exercises the partitioned code path; the numbers are meaningless)")
@@ -288,7 +362,8 @@ def main():
         ms_step = 1e3 * r["dt"] / args.steps
         value = r["n_dofs"] / (r["dt"] / args.steps)
         w = r["work"]
-        frac_rows = r["stats"]["n_owned_agg"] / r["n_agg"]
+        # rank 0's algorithmic work: of the global description scaled to its share, or of its own local description
+        frac_rows = 1.0 if r["local"] else r["stats"]["n_owned_agg"] / r["n_agg"]
         # "moment": both kinds of block through pdh_moment.h; "mixed": diagonal blocks moment, coupling blocks direct
         names = ("k_mdiag" if r["alg"] in ("moment", "mixed") else "k_diag", "k_moffdiag" if r["alg"] == "moment" else "k_offdiag")
         moment = r["alg"] != "direct"
@@ -369,9 +444,10 @@ def main():
                                       "FE_DGQ" if args.fe == "dgq" else "FE_AggloDGP", args.degree, r["n"],
                                       args.degree + 1, {"poisson": "examples/poisson.cc", "diffusion_reaction": "examples/diffusion_reaction.cc",
                                                         "assemble_dg_matrix": "PolyUtils::assemble_dg_matrix"}[args.variant],
-                                      r["n_dofs"], r["nnz"]),
+                                      r["n_dofs"], r["nnz"] if r["nnz"] is not None else -1),
                        "algorithm": r["alg"],
-                       "parallelism": "rows(polytopes) split in %d contiguous ranges, owner-computes-rows, no collective" % world},
+                       "parallelism": "rows(polytopes) split in %d contiguous ranges, owner-computes-rows, no collective" % world,
+                       "exchange_variant": r["ghost"]},
             "roofline": roof,
             "cpu_baseline": cpu,
             "extra": extra,

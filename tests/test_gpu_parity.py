@@ -831,9 +831,32 @@ def test_ghost_block_exchange_equals_owner_computes_rows(basis, p, vname, dist, 
     """The reference's distributed scheme (include/poly_utils.h:1930-1992, 2134-2194: the owner of a cut face assembles M11,
     M12, M21, M22 and ships M21 / M22) as a selectable variant: W contexts on one device play the ranks, the transport is a
     device-to-device copy here (bench.py uses RCCL all-to-all).  Rows must equal owner-computes-rows and the oracle."""
-    import torch
+    import ctypes as C
     import polydeal_amd as pa
     from polydeal_amd.partition import row_range
+
+    hip = C.CDLL("libamdhip64.so")  # the runtime the library itself is linked to (torch is not needed for device buffers)
+
+    class DevBuf:
+        def __init__(self, n_doubles, fill):
+            self.n, self.p = max(n_doubles, 1), C.c_void_p()
+            assert hip.hipMalloc(C.byref(self.p), C.c_size_t(8 * self.n)) == 0
+            self.put(np.full(self.n, fill))
+
+        def put(self, a, off=0):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            assert hip.hipMemcpy(C.c_void_p(self.p.value + 8 * off), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0
+
+        def get(self):
+            out = np.empty(self.n)
+            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self.p, C.c_size_t(out.nbytes), 2) == 0
+            return out
+
+        def data_ptr(self):
+            return self.p.value
+
+        def __del__(self):
+            hip.hipFree(self.p)
 
     grid, ah, fe, pvar, oah, ovar = _mirror_pair(3, 3 if p < 3 else 2, 2, basis, p, p + 1, vname, dist)
     n, nA, N = fe.n_dofs_per_cell, ah.n_agglomerates, ah.n_dofs
@@ -851,8 +874,8 @@ def test_ghost_block_exchange_equals_owner_computes_rows(basis, p, vname, dist, 
             c.set_problem(loc, splits[r], splits[r + 1])
             sc, rc = c.exchange_layout(world)
             lay.append((sc, rc))
-            sends.append(torch.zeros(max(sum(sc), 1), dtype=torch.float64, device="cuda"))
-            recvs.append(torch.full((max(sum(rc), 1),), np.nan, dtype=torch.float64, device="cuda"))
+            sends.append(DevBuf(sum(sc), 0.0))
+            recvs.append(DevBuf(sum(rc), np.nan))
             ctxs.append(c)
         n_cut_blocks = sum(sum(l[0]) for l in lay) // (n * n)
         assert n_cut_blocks > 0
@@ -864,12 +887,12 @@ def test_ghost_block_exchange_equals_owner_computes_rows(basis, p, vname, dist, 
             c.exchange_get_send(sends[r].data_ptr())
             c.synchronize()
         for r in range(world):  # the transport: segment (r -> s) of r's send buffer becomes segment (from r) of s's recv buffer
-            so = np.concatenate([[0], np.cumsum(lay[r][0])])
+            so = np.concatenate([[0], np.cumsum(lay[r][0])]).astype(np.int64)
+            hs = sends[r].get()
             for s_ in range(world):
-                ro = np.concatenate([[0], np.cumsum(lay[s_][1])])
+                ro = np.concatenate([[0], np.cumsum(lay[s_][1])]).astype(np.int64)
                 if lay[r][0][s_]:
-                    recvs[s_][ro[r]:ro[r + 1]] = sends[r][so[s_]:so[s_ + 1]]
-        torch.cuda.synchronize()
+                    recvs[s_].put(hs[so[s_]:so[s_ + 1]], off=int(ro[r]))
         got = []
         for r, c in enumerate(ctxs):
             c.exchange_apply(recvs[r].data_ptr())
