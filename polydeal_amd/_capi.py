@@ -46,7 +46,7 @@ EXPORTS = [
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
     "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values", "pdh_set_algorithm", "pdh_algorithm_in_use", "pdh_set_overlap",
     "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
-    "pdh_check_exchange", "pdh_copy_values",
+    "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows",
 ]
 
 _lib = None
@@ -77,6 +77,7 @@ def _bind(lib):
     lib.pdh_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.pdh_check_exchange.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, C.c_int, P(C.c_int64), P(C.c_int64)]
     lib.pdh_copy_values.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdh_check_rows.argtypes = [P(pdh_problem), C.c_int32, C.c_int32]
     lib.pdh_shape_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
@@ -233,7 +234,7 @@ class Context:
 
     def set_algorithm(self, alg):
         """'auto' | 'direct' (MFMA contraction over the points) | 'moment' (Legendre moments + sum factorisation)."""
-        self._chk(self.lib.pdh_set_algorithm(self.h, {"auto": 0, "direct": 1, "moment": 2}[alg]))
+        self._chk(self.lib.pdh_set_algorithm(self.h, {"auto": 0, "direct": 1, "moment": 2, "rows": 4}[alg]))
 
     def set_exchange_mode(self, mode):
         """'none': owner-computes-rows (no matrix traffic); 'ghost': the reference's scheme - the owner of a cut face ships
@@ -265,7 +266,7 @@ class Context:
         rc = self.lib.pdh_algorithm_in_use(self.h)
         if rc < 0:
             self._chk(rc)
-        return {1: "direct", 2: "moment", 3: "mixed"}[rc]
+        return {1: "direct", 2: "moment", 3: "mixed", 4: "rows"}[rc]
 
     def set_profiling(self, on=True):
         self._chk(self.lib.pdh_set_profiling(self.h, int(on)))

@@ -39,6 +39,9 @@ extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_
                                        const double *pts, int64_t pts_stride, double *out, hipStream_t stream);
 
 extern "C" hipError_t pdh_launch_moment(int n1d, int which, const PdhDev *P, const double *mtab, int count, hipStream_t stream);
+#include "pdh_rows_tables.h"
+extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const double *mtab, int count, hipStream_t stream);
+extern "C" int pdh_rows_max_faces(void);
 extern "C" int pdh_moment_table_doubles(int n1d);
 
 static pdh_launch_fn g_launch[PDH_N_GROUPS] = {pdh_launch_g0, pdh_launch_g1, pdh_launch_g2, pdh_launch_g3,
@@ -111,6 +114,10 @@ struct pdh_ctx
   int algorithm = PDH_ALG_AUTO;
   int basis = 0;
   double *d_mtab = nullptr;
+  // row kernel (pdh_rows.h): available when every face of every owned polytope is an axis-aligned plane (FE_DGQ(3), 3-D)
+  bool rows_ok = false;
+  PdhRows rows;
+  bool use_rows() const { return rows_ok && d_mtab && (algorithm == PDH_ALG_AUTO || algorithm == PDH_ALG_ROWS); }
   // which form each of the two launches uses: [0] diagonal blocks, [1] coupling blocks
   bool use_moment(int kind) const
   {
@@ -118,6 +125,8 @@ struct pdh_ctx
       return false;
     if (algorithm == PDH_ALG_MOMENT)
       return true;
+    if (algorithm == PDH_ALG_ROWS)
+      return false;
     // auto: where the moment form was measured faster than the MFMA contraction (profiles/README.md): FE_DGQ(3) both
     // kinds (8.5 -> 4.7 ms), FE_DGQ(2) the diagonal blocks only (BASELINE configs[3]: 9.7 -> 5.6 ms; its coupling blocks
     // 4.3 ms direct vs 6.4 ms moment)
@@ -260,6 +269,10 @@ struct Packed
   std::vector<double> vq_x, vq_w, ap_x, ap_n, ap_wself, ap_wcross, ap_sig;
   std::vector<int64_t> vq_src, run_ap, run_fq;
   std::vector<int32_t> run_cnt, run_bdry;
+  // per run (owned slots only, same order): owning slot, neighbour polytope (-1 boundary) and the ascending rank of the
+  // neighbour's block in the slot's rows, penalty as stored per point - input of the row kernel's face table (pdh_rows.h)
+  std::vector<int32_t> run_slot, run_nbr, run_blk;
+  std::vector<double> run_sig;
   int64_t n_values = 0;
   int n_owned = 0; // own_agg / ap_ptr / ... may carry pseudo slots behind the owned ones (ghost-block exchange)
   // ghost-block exchange (PDH_EXCHANGE_GHOST): doubles per peer rank, and where the received blocks go
@@ -578,6 +591,16 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           K.run_fq.push_back(qb);
           K.run_cnt.push_back((int32_t)(qe - qb));
           K.run_bdry.push_back(other < 0 ? 1 : 0);
+          K.run_slot.push_back(slot);
+          K.run_nbr.push_back(other);
+          {
+            int brank = -1;
+            for (size_t u = 0; u < blocks.size(); ++u)
+              if (other >= 0 && blocks[u].second == other)
+                brank = (int)u;
+            K.run_blk.push_back(brank);
+          }
+          K.run_sig.push_back(other < 0 ? 0.5 * p->face_sigma[f] : p->face_sigma[f]);
           if (other >= 0)
             {
               const int ooff = colnum(other);
@@ -737,6 +760,141 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
     }
   return PDH_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// Face tables of the row kernel (pdh_rows.h).  Eligible: 3-D FE_DGQ(3), no exchange variant, and for every owned polytope
+// at most pdh_rows_max_faces() faces, each lying in ONE axis-aligned plane (agglomerates of Cartesian cells).  The test
+// is made on the packed points themselves, so any description qualifies that has the geometry - there is no mesh-type
+// flag.  Planarity is required to a few ulp: the kernel evaluates the bases at ONE plane coordinate per face (the mean).
+// ---------------------------------------------------------------------------------------------------
+struct RowsHost
+{
+  std::vector<int32_t> fr_ptr, fr_pcnt, fr_nbr, fr_axis, fr_blk;
+  std::vector<int64_t> fr_pbeg;
+  std::vector<double> fr_coord, fr_sigma, fr_nsign;
+};
+static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R, std::string *why = nullptr)
+{
+  auto no = [&](const char *m) {
+    if (why)
+      *why = m;
+    return false;
+  };
+  if (p->dim != 3 || p->basis != PDH_BASIS_DGQ || p->degree != 3 || K.n != 64)
+    return no("not 3-D FE_DGQ(3)");
+  if ((int)K.own_agg.size() != K.n_owned) // pseudo slots of the exchange variant
+    return no("exchange variant");
+  const int64_t nap = (int64_t)K.ap_wself.size();
+  const size_t nruns = K.run_ap.size();
+  const int maxf = pdh_rows_max_faces();
+  // Planes of every run.  An interior face must lie in one plane.  The boundary "face" of a polytope collects ALL its
+  // domain-boundary sub-faces (reference source/agglomeration_handler.cc:1575-1613), up to three planes at a corner: it
+  // becomes one entry per plane over the same point range, and the kernel masks the points of the other planes.
+  struct Plane { int axis; double sign, coord; };
+  std::vector<std::vector<Plane>> planes(nruns);
+  for (size_t r = 0; r < nruns; ++r)
+    {
+      const int64_t b = K.run_ap[r];
+      const int cnt = K.run_cnt[r];
+      if (cnt <= 0)
+        return no("empty face");
+      const int a = K.own_agg[K.run_slot[r]];
+      std::vector<double> sum;
+      std::vector<int> num;
+      for (int q = 0; q < cnt; ++q)
+        {
+          int c = -1;
+          for (int d = 0; d < 3; ++d)
+            if (std::fabs(K.ap_n[d * nap + b + q]) > 0.5)
+              c = d;
+          if (c < 0)
+            return no("normal not axis-aligned");
+          const double sg = K.ap_n[c * nap + b + q] > 0 ? 1.0 : -1.0;
+          for (int d = 0; d < 3; ++d)
+            {
+              const double nd = K.ap_n[d * nap + b + q];
+              if (d == c ? std::fabs(nd - sg) > 1e-14 : std::fabs(nd) > 1e-14)
+                return no("normal not axis-aligned");
+            }
+          const double x = K.ap_x[c * nap + b + q];
+          const double h = p->bbox[(size_t)a * 6 + 3 + c] - p->bbox[(size_t)a * 6 + c];
+          size_t k = 0;
+          for (; k < planes[r].size(); ++k)
+            if (planes[r][k].axis == c && planes[r][k].sign == sg && std::fabs(planes[r][k].coord - x) <= 1e-9 * h)
+              break;
+          if (k == planes[r].size())
+            {
+              planes[r].push_back({c, sg, x});
+              sum.push_back(0.0);
+              num.push_back(0);
+            }
+          sum[k] += x;
+          num[k] += 1;
+        }
+      if (K.run_nbr[r] >= 0 && planes[r].size() != 1)
+        return no("an interior face spans more than one plane");
+      // the kernel evaluates the bases at ONE coordinate per plane (the mean): the points must agree with it to a few ulp
+      for (size_t k = 0; k < planes[r].size(); ++k)
+        planes[r][k].coord = sum[k] / num[k];
+      for (int q = 0; q < cnt; ++q)
+        for (const Plane &pl : planes[r])
+          {
+            const double x = K.ap_x[pl.axis * nap + b + q];
+            const double h = p->bbox[(size_t)a * 6 + 3 + pl.axis] - p->bbox[(size_t)a * 6 + pl.axis];
+            const bool mine = K.ap_n[pl.axis * nap + b + q] * pl.sign > 0.5 && std::fabs(x - pl.coord) <= 1e-9 * h;
+            if (mine && std::fabs(x - pl.coord) > 2e-15 * (std::fabs(pl.coord) + h))
+              return no("face not planar");
+          }
+    }
+  // runs are stored slot by slot; order the faces of a slot: boundary first, then ascending block rank
+  R.fr_ptr.assign(1, 0);
+  size_t r = 0;
+  for (int sl = 0; sl < K.n_owned; ++sl)
+    {
+      std::vector<size_t> idx;
+      for (; r < nruns && K.run_slot[r] == sl; ++r)
+        idx.push_back(r);
+      std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return K.run_blk[x] < K.run_blk[y]; });
+      int nf = 0;
+      for (size_t t : idx)
+        for (const Plane &pl : planes[t])
+          {
+            R.fr_pbeg.push_back(K.run_ap[t]);
+            R.fr_pcnt.push_back(K.run_cnt[t]);
+            R.fr_nbr.push_back(K.run_nbr[t]);
+            R.fr_axis.push_back(pl.axis);
+            R.fr_blk.push_back(K.run_blk[t]);
+            R.fr_coord.push_back(pl.coord);
+            R.fr_sigma.push_back(K.run_sig[t]);
+            R.fr_nsign.push_back(pl.sign);
+            if (K.run_nbr[t] >= 0)
+              ++nf; // the LDS layout of the kernel limits the INTERIOR faces (coupling moments kept per face)
+          }
+      if (nf > maxf)
+        return no("too many faces on a polytope");
+      R.fr_ptr.push_back((int32_t)R.fr_pbeg.size());
+    }
+  return r == nruns ? true : no("run bookkeeping");
+}
+
+// Host-only: 1 if the row kernel (PDH_ALG_ROWS) applies to this description and row range, 0 if not (pdh_last_error(NULL)
+// says why), < 0 on an invalid description.
+extern "C" int pdh_check_rows(const pdh_problem *p, int32_t row_begin, int32_t row_end)
+{
+  Packed K;
+  g_err_noctx.clear();
+  const int rc = pack_problem(nullptr, p, row_begin, row_end, K);
+  if (rc != PDH_OK)
+    return rc;
+  RowsHost R;
+  std::string why;
+  if (build_rows_tables(p, K, R, &why))
+    return 1;
+  g_err_noctx = why;
+  return 0;
+}
+
 
 // Host-only validation (no GPU needed): runs exactly the checks of pdh_set_problem.
 extern "C" int pdh_check_problem(const pdh_problem *p, int32_t row_begin, int32_t row_end, int64_t *stats)
@@ -914,6 +1072,25 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
         }
       ctx->d_mtab = static_cast<double *>(dm);
     }
+  ctx->rows_ok = false;
+  if (ctx->d_mtab && !ctx->problem_ghost)
+    {
+      RowsHost RH;
+      if (build_rows_tables(p, K, RH))
+        {
+          PdhRows &R = ctx->rows;
+          if ((rc = upload(ctx, RH.fr_ptr, &R.fr_ptr)) != PDH_OK || (rc = upload(ctx, RH.fr_pbeg, &R.fr_pbeg)) != PDH_OK ||
+              (rc = upload(ctx, RH.fr_pcnt, &R.fr_pcnt)) != PDH_OK || (rc = upload(ctx, RH.fr_nbr, &R.fr_nbr)) != PDH_OK ||
+              (rc = upload(ctx, RH.fr_axis, &R.fr_axis)) != PDH_OK || (rc = upload(ctx, RH.fr_blk, &R.fr_blk)) != PDH_OK ||
+              (rc = upload(ctx, RH.fr_coord, &R.fr_coord)) != PDH_OK || (rc = upload(ctx, RH.fr_sigma, &R.fr_sigma)) != PDH_OK ||
+              (rc = upload(ctx, RH.fr_nsign, &R.fr_nsign)) != PDH_OK)
+            {
+              free_problem(ctx);
+              return rc;
+            }
+          ctx->rows_ok = true;
+        }
+    }
   ctx->has_problem = true;
   ctx->ev_used = 0;
   return PDH_OK;
@@ -923,8 +1100,8 @@ extern "C" int pdh_set_algorithm(pdh_ctx *ctx, int algorithm)
 {
   if (!ctx)
     return fail(nullptr, PDH_EINVAL, "ctx is NULL");
-  if (algorithm != PDH_ALG_AUTO && algorithm != PDH_ALG_DIRECT && algorithm != PDH_ALG_MOMENT)
-    return fail(ctx, PDH_EINVAL, "algorithm must be PDH_ALG_AUTO, PDH_ALG_DIRECT or PDH_ALG_MOMENT");
+  if (algorithm != PDH_ALG_AUTO && algorithm != PDH_ALG_DIRECT && algorithm != PDH_ALG_MOMENT && algorithm != PDH_ALG_ROWS)
+    return fail(ctx, PDH_EINVAL, "algorithm must be PDH_ALG_AUTO, PDH_ALG_DIRECT, PDH_ALG_MOMENT or PDH_ALG_ROWS");
   ctx->algorithm = algorithm;
   return PDH_OK;
 }
@@ -933,6 +1110,8 @@ extern "C" int pdh_algorithm_in_use(pdh_ctx *ctx)
 {
   if (!ctx || !ctx->has_problem)
     return fail(ctx, PDH_ESTATE, "no problem resident");
+  if (ctx->use_rows())
+    return PDH_ALG_ROWS;
   const bool d = ctx->use_moment(0), o = ctx->use_moment(1);
   return d && o ? PDH_ALG_MOMENT : (d || o ? PDH_ALG_MIXED : PDH_ALG_DIRECT);
 }
@@ -955,6 +1134,30 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
   const int dim = ctx->dev.dim, n1d = ctx->dev.n1d, nt = ctx->NT, lb = ctx->LB;
   if (ctx->algorithm == PDH_ALG_MOMENT && !ctx->d_mtab)
     return fail(ctx, PDH_EUNSUPPORTED, "the moment form exists for 3-D bases of degree 1..3 only");
+  if (ctx->algorithm == PDH_ALG_ROWS && !ctx->use_rows())
+    return fail(ctx, PDH_EUNSUPPORTED, "the row kernel needs 3-D FE_DGQ(3), axis-aligned planar faces and no exchange variant");
+  if (ctx->use_rows())
+    { // one launch writes everything; reported as kernel 0, kernel 1 takes no time
+      hipEvent_t r0 = nullptr, r1 = nullptr, z0 = nullptr, z1 = nullptr;
+      if (ctx->profiling)
+        {
+          r0 = ctx->next_event();
+          r1 = ctx->next_event();
+          z0 = ctx->next_event();
+          z1 = ctx->next_event();
+          if (!r0 || !r1 || !z0 || !z1)
+            return fail(ctx, PDH_EDEVICE, "hipEventCreate failed");
+          PDH_HIP(ctx, hipEventRecord(r0, ctx->stream));
+        }
+      PDH_HIP(ctx, pdh_launch_rows(&ctx->dev, &ctx->rows, ctx->d_mtab, ctx->n_owned, ctx->stream));
+      if (ctx->profiling)
+        {
+          PDH_HIP(ctx, hipEventRecord(r1, ctx->stream));
+          PDH_HIP(ctx, hipEventRecord(z0, ctx->stream));
+          PDH_HIP(ctx, hipEventRecord(z1, ctx->stream));
+        }
+      return PDH_OK;
+    }
   hipEvent_t e0 = nullptr, e1 = nullptr, f0 = nullptr, f1 = nullptr;
   if (ctx->profiling)
     {
@@ -1392,8 +1595,8 @@ extern "C" int pdh_kernel_work(pdh_ctx *ctx, int64_t *mfma_instr)
 {
   if (!ctx || !ctx->has_problem || !mfma_instr)
     return fail(ctx, PDH_ESTATE, "no problem resident");
-  mfma_instr[0] = ctx->use_moment(0) ? 0 : ctx->mfma_diag; // counted for the direct form only
-  mfma_instr[1] = ctx->use_moment(1) ? 0 : ctx->mfma_offdiag;
+  mfma_instr[0] = (ctx->use_moment(0) || ctx->use_rows()) ? 0 : ctx->mfma_diag; // counted for the direct form only
+  mfma_instr[1] = (ctx->use_moment(1) || ctx->use_rows()) ? 0 : ctx->mfma_offdiag;
   return PDH_OK;
 }
 

@@ -1,5 +1,6 @@
 // pdh_moment.hip — instantiations and launcher of the moment-form kernels (pdh_moment.h): 3-D, degree <= 3.
 #include "pdh_moment.h"
+#include "pdh_rows.h"
 
 // which: 0 = diagonal blocks (count = owned polytopes), 1 = coupling blocks (count = interior-face items)
 extern "C" hipError_t pdh_launch_moment(int n1d, int which, const PdhDev *P, const double *mtab, int count, hipStream_t stream)
@@ -42,3 +43,14 @@ extern "C" int pdh_moment_table_doubles(int n1d)
     }
   return 0;
 }
+
+// Row kernel (pdh_rows.h): one wave per owned polytope writes all blocks of its rows; FE_DGQ(3), axis-aligned planar faces.
+extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const double *mtab, int count, hipStream_t stream)
+{
+  if (count <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL((pdhr::k_rows<4>), dim3((unsigned)count), dim3(PDH_WAVE), pdhr::lds_doubles_rows<4>() * sizeof(double), stream,
+                     *P, *R, mtab, count);
+  return hipGetLastError();
+}
+extern "C" int pdh_rows_max_faces(void) { return pdhr::MAXF; }

@@ -1,0 +1,635 @@
+// pdh_rows.h — the row kernel: FE_DGQ(3) in 3-D on polytopes whose faces are axis-aligned planes (agglomerates of
+// Cartesian cells: every configuration of BASELINE.json but the piston mesh).  ONE wave per owned polytope computes and
+// writes ALL values of the polytope's 64 rows - the diagonal block and every coupling block - as complete, aligned
+// 512-byte pieces.  It replaces the pair k_mdiag / k_moffdiag (pdh_moment.h) where it applies; what is computed is
+// unchanged (reference include/poly_utils.h:2040-2084 volume + boundary, :1870-1926 interface blocks), only the order
+// of summation differs, so results agree with the other forms to rounding (tests/test_gpu_parity.py runs all three
+// against the oracle).
+//
+// Why a separate kernel.  On a face that lies in the plane x_c = const with normal +-e_c
+//   * the face moments of the diagonal block (pdh_moment.h) are rank one in direction c:
+//       M[a0,a1,a2] = L_{a_c}(zeta) (x) M2[a_i,a_j]   - 49 x 2 numbers from a 2-D moment GEMM (2 MFMA per 4 points
+//       instead of 26), expanded into the 3-D tensors with 14 FMAs per lane;
+//   * a coupling block is a Kronecker product:  A[P,Q]_(k,l) = C[k_c,l_c] * S[(k_i,k_j),(l_i,l_j)]  with ONE 4x4 matrix
+//       C = (1/2 s B'_k(zeta^P)/h^P - sigma B_k(zeta^P)) B_l(zeta^Q) - 1/2 s B_k(zeta^P) B'_l(zeta^Q)/h^Q
+//     and ONE 16x16 matrix S = sum_q w B^P_ki B^P_kj B^Q_li B^Q_lj, obtained from 49 2-D moments by two small
+//     contractions - a few hundred FMAs per face instead of the three-stage contraction of 4 x 343 moments.
+//   The arithmetic of a coupling block shrinks so much that a polytope can afford to compute the blocks of BOTH sides of
+//   each of its faces itself ("owner computes rows" taken literally).  Then one wave holds every value of a row and
+//   the stores can be laid out for the memory system instead of for the arithmetic: in deal.II's diagonal-first rows
+//   the blocks left of the diagonal start one double late, so a block-wise writer leaves two partial 128-byte lines per
+//   block and row (2.7 TB/s measured against 6.1 TB/s for whole lines, profiles/r01_probe_store_pattern.txt).  Here every
+//   store instruction writes positions 64 m .. 64 m + 63 of a row: lane 0 carries the last column of the block before
+//   (or the diagonal entry), lanes 1..63 the first 63 columns of block m.
+//
+// Phases (one wave, LDS region W is re-used from phase to phase):
+//   P1 volume moments on the f64 MFMA                       (MomentAcc of pdh_moment.h, unchanged)
+//   P2 per face: 2-D moments (weights: w sigma, -w n_c/2 for the diagonal block in P's frame; w for the coupling block in
+//      the per-direction shorter frame F, see pdh_moment.h), expansion into this lane's rows of the S / N_c tensors
+//   P3 carry into the own block's piece: last column of the block left of it
+//   P4 diagonal block: three-stage contraction on the MFMA (pdh_moment.h), rows written slab by slab
+//   P5 coupling blocks in ascending column order: tables -> S, C -> 64 products per lane -> stores
+#pragma once
+#include "pdh_moment.h"
+
+#include "pdh_rows_tables.h"
+
+namespace pdhr
+{
+using pdh::static_for;
+using pdhm::d2_t;
+
+constexpr int MAXF = 8;  // INTERIOR faces per polytope the LDS layout provides for
+constexpr int FREC = 33; // face record: L_i[8], (s_t L_j)[3][8], pad (odd stride)
+constexpr int FCH = 32;  // face points per chunk
+constexpr int FSTEP = 4 * FREC * 8;
+
+template <int N1D>
+constexpr int lds_doubles_rows()
+{
+  using M = pdhm::MT<N1D>;
+  using A = pdhm::MomentAcc<N1D>;
+  constexpr int w_rec = A::VCH * A::VREC > FCH * FREC ? A::VCH * A::VREC : FCH * FREC;
+  constexpr int w_con = 4 * 2 * 2 * 64 + 2 * 4 * 64; // T1B + T2B
+  constexpr int w = w_rec > w_con ? w_rec : w_con;
+  return 3 * M::LTAB + MAXF * 64 + 64 /* diagv */ + 16 /* C */ + 16 /* coef */ + w;
+}
+
+// multi-index digits of a function index i = k0 + 4 k1 + 16 k2: digit of axis c, and u = k_i + 4 k_j of the other two (i < j)
+__device__ __forceinline__ int digit_c(int i, int c) { return (i >> (2 * c)) & 3; }
+__device__ __forceinline__ int digits_t(int i, int c)
+{
+  const int k0 = i & 3, k1 = (i >> 2) & 3, k2 = (i >> 4) & 3;
+  return c == 0 ? (k1 + 4 * k2) : (c == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
+}
+
+template <int N1D>
+__global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhRows Rw, const double *__restrict__ mt, const int n_owned)
+{
+  static_assert(N1D == 4, "the row kernel is written for FE_DGQ(3)");
+  using M = pdhm::MT<N1D>;
+  using Acc = pdhm::MomentAcc<N1D>;
+  constexpr int NA = M::NA, NAP = M::NAP, NG = M::NG, DIM = 3;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x;
+  if (slot >= n_owned)
+    return;
+  const int agg = P.own_agg[slot];
+  double lo[DIM], ih[DIM];
+  for (int c = 0; c < DIM; ++c)
+    {
+      lo[c] = P.bbox[(int64_t)agg * 2 * DIM + c];
+      ih[c] = 1.0 / (P.bbox[(int64_t)agg * 2 * DIM + DIM + c] - lo[c]);
+    }
+  double *tabE = lds, *tabD = lds + M::LTAB, *tabF = lds + 2 * M::LTAB;
+  double *M2c = lds + 3 * M::LTAB;  // [MAXF][8][8] coupling moments of every face
+  double *diagv = M2c + MAXF * 64;  // [64] diagonal entries A[R,R]
+  double *Cbuf = diagv + 64;        // [4][4]
+  double *coefL = Cbuf + 16;        // [4][4] monomial coefficients of the 1-D basis (centred variable)
+  double *W = coefL + 16;           // phase-local
+  for (int t = lane; t < 3 * M::TAB; t += PDH_WAVE)
+    lds[(t / NAP) * M::RS + t % NAP] = mt[t];
+  if (lane < 16)
+    coefL[lane] = P.tab.coef[lane >> 2][lane & 3];
+
+  const bool act = lane < NA * NA;
+  const int a0 = act ? lane / NA : 0, a1 = act ? lane % NA : 0;
+  const int64_t rbase = P.row_base[slot];
+  const int rlen = P.row_len[slot];
+  const int L = P.diag_L[slot];
+  const int m0 = L >> 6;
+  const int f_begin = Rw.fr_ptr[slot], f_end = Rw.fr_ptr[slot + 1];
+  int f_int = f_begin; // first interior face (boundary entries come first); coupling moments are kept per interior face
+  while (f_int < f_end && Rw.fr_blk[f_int] < 0)
+    ++f_int;
+
+  // ================= P1: volume moments ========================================================================
+  Acc ma;
+  ma.init(lane);
+  ma.init_addr(W, lane);
+  {
+    const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
+    double px[DIM] = {0.0, 0.0, 0.0}, pw = 0.0;
+    auto fetch = [&](int64_t base) {
+      const bool on = base + lane < qe;
+      for (int c = 0; c < DIM; ++c)
+        px[c] = on ? P.vq_x[c * P.vq_stride + base + lane] : 0.0;
+      pw = on ? P.vq_w[base + lane] : 0.0;
+    };
+    fetch(qb);
+    for (int64_t base = qb; base < qe; base += Acc::VCH)
+      {
+        const int cnt = (int)((qe - base < Acc::VCH) ? (qe - base) : Acc::VCH);
+        __syncthreads();
+        {
+          double xu[DIM] = {0.5, 0.5, 0.5}, w = 0.0;
+          if (lane < cnt)
+            {
+              for (int c = 0; c < DIM; ++c)
+                xu[c] = (px[c] - lo[c]) * ih[c];
+              w = pw;
+            }
+          fetch(base + Acc::VCH);
+          Acc::write_volume_record(W + lane * Acc::VREC, xu, w);
+        }
+        __syncthreads();
+        ma.volume_chunk_full(); // dead points carry zero weights
+      }
+  }
+
+  // ================= P2: faces ==================================================================================
+  double accS[NAP], accN[DIM][NAP];
+  for (int a = 0; a < NAP; ++a)
+    {
+      accS[a] = 0.0;
+      for (int c = 0; c < DIM; ++c)
+        accN[c][a] = 0.0;
+    }
+  {
+    // operand addresses of the 2-D moment GEMM: rows a_i (two blocks, replicated), columns (t, a_j)
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    const unsigned wbase = (unsigned)(uintptr_t)(lds_cchar *)reinterpret_cast<const char *>(W);
+    const int kq = lane >> 4, blk = (lane >> 2) & 3, idx = lane & 3;
+    const unsigned rb = wbase + kq * FREC * 8;
+    const unsigned adA = rb + (4 * (blk & 1) + idx) * 8;
+    const unsigned adB0 = rb + (8 + 4 * blk + idx) * 8;
+    const unsigned adB1 = rb + (8 + 4 * ((blk + 1) & 3) + idx) * 8;
+    const unsigned adB2 = rb + (24 + 4 * ((blk == 1 || blk == 2) ? 1 : 0) + idx) * 8;
+    const int half = lane >> 5, pt = lane & 31;
+    for (int f = f_begin; f < f_end; ++f)
+      {
+        const int fl = f - f_int;
+        const int c = Rw.fr_axis[f];
+        const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
+        const int nbr = Rw.fr_nbr[f];
+        const int64_t pb = Rw.fr_pbeg[f], pe = pb + Rw.fr_pcnt[f];
+        // frames of the two tangential directions for the coupling moments: the shorter of the two box intervals
+        double lo_t[2] = {ti == 0 ? lo[0] : lo[1], tj == 1 ? lo[1] : lo[2]};
+        double ih_t[2] = {ti == 0 ? ih[0] : ih[1], tj == 1 ? ih[1] : ih[2]};
+        double loF[2] = {lo_t[0], lo_t[1]}, ihF[2] = {ih_t[0], ih_t[1]};
+        bool sep = false;
+        if (nbr >= 0)
+          {
+            const double *bq = P.bbox + (int64_t)nbr * 2 * DIM;
+            const double lq[2] = {bq[ti], bq[tj]};
+            const double iq[2] = {1.0 / (bq[DIM + ti] - bq[ti]), 1.0 / (bq[DIM + tj] - bq[tj])};
+            for (int d = 0; d < 2; ++d)
+              if (iq[d] > ih_t[d])
+                {
+                  loF[d] = lq[d];
+                  ihF[d] = iq[d];
+                  sep = true;
+                }
+          }
+        const int npass = (nbr >= 0 && sep) ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass)
+          {
+            const double flo = half == 0 ? (pass ? loF[0] : lo_t[0]) : (pass ? loF[1] : lo_t[1]);
+            const double fih = half == 0 ? (pass ? ihF[0] : ih_t[0]) : (pass ? ihF[1] : ih_t[1]);
+            const double *px = P.ap_x + (int64_t)(half == 0 ? ti : tj) * P.ap_stride;
+            const double *pn = P.ap_n + (int64_t)c * P.ap_stride;
+            const double *pc = P.ap_x + (int64_t)c * P.ap_stride;
+            // a boundary run may hold the points of several planes (one entry per plane): the others get zero weights
+            const double nsg = Rw.fr_nsign[f], xpl = Rw.fr_coord[f];
+            const double ptol = 1e-9 / (c == 0 ? ih[0] : (c == 1 ? ih[1] : ih[2]));
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+            for (int64_t base = pb; base < pe; base += FCH)
+              {
+                const bool on = base + pt < pe;
+                const int64_t q = on ? base + pt : pb;
+                // half 0: L_i; half 1: the three weighted copies of L_j
+                const double xh = (px[q] - flo) * fih;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                if (half == 1 && on && pn[q] * nsg > 0.5 && fabs(pc[q] - xpl) <= ptol)
+                  {
+                    const double wS = P.ap_wself[q], wC = P.ap_wcross[q];
+                    if (pass == 0)
+                      {
+                        s0 = wS * P.ap_sig[q];
+                        s1 = -0.5 * wS * pn[q];
+                        s2 = (nbr >= 0 && !sep) ? wC : 0.0;
+                      }
+                    else
+                      s2 = wC;
+                  }
+                double Lh[NA];
+                pdhm::legendre01<NA>(on ? xh : 0.5, Lh);
+                __syncthreads();
+                double *r = W + pt * FREC;
+                if (half == 0)
+                  {
+                    for (int a = 0; a < NA; ++a)
+                      r[a] = Lh[a];
+                    r[NA] = 0.0;
+                  }
+                else
+                  {
+                    for (int a = 0; a < NA; ++a)
+                      {
+                        r[8 + a] = s0 * Lh[a];
+                        r[16 + a] = s1 * Lh[a];
+                        r[24 + a] = s2 * Lh[a];
+                      }
+                    r[8 + NA] = 0.0;
+                    r[16 + NA] = 0.0;
+                    r[24 + NA] = 0.0;
+                  }
+                __syncthreads();
+                // 8 steps of 4 points, operands one step ahead of the MFMAs (see MomentAcc::volume_chunk_full)
+                double ra[2], rb0[2], rb1[2], rb2[2];
+                Acc::template lds_read<0>(ra[0], adA);
+                Acc::template lds_read<0>(rb0[0], adB0);
+                Acc::template lds_read<0>(rb1[0], adB1);
+                Acc::template lds_read<0>(rb2[0], adB2);
+                static_for<0, FCH / 4>([&](auto s_) {
+                  constexpr int s = s_;
+                  constexpr int cur = s & 1, nxt = (s + 1) & 1;
+                  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[cur]), "+v"(rb0[cur]), "+v"(rb1[cur]), "+v"(rb2[cur]));
+                  if constexpr (s + 1 < FCH / 4)
+                    {
+                      Acc::template lds_read<(s + 1) * FSTEP>(ra[nxt], adA);
+                      Acc::template lds_read<(s + 1) * FSTEP>(rb0[nxt], adB0);
+                      Acc::template lds_read<(s + 1) * FSTEP>(rb1[nxt], adB1);
+                      Acc::template lds_read<(s + 1) * FSTEP>(rb2[nxt], adB2);
+                    }
+                  __builtin_amdgcn_sched_barrier(0);
+                  acc0 = pdh::mfma4(ra[cur], rb0[cur], acc0);
+                  acc1 = pdh::mfma4(ra[cur], rb1[cur], acc1);
+                  acc2 = pdh::mfma4(ra[cur], rb2[cur], acc2);
+                  __builtin_amdgcn_sched_barrier(0);
+                });
+              }
+            // flush: D lane (i, blk, j) = rows a_i = 4 (blk & 1) + i; acc0: column block blk, acc1: block blk + 1, acc2: t = 2
+            __syncthreads();
+            double *M2 = W; // [3][8][8]
+            {
+              const int i = lane >> 4, j = lane & 3;
+              const int ai = 4 * (blk & 1) + i;
+              const int b1 = (blk + 1) & 3;
+              M2[(blk >> 1) * 64 + ai * 8 + 4 * (blk & 1) + j] = acc0;
+              M2[(b1 >> 1) * 64 + ai * 8 + 4 * (b1 & 1) + j] = acc1;
+              M2[2 * 64 + ai * 8 + 4 * ((blk == 1 || blk == 2) ? 1 : 0) + j] = acc2;
+            }
+            __syncthreads();
+            if (pass == 0)
+              {
+                // expansion into this lane's (a0, a1) rows of the 3-D tensors: M[a0,a1,a2] += L_{a_c}(zeta) M2[a_i][a_j]
+                const double zeta = (Rw.fr_coord[f] - (c == 0 ? lo[0] : (c == 1 ? lo[1] : lo[2]))) * (c == 0 ? ih[0] : (c == 1 ? ih[1] : ih[2]));
+                double Lc[NA];
+                pdhm::legendre01<NA>(zeta, Lc);
+                if (c == 2)
+                  {
+                    const double mS = M2[0 * 64 + a0 * 8 + a1], mN = M2[1 * 64 + a0 * 8 + a1];
+                    for (int a = 0; a < NA; ++a)
+                      {
+                        accS[a] += Lc[a] * mS;
+                        accN[2][a] += Lc[a] * mN;
+                      }
+                  }
+                else
+                  {
+                    // c == 1: (i, j) = (0, 2): factor L_{a1}(zeta), row a0;  c == 0: (i, j) = (1, 2): factor L_{a0}(zeta), row a1
+                    const int asel = c == 1 ? a1 : a0, arow = c == 1 ? a0 : a1;
+                    double lc = Lc[0];
+                    static_for<1, NA>([&](auto a_) {
+                      constexpr int a = a_;
+                      lc = asel == a ? Lc[a] : lc;
+                    });
+                    for (int a = 0; a < NA; ++a)
+                      {
+                        const double mS = M2[0 * 64 + arow * 8 + a], mN = M2[1 * 64 + arow * 8 + a];
+                        accS[a] += lc * mS;
+                        if (c == 1)
+                          accN[1][a] += lc * mN;
+                        else
+                          accN[0][a] += lc * mN;
+                      }
+                  }
+              }
+            if (nbr >= 0 && (pass == 1 || !sep) && fl >= 0 && fl < MAXF)
+              M2c[fl * 64 + lane] = M2[2 * 64 + lane];
+          }
+      }
+  }
+
+  // ---- S and C of one face into W (tables for the tangential directions, T, S) ----------------------------------------
+  double *tabQ = W;               // [2][PAIRS][RS]
+  double *Tst = W + 2 * M::LTAB;  // [16 pairs (k_j,l_j)][8]
+  double *Sbuf = Tst + 128;       // [16 u][16 v]
+  auto build_S = [&](int f) {
+    const int fl = f - f_int;
+    const int c = Rw.fr_axis[f];
+    const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
+    const int nbr = Rw.fr_nbr[f];
+    const double *bq = P.bbox + (int64_t)nbr * 2 * DIM;
+    bool same[2];
+    {
+      const int dd = (lane >> 4) & 1;
+      const int d = dd == 0 ? ti : tj;
+      const double lo_d = d == 0 ? lo[0] : (d == 1 ? lo[1] : lo[2]), ih_d = d == 0 ? ih[0] : (d == 1 ? ih[1] : ih[2]);
+      const double loq_d = bq[d], ihq_d = 1.0 / (bq[DIM + d] - bq[d]);
+      const bool same_d = (loq_d == lo_d) && (ihq_d == ih_d);
+      same[0] = __shfl(same_d ? 1 : 0, 0) != 0;
+      same[1] = __shfl(same_d ? 1 : 0, 16) != 0;
+      __syncthreads();
+      if (lane < 32 && !same_d)
+        {
+          // E^Q_d[k,l,a] = <B_k(xi^P(t)) B_l(xi^Q(t)), L_a>, frame = the shorter interval (pdh_moment.h, k_moffdiag)
+          const bool use_q = ihq_d > ih_d;
+          const double loF = use_q ? loq_d : lo_d, ihF = use_q ? ihq_d : ih_d;
+          const double hF = 1.0 / ihF;
+          const double aP = hF * ih_d, bP = (loF - lo_d) * ih_d - 0.5;
+          const double aQ = hF * ihq_d, bQ = (loF - loq_d) * ihq_d - 0.5;
+          const int k = (lane >> 2) & 3, l = lane & 3;
+          double e[NA];
+          for (int a = 0; a < NA; ++a)
+            e[a] = 0.0;
+          for (int gq = 0; gq < NG; ++gq)
+            {
+              const double t = mt[M::OFF_GX + gq];
+              const double xp = aP * t + bP, xq = aQ * t + bQ;
+              double vk = coefL[k * 4 + 3], vl = coefL[l * 4 + 3];
+              for (int m = 2; m >= 0; --m)
+                {
+                  vk = vk * xp + coefL[k * 4 + m];
+                  vl = vl * xq + coefL[l * 4 + m];
+                }
+              const double vv = vk * vl;
+              for (int a = 0; a < NA; ++a)
+                e[a] += vv * mt[M::OFF_GL + a * NG + gq];
+            }
+          double *te = tabQ + dd * M::LTAB + (k * 4 + l) * M::RS;
+          for (int a = 0; a < NA; ++a)
+            te[a] = e[a];
+          te[NA] = 0.0;
+        }
+      __syncthreads();
+    }
+    const double *EQi = same[0] ? tabE : tabQ, *EQj = same[1] ? tabE : (tabQ + M::LTAB);
+    {
+      // T[(k_j,l_j)][alpha] = sum_beta EQj[(k_j,l_j)][beta] M2c[alpha][beta]
+      const int pair = lane & 15;
+      const double *m2 = M2c + fl * 64;
+      double ej[NA];
+      for (int b = 0; b < NA; ++b)
+        ej[b] = EQj[pair * M::RS + b];
+      static_for<0, 2>([&](auto h_) {
+        constexpr int h = h_;
+        const int al = (lane >> 4) + 4 * h;
+        if (al < NA)
+          {
+            double s = 0.0;
+            for (int b = 0; b < NA; ++b)
+              s += ej[b] * m2[al * 8 + b];
+            Tst[pair * 8 + al] = s;
+          }
+      });
+    }
+    __syncthreads();
+    {
+      // S[k_i + 4 k_j][l_i + 4 l_j] = sum_alpha EQi[(k_i,l_i)][alpha] T[(k_j,l_j)][alpha]
+      const int pairI = lane & 15, ki = pairI >> 2, li = pairI & 3;
+      double ei[NA];
+      for (int a = 0; a < NA; ++a)
+        ei[a] = EQi[pairI * M::RS + a];
+      static_for<0, 4>([&](auto r_) {
+        constexpr int r = r_;
+        const int pairJ = (lane >> 4) + 4 * r, kj = pairJ >> 2, lj = pairJ & 3;
+        double s = 0.0;
+        for (int a = 0; a < NA; ++a)
+          s += ei[a] * Tst[pairJ * 8 + a];
+        Sbuf[(ki + 4 * kj) * 16 + li + 4 * lj] = s;
+      });
+    }
+    if (lane < 16)
+      {
+        // C[k][l] = (1/2 s B'_k(zP)/hP - sigma B_k(zP)) B_l(zQ) - 1/2 s B_k(zP) B'_l(zQ)/hQ    (centred variable)
+        const double x = Rw.fr_coord[f];
+        const double lo_c = c == 0 ? lo[0] : (c == 1 ? lo[1] : lo[2]), ih_c = c == 0 ? ih[0] : (c == 1 ? ih[1] : ih[2]);
+        const double ihq_c = 1.0 / (bq[DIM + c] - bq[c]);
+        const double zp = (x - lo_c) * ih_c - 0.5, zq = (x - bq[c]) * ihq_c - 0.5;
+        const int k = lane >> 2, l = lane & 3;
+        double vk = coefL[k * 4 + 3], dk = 0.0, vl = coefL[l * 4 + 3], dl = 0.0;
+        for (int m = 2; m >= 0; --m)
+          {
+            dk = dk * zp + vk;
+            vk = vk * zp + coefL[k * 4 + m];
+            dl = dl * zq + vl;
+            vl = vl * zq + coefL[l * 4 + m];
+          }
+        const double sg = Rw.fr_nsign[f], sig = Rw.fr_sigma[f];
+        Cbuf[lane] = (0.5 * sg * dk * ih_c - sig * vk) * vl - 0.5 * sg * vk * dl * ihq_c;
+      }
+    __syncthreads();
+  };
+  // last column (63: l = (3,3,3)) of the block just built, row R = lane
+  auto last_column = [&](int c) { return Cbuf[digit_c(lane, c) * 4 + 3] * Sbuf[digits_t(lane, c) * 16 + 15]; };
+
+  // ================= P3: carry into the own block's piece ==========================================================
+  const bool shifted = P.diag_first != 0;
+  double carry_own = 0.0;
+  if (shifted && m0 > 0)
+    for (int f = f_begin; f < f_end; ++f)
+      if (Rw.fr_blk[f] == m0 - 1)
+        {
+          __syncthreads();
+          build_S(f);
+          carry_own = last_column(Rw.fr_axis[f]);
+        }
+
+  // ================= P4: diagonal block ============================================================================
+  double accM[NAP];
+  __syncthreads();
+  {
+    // volume accumulators -> W[(a0,a1) row][a2] (scatter of MomentAcc, volume part)
+    const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+    if constexpr (Acc::LAST_ROW)
+      if (j == 0 && blk < 2 && 4 * blk + i < NA)
+        W[(Acc::ROWS - 1) * NA + 4 * blk + i] = ma.accyv;
+    static_for<0, Acc::NFAM>([&](auto a_) {
+      constexpr int a = a_;
+      const int row = 16 * a + 4 * blk + i;
+      if (row < Acc::ROWS)
+        static_for<0, 2>([&](auto r_) {
+          constexpr int r = r_;
+          const int a2 = 4 * ((blk + r) & 1) + j;
+          if (a2 < NA)
+            W[row * NA + a2] = ma.accv[a][r];
+        });
+    });
+  }
+  __syncthreads();
+  for (int a = 0; a < NA; ++a)
+    accM[a] = W[(act ? lane : 0) * NA + a];
+  if (P.reaction_c != 0.0)
+    for (int a = 0; a < NA; ++a)
+      accS[a] += P.reaction_c * accM[a];
+  {
+    double *T1B = W;                  // [4 arrays][2 bf][2 ks][64]
+    double *T2B = W + 4 * 2 * 2 * 64; // [2 ks][4 cf][64]
+    double *rowst = W;                // [16 rows][64 columns] (after stage 3)
+    const double ih0 = ih[0], ih1 = ih[1], ih2 = ih[2];
+    const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
+    const int O = di + 4 * dj + 16 * dblk; // this lane's column in the D layout of stage 3
+    pdhm::T1Off t1o;
+    t1o.init(a0, a1);
+#pragma unroll 1
+    for (int k2 = 0; k2 < 4; ++k2)
+      {
+        __syncthreads();
+        if (act)
+          static_for<0, 4>([&](auto ll_) {
+            constexpr int ll = ll_;
+            const int pr = (k2 * 4 + ll) * M::RS;
+            double g1 = 0.0, ee = 0.0, n0 = 0.0, n1 = 0.0;
+            static_for<0, NA>([&](auto a_) {
+              constexpr int a = a_;
+              const double e = tabE[pr + a];
+              g1 += e * accM[a];
+              ee += (tabD[pr + a] * (ih2 * ih2)) * accM[a] + e * accS[a] + (tabF[pr + a] * ih2) * accN[2][a];
+              n0 += e * accN[0][a];
+              n1 += e * accN[1][a];
+            });
+            pdhm::t1b_store<0, ll>(T1B, t1o, g1);
+            pdhm::t1b_store<1, ll>(T1B, t1o, ee);
+            pdhm::t1b_store<2, ll>(T1B, t1o, n0);
+            pdhm::t1b_store<3, ll>(T1B, t1o, n1);
+          });
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        pdhm::ASet AE, AD, AF;
+        pdhm::load_aset<false>(tabE + zero, M::RS, lane, AE);
+        pdhm::load_aset<false>(tabD + zero, M::RS, lane, AD);
+        pdhm::load_aset<false>(tabF + zero, M::RS, lane, AF);
+        double D3[4][4];
+        for (int c = 0; c < 4; ++c)
+          for (int r = 0; r < 4; ++r)
+            D3[c][r] = 0.0;
+        {
+          __syncthreads();
+          double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = D
+          pdhm::mstage2_term(AE, 0, ih0 * ih0, T1B, lane, D2);
+          pdhm::mstage2_scatter(D2, T2B, lane);
+          __syncthreads();
+          pdhm::mstage3(AD, T2B, lane, D3);
+        }
+        {
+          __syncthreads();
+          double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = E
+          pdhm::mstage2_term(AD, 0, ih1 * ih1, T1B, lane, D2);
+          pdhm::mstage2_term(AE, 1, 1.0, T1B, lane, D2);
+          pdhm::mstage2_term(AF, 3, ih1, T1B, lane, D2);
+          pdhm::mstage2_scatter(D2, T2B, lane);
+          __syncthreads();
+          pdhm::mstage3(AE, T2B, lane, D3);
+        }
+        {
+          __syncthreads();
+          double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = Fs
+          pdhm::mstage2_term(AE, 2, ih0, T1B, lane, D2);
+          pdhm::mstage2_scatter(D2, T2B, lane);
+          __syncthreads();
+          pdhm::mstage3(AF, T2B, lane, D3);
+        }
+        if (!shifted)
+          { // ascending layout: the own block is aligned, a register is a complete row
+            static_for<0, 4>([&](auto cf_) {
+              constexpr int cf = cf_;
+              static_for<0, 4>([&](auto s0_) {
+                constexpr int s0 = s0_;
+                const int R = s0 + 4 * cf + 16 * k2;
+                P.values[rbase + (int64_t)R * rlen + L + O] = D3[cf][s0];
+              });
+            });
+          }
+        else
+          {
+            // diagonal-first layout: piece m0 of row R = [carry | own columns without the diagonal]; the diagonal entry is
+            // position 0 of the row (lane 0 of piece 0: written here if the own block is the first one, else kept for P5)
+            __syncthreads();
+            static_for<0, 4>([&](auto cf_) {
+              constexpr int cf = cf_;
+              static_for<0, 4>([&](auto s0_) {
+                constexpr int s0 = s0_;
+                rowst[(s0 + 4 * cf) * 64 + O] = D3[cf][s0];
+              });
+            });
+            __syncthreads();
+            const int clo = __double2loint(carry_own), chi = __double2hiint(carry_own);
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r)
+              {
+                const int R = r + 16 * k2;
+                const int col = lane == 0 ? R : (lane - 1 + (lane - 1 >= R ? 1 : 0));
+                double v = rowst[r * 64 + col];
+                if (m0 > 0)
+                  {
+                    const double cin = __hiloint2double(__builtin_amdgcn_readlane(chi, R), __builtin_amdgcn_readlane(clo, R));
+                    if (lane == 0)
+                      {
+                        diagv[R] = v;
+                        v = cin;
+                      }
+                  }
+                P.values[rbase + (int64_t)R * rlen + L + lane] = v;
+              }
+          }
+      }
+  }
+
+  // ================= P5: coupling blocks in ascending column order ====================================================
+  {
+    double carry = 0.0; // lane R: the value that lane 0 stores in row R of the next piece
+    bool first_left = true;
+    for (int f = f_begin; f < f_end; ++f)
+      {
+        const int b = Rw.fr_blk[f];
+        if (b < 0)
+          continue;
+        const int c = Rw.fr_axis[f];
+        const bool left = shifted && b < m0;
+        __syncthreads();
+        if (left && first_left)
+          carry = diagv[lane]; // piece 0 starts with the diagonal entry
+        if (left)
+          first_left = false;
+        build_S(f);
+        // this lane's column of the block: shifted pieces hold columns -1 .. 62 (lane 0: the carry)
+        const int jcol = left ? (lane > 0 ? lane - 1 : 0) : lane;
+        const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
+        double Cl[4], sc[16];
+        for (int k = 0; k < 4; ++k)
+          Cl[k] = Cbuf[k * 4 + lc];
+        for (int u = 0; u < 16; ++u)
+          sc[u] = Sbuf[u * 16 + vt];
+        const double next_carry = left ? last_column(c) : 0.0;
+        const int clo = __double2loint(carry), chi = __double2hiint(carry);
+        double *dst = P.values + rbase + 64 * (int64_t)b + lane;
+        auto rows = [&](auto c_) {
+          constexpr int cc = c_;
+          static_for<0, 64>([&](auto R_) {
+            constexpr int R = R_;
+            constexpr int kc = (R >> (2 * cc)) & 3;
+            constexpr int k0 = R & 3, k1 = (R >> 2) & 3, k2 = (R >> 4) & 3;
+            constexpr int u = cc == 0 ? (k1 + 4 * k2) : (cc == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
+            double v = Cl[kc] * sc[u];
+            if (left)
+              {
+                const double cin = __hiloint2double(__builtin_amdgcn_readlane(chi, R), __builtin_amdgcn_readlane(clo, R));
+                v = lane == 0 ? cin : v;
+              }
+            dst[(int64_t)R * rlen] = v;
+          });
+        };
+        if (c == 0)
+          rows(std::integral_constant<int, 0>{});
+        else if (c == 1)
+          rows(std::integral_constant<int, 1>{});
+        else
+          rows(std::integral_constant<int, 2>{});
+        carry = next_carry;
+      }
+  }
+}
+} // namespace pdhr

@@ -1,0 +1,15 @@
+// pdh_rows_tables.h — the PdhRows struct shared by the row kernel (pdh_rows.h, device) and pdh_capi.cpp (host).
+#pragma once
+#include <stdint.h>
+struct PdhRows
+{
+  const int32_t *fr_ptr;   // [n_owned+1] faces of every owned polytope: boundary faces first, then ascending block rank
+  const int64_t *fr_pbeg;  // first own-side point in the ap_* arrays
+  const int32_t *fr_pcnt;  // number of points
+  const int32_t *fr_nbr;   // neighbour polytope, -1 on the boundary
+  const int32_t *fr_axis;  // normal axis c
+  const int32_t *fr_blk;   // ascending rank of the neighbour's block in the row (-1 on the boundary)
+  const double *fr_coord;  // x_c of the plane
+  const double *fr_sigma;  // penalty as stored per point (sigma; sigma/2 on the boundary)
+  const double *fr_nsign;  // +-1: own outward normal along c
+};

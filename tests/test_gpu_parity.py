@@ -601,7 +601,7 @@ def test_moment_form_parity(fe_cls, p, lg, b, dist, varname, diag_first):
     va, used_a = _values(kw, "auto")
     expect = "direct"
     if fe_cls is po.FE_DGQ and p == 3:
-        expect = "moment"
+        expect = "rows" if dist == 0.0 else "moment"  # undistorted: every face an axis-aligned plane -> row kernel
     elif fe_cls is po.FE_DGQ and p == 2:
         expect = "mixed"
     assert used_a == expect
@@ -911,3 +911,120 @@ def test_ghost_block_exchange_equals_owner_computes_rows(basis, p, vname, dist, 
             own.append(c.assemble())
             c.close()
         assert np.max(np.abs(got - np.concatenate(own))) <= 1e-13 * np.max(np.abs(ref))
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Row kernel (csrc/pdh_rows.h): FE_DGQ(3) on polytopes with axis-aligned planar faces; one wave writes all blocks of a
+# polytope's rows (Kronecker form of the coupling blocks, rank-one face moments, whole-line stores).
+# ---------------------------------------------------------------------------------------------------------------------
+def _staircase_groups(grid):
+    """Irregular agglomerates of Cartesian cells (L-shapes, a 1x1x2 bar, singletons): every polytopal face run is still
+    planar?  No - an L-shape touches a neighbour along two planes.  Used to check that such problems FALL BACK."""
+    c = lambda i, j, k: int(grid.ijk_to_cell[(i, j, k)])
+    groups = [sorted([c(0, 0, 0), c(1, 0, 0), c(0, 1, 0)]), sorted([c(1, 1, 0), c(1, 1, 1)])]
+    used = {x for g in groups for x in g}
+    groups += [[x] for x in range(grid.n_cells) if x not in used]
+    return groups
+
+
+def _box_groups(grid, n):
+    """Axis-aligned boxes of different sizes tiling an n^3 grid: a 2x2x2 box, 1x1x2 bars, 2x1x1 bars, singletons - all
+    faces planar, neighbours of different size (frames differ: second record pass, per-face tables)."""
+    c = lambda i, j, k: int(grid.ijk_to_cell[(i, j, k)])
+    groups, used = [], set()
+
+    def box(i0, j0, k0, di, dj, dk):
+        g = sorted(c(i, j, k) for i in range(i0, i0 + di) for j in range(j0, j0 + dj) for k in range(k0, k0 + dk))
+        assert not (set(g) & used)
+        used.update(g)
+        groups.append(g)
+
+    box(0, 0, 0, 2, 2, 2)
+    box(2, 0, 0, 2, 1, 2)  # +x block split along y
+    box(2, 1, 0, 2, 1, 2)
+    box(0, 2, 0, 1, 2, 2)  # +y block split along x
+    box(1, 2, 0, 1, 2, 2)
+    box(0, 0, 2, 2, 1, 2)  # +z block split along y
+    box(0, 1, 2, 2, 1, 2)
+    box(2, 2, 0, 2, 2, 1)  # split along z
+    box(2, 2, 1, 2, 2, 1)
+    box(2, 0, 2, 2, 2, 2)
+    box(0, 2, 2, 2, 2, 2)
+    box(2, 2, 2, 1, 2, 2)
+    box(3, 2, 2, 1, 2, 2)
+    assert len(used) == grid.n_cells
+    # a planar-faced but non-convex set would still need one plane per neighbour: boxes guarantee it
+    return groups
+
+
+ROWS_CASES = [
+    # lg, block (0: mixed boxes), variant, diag_first, world
+    (2, 2, "poisson", True, 1), (2, 2, "dr", False, 1), (3, 2, "adm", True, 3), (2, 1, "test", True, 1),
+    (2, 0, "poisson", True, 1), (2, 0, "dr", False, 2), (1, 2, "poisson", True, 1),
+]
+
+
+@pytest.mark.parametrize("lg,b,vname,diag_first,world", ROWS_CASES)
+def test_row_kernel_parity(lg, b, vname, diag_first, world):
+    import polydeal_amd as pa
+    from polydeal_amd.partition import row_range
+
+    fe = po.FE_DGQ(3, 3)
+    grid = po.hyper_cube_refined(3, 0.0, 1.0, lg)
+    ah = po.AgglomerationHandler(grid)
+    for g in (po.block_agglomerates(grid, b) if b else _box_groups(grid, 4)):
+        ah.define_agglomerate(g)
+    ah.initialize_fe_values(4, 4)
+    ah.distribute_agglomerated_dofs(fe)
+    var = variant(vname, fe)
+    kw = flatten(ah, var, diag_first=diag_first)
+    ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
+    sc = np.max(np.abs(ref))
+    vr, used = _values(kw, "rows")
+    assert used == "rows"
+    assert np.max(np.abs(vr - ref)) <= TOL * sc, np.max(np.abs(vr - ref)) / sc
+    vm, used_m = _values(kw, "moment")
+    assert used_m == "moment" and np.max(np.abs(vr - vm)) <= 1e-13 * sc
+    # per block, not only against the global maximum
+    n = 64
+    blk = np.abs(ref).reshape(-1, n).max(axis=1)
+    err = np.abs(vr - ref).reshape(-1, n).max(axis=1)
+    assert np.all(err <= 1e-11 * np.maximum(blk, 1e-3 * sc))
+    if world > 1:
+        parts = []
+        for r in range(world):
+            rb, re = row_range(ah.n_agglomerates, n, r, world)
+            v, u = _values(kw, "rows", rb, re)
+            assert u == "rows"
+            parts.append(v)
+        assert np.max(np.abs(np.concatenate(parts) - ref)) <= TOL * sc
+
+
+def test_row_kernel_falls_back_when_faces_are_not_planar():
+    """AUTO must not pick the row kernel on distorted grids or when a polytopal face spans two planes; forcing it fails."""
+    import polydeal_amd as pa
+
+    fe = po.FE_DGQ(3, 3)
+    for mode in ("distorted", "staircase"):
+        grid = po.hyper_cube_refined(3, 0.0, 1.0, 2)
+        if mode == "distorted":
+            grid.distort(1e-9, seed=1)  # even a tiny perturbation: the kernel evaluates ONE plane coordinate per face
+        ah = po.AgglomerationHandler(grid)
+        for g in (po.block_agglomerates(grid, 2) if mode == "distorted" else _staircase_groups(grid)):
+            ah.define_agglomerate(g)
+        ah.initialize_fe_values(4, 4)
+        ah.distribute_agglomerated_dofs(fe)
+        var = po.variant_poisson_example(fe)
+        kw = flatten(ah, var)
+        ref = po.assemble_csr(ah, var)[2]
+        va, used = _values(kw, "auto")
+        assert used == "moment"
+        assert np.max(np.abs(va - ref)) <= TOL * np.max(np.abs(ref))
+        prob = pa.Problem(**kw)
+        ctx = pa.Context(0)
+        ctx.set_problem(prob)
+        ctx.set_algorithm("rows")
+        with pytest.raises(pa.PdhError):
+            ctx.assemble()
+        ctx.close()
