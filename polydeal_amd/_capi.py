@@ -52,8 +52,25 @@ EXPORTS = [
 _lib = None
 
 
+class _Tolerant:
+    """Attribute access that ignores entry points an OLDER build of the library lacks (tools/ab_bench.py loads two builds)."""
+
+    class _Sink:
+        argtypes = restype = None
+
+    def __init__(self, lib):
+        object.__setattr__(self, "_lib", lib)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._lib, name)
+        except AttributeError:
+            return _Tolerant._Sink()
+
+
 def _bind(lib):
     P = C.POINTER
+    real, lib = lib, _Tolerant(lib)
     lib.pdh_create.argtypes = [P(C.c_void_p), C.c_int]
     lib.pdh_destroy.argtypes = [C.c_void_p]
     lib.pdh_destroy.restype = None
@@ -89,7 +106,7 @@ def _bind(lib):
     lib.pdh_kernel_work.argtypes = [C.c_void_p, P(C.c_int64)]
     lib.pdh_check_problem.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, P(C.c_int64)]
     lib.pdh_version.restype = C.c_char_p
-    return lib
+    return real
 
 
 def load_library(path=None):

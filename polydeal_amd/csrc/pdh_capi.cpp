@@ -871,7 +871,7 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
             if (K.run_nbr[t] >= 0)
               ++nf; // the LDS layout of the kernel limits the INTERIOR faces (coupling moments kept per face)
           }
-      if (nf > maxf)
+      if (nf > maxf || (int)R.fr_pbeg.size() - R.fr_ptr.back() > 64)
         return no("too many faces on a polytope");
       R.fr_ptr.push_back((int32_t)R.fr_pbeg.size());
     }

@@ -34,6 +34,12 @@
 
 #include "pdh_rows_tables.h"
 
+// experiment switches (tools/ab_bench.py; never defined in the shipped build): -DPDHR_EXP=1 no coupling blocks (P5),
+// 2 no diagonal block (P4), 3 no faces (P2), 4 no volume (P1), 5 P5 without its global stores
+#ifndef PDHR_EXP
+#define PDHR_EXP 0
+#endif
+
 namespace pdhr
 {
 using pdh::static_for;
@@ -76,14 +82,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   if (slot >= n_owned)
     return;
   const int agg = P.own_agg[slot];
-  double lo[DIM], ih[DIM];
-  for (int c = 0; c < DIM; ++c)
-    {
-      lo[c] = P.bbox[(int64_t)agg * 2 * DIM + c];
-      ih[c] = 1.0 / (P.bbox[(int64_t)agg * 2 * DIM + DIM + c] - lo[c]);
-    }
+  // bounding box as scalars (indexed by a run-time axis through sel3: an array would be demoted to scratch memory)
+  const double lo0 = P.bbox[(int64_t)agg * 6 + 0], lo1 = P.bbox[(int64_t)agg * 6 + 1], lo2 = P.bbox[(int64_t)agg * 6 + 2];
+  const double ih0 = 1.0 / (P.bbox[(int64_t)agg * 6 + 3] - lo0), ih1 = 1.0 / (P.bbox[(int64_t)agg * 6 + 4] - lo1),
+               ih2 = 1.0 / (P.bbox[(int64_t)agg * 6 + 5] - lo2);
+  auto sel3 = [](int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); };
   double *tabE = lds, *tabD = lds + M::LTAB, *tabF = lds + 2 * M::LTAB;
-  double *M2c = lds + 3 * M::LTAB;  // [MAXF][8][8] coupling moments of every face
+  double *M2c = lds + 3 * M::LTAB;  // [MAXF][8][8] coupling moments of every interior face
   double *diagv = M2c + MAXF * 64;  // [64] diagonal entries A[R,R]
   double *Cbuf = diagv + 64;        // [4][4]
   double *coefL = Cbuf + 16;        // [4][4] monomial coefficients of the 1-D basis (centred variable)
@@ -99,10 +104,44 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   const int rlen = P.row_len[slot];
   const int L = P.diag_L[slot];
   const int m0 = L >> 6;
-  const int f_begin = Rw.fr_ptr[slot], f_end = Rw.fr_ptr[slot + 1];
-  int f_int = f_begin; // first interior face (boundary entries come first); coupling moments are kept per interior face
-  while (f_int < f_end && Rw.fr_blk[f_int] < 0)
-    ++f_int;
+  const int f_begin = Rw.fr_ptr[slot];
+  const int nfaces = Rw.fr_ptr[slot + 1] - f_begin; // <= 64 (host)
+  // The face table of the polytope lives in the lanes (lane t = face t): ONE round of loads (+ one for the neighbours'
+  // boxes) instead of a chain of dependent loads per face; a face's entries are read with v_readlane.
+  int t_pcnt = 0, t_nbr = -1, t_axis = 0, t_blk = -1, t_pblo = 0, t_pbhi = 0;
+  double t_coord = 0.0, t_sigma = 0.0, t_nsign = 1.0, t_qlo0 = 0.0, t_qlo1 = 0.0, t_qlo2 = 0.0, t_qih0 = 1.0, t_qih1 = 1.0, t_qih2 = 1.0;
+  if (lane < nfaces)
+    {
+      const int f = f_begin + lane;
+      const int64_t pbeg = Rw.fr_pbeg[f];
+      t_pblo = (int)(uint32_t)pbeg;
+      t_pbhi = (int)(pbeg >> 32);
+      t_pcnt = Rw.fr_pcnt[f];
+      t_nbr = Rw.fr_nbr[f];
+      t_axis = Rw.fr_axis[f];
+      t_blk = Rw.fr_blk[f];
+      t_coord = Rw.fr_coord[f];
+      t_sigma = Rw.fr_sigma[f];
+      t_nsign = Rw.fr_nsign[f];
+      if (t_nbr >= 0)
+        {
+          const double *bq = P.bbox + (int64_t)t_nbr * 6;
+          t_qlo0 = bq[0];
+          t_qlo1 = bq[1];
+          t_qlo2 = bq[2];
+          t_qih0 = 1.0 / (bq[3] - bq[0]);
+          t_qih1 = 1.0 / (bq[4] - bq[1]);
+          t_qih2 = 1.0 / (bq[5] - bq[2]);
+        }
+    }
+  auto rl_i = [](int v, int t) { return __builtin_amdgcn_readlane(v, t); };
+  auto rl_d = [](double v, int t) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), t), __builtin_amdgcn_readlane(__double2loint(v), t));
+  };
+  int n_bdry = 0; // boundary entries come first; coupling moments are kept per interior face
+  while (n_bdry < nfaces && rl_i(t_blk, n_bdry) < 0)
+    ++n_bdry;
+  const double lo[DIM] = {lo0, lo1, lo2}, ih[DIM] = {ih0, ih1, ih2}; // compile-time indices only
 
   // ================= P1: volume moments ========================================================================
   Acc ma;
@@ -118,7 +157,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       pw = on ? P.vq_w[base + lane] : 0.0;
     };
     fetch(qb);
+#if PDHR_EXP == 4
+    for (int64_t base = qb; base < qe && P.n < 0; base += Acc::VCH)
+#else
     for (int64_t base = qb; base < qe; base += Acc::VCH)
+#endif
       {
         const int cnt = (int)((qe - base < Acc::VCH) ? (qe - base) : Acc::VCH);
         __syncthreads();
@@ -157,158 +200,225 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     const unsigned adB1 = rb + (8 + 4 * ((blk + 1) & 3) + idx) * 8;
     const unsigned adB2 = rb + (24 + 4 * ((blk == 1 || blk == 2) ? 1 : 0) + idx) * 8;
     const int half = lane >> 5, pt = lane & 31;
-    for (int f = f_begin; f < f_end; ++f)
+    // uniform parameters of face t
+    struct FP
+    {
+      int c, ti, tj, nbr, npass;
+      int64_t pb, pe;
+      bool sep;
+      double lo_t0, lo_t1, ih_t0, ih_t1, loF0, loF1, ihF0, ihF1, nsg, xpl, ptol;
+    };
+    auto face_params = [&](int t) {
+      FP fp;
+      fp.c = rl_i(t_axis, t);
+      fp.ti = fp.c == 0 ? 1 : 0;
+      fp.tj = fp.c == 2 ? 1 : 2;
+      fp.nbr = rl_i(t_nbr, t);
+      fp.pb = ((int64_t)rl_i(t_pbhi, t) << 32) | (uint32_t)rl_i(t_pblo, t);
+      fp.pe = fp.pb + rl_i(t_pcnt, t);
+      fp.lo_t0 = fp.ti == 0 ? lo0 : lo1;
+      fp.lo_t1 = fp.tj == 1 ? lo1 : lo2;
+      fp.ih_t0 = fp.ti == 0 ? ih0 : ih1;
+      fp.ih_t1 = fp.tj == 1 ? ih1 : ih2;
+      fp.loF0 = fp.lo_t0, fp.loF1 = fp.lo_t1, fp.ihF0 = fp.ih_t0, fp.ihF1 = fp.ih_t1;
+      fp.sep = false;
+      if (fp.nbr >= 0)
+        { // frames of the coupling moments: per tangential direction the shorter of the two box intervals
+          const double q0 = rl_d(t_qlo0, t), q1 = rl_d(t_qlo1, t), q2 = rl_d(t_qlo2, t);
+          const double i0 = rl_d(t_qih0, t), i1 = rl_d(t_qih1, t), i2 = rl_d(t_qih2, t);
+          const double lqa = fp.ti == 0 ? q0 : q1, lqb = fp.tj == 1 ? q1 : q2;
+          const double iqa = fp.ti == 0 ? i0 : i1, iqb = fp.tj == 1 ? i1 : i2;
+          if (iqa > fp.ih_t0)
+            fp.loF0 = lqa, fp.ihF0 = iqa, fp.sep = true;
+          if (iqb > fp.ih_t1)
+            fp.loF1 = lqb, fp.ihF1 = iqb, fp.sep = true;
+        }
+      fp.npass = (fp.nbr >= 0 && fp.sep) ? 2 : 1;
+      fp.nsg = rl_d(t_nsign, t);
+      fp.xpl = rl_d(t_coord, t);
+      fp.ptol = 1e-9 / sel3(fp.c, ih0, ih1, ih2);
+      return fp;
+    };
+    // point data of one chunk, loaded one chunk ahead of its use (half 0: x_i; half 1: x_j and the weights)
+    struct Raw
+    {
+      double x, wS, wC, sig, n, xc;
+      bool on;
+    };
+    auto issue = [&](const FP &fp, int64_t base) {
+      Raw r;
+      r.on = base + pt < fp.pe;
+      const int64_t q = r.on ? base + pt : fp.pb;
+      r.x = P.ap_x[(int64_t)(half == 0 ? fp.ti : fp.tj) * P.ap_stride + q];
+      r.wS = r.wC = r.sig = r.n = r.xc = 0.0;
+      if (half == 1)
+        {
+          r.wS = P.ap_wself[q];
+          r.wC = P.ap_wcross[q];
+          r.sig = P.ap_sig[q];
+          r.n = P.ap_n[(int64_t)fp.c * P.ap_stride + q];
+          r.xc = P.ap_x[(int64_t)fp.c * P.ap_stride + q];
+        }
+      return r;
+    };
+#if PDHR_EXP == 3
+    if (nfaces > 0 && P.n < 0)
+#else
+    if (nfaces > 0)
+#endif
       {
-        const int fl = f - f_int;
-        const int c = Rw.fr_axis[f];
-        const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
-        const int nbr = Rw.fr_nbr[f];
-        const int64_t pb = Rw.fr_pbeg[f], pe = pb + Rw.fr_pcnt[f];
-        // frames of the two tangential directions for the coupling moments: the shorter of the two box intervals
-        double lo_t[2] = {ti == 0 ? lo[0] : lo[1], tj == 1 ? lo[1] : lo[2]};
-        double ih_t[2] = {ti == 0 ? ih[0] : ih[1], tj == 1 ? ih[1] : ih[2]};
-        double loF[2] = {lo_t[0], lo_t[1]}, ihF[2] = {ih_t[0], ih_t[1]};
-        bool sep = false;
-        if (nbr >= 0)
+        int t = 0, pass = 0;
+        FP fp = face_params(0);
+        int64_t base = fp.pb;
+        Raw cur = issue(fp, base);
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+        while (t < nfaces)
           {
-            const double *bq = P.bbox + (int64_t)nbr * 2 * DIM;
-            const double lq[2] = {bq[ti], bq[tj]};
-            const double iq[2] = {1.0 / (bq[DIM + ti] - bq[ti]), 1.0 / (bq[DIM + tj] - bq[tj])};
-            for (int d = 0; d < 2; ++d)
-              if (iq[d] > ih_t[d])
-                {
-                  loF[d] = lq[d];
-                  ihF[d] = iq[d];
-                  sep = true;
-                }
-          }
-        const int npass = (nbr >= 0 && sep) ? 2 : 1;
-        for (int pass = 0; pass < npass; ++pass)
-          {
-            const double flo = half == 0 ? (pass ? loF[0] : lo_t[0]) : (pass ? loF[1] : lo_t[1]);
-            const double fih = half == 0 ? (pass ? ihF[0] : ih_t[0]) : (pass ? ihF[1] : ih_t[1]);
-            const double *px = P.ap_x + (int64_t)(half == 0 ? ti : tj) * P.ap_stride;
-            const double *pn = P.ap_n + (int64_t)c * P.ap_stride;
-            const double *pc = P.ap_x + (int64_t)c * P.ap_stride;
-            // a boundary run may hold the points of several planes (one entry per plane): the others get zero weights
-            const double nsg = Rw.fr_nsign[f], xpl = Rw.fr_coord[f];
-            const double ptol = 1e-9 / (c == 0 ? ih[0] : (c == 1 ? ih[1] : ih[2]));
-            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-            for (int64_t base = pb; base < pe; base += FCH)
+            // the chunk after this one: same face, next pass of the face, or first chunk of the next face
+            int nt = t, npass = pass;
+            int64_t nbase = base + FCH;
+            FP nfp = fp;
+            const bool last_chunk = nbase >= fp.pe;
+            if (last_chunk)
               {
-                const bool on = base + pt < pe;
-                const int64_t q = on ? base + pt : pb;
-                // half 0: L_i; half 1: the three weighted copies of L_j
-                const double xh = (px[q] - flo) * fih;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-                if (half == 1 && on && pn[q] * nsg > 0.5 && fabs(pc[q] - xpl) <= ptol)
+                if (pass + 1 < fp.npass)
+                  npass = pass + 1, nbase = fp.pb;
+                else
                   {
-                    const double wS = P.ap_wself[q], wC = P.ap_wcross[q];
-                    if (pass == 0)
+                    nt = t + 1, npass = 0;
+                    if (nt < nfaces)
                       {
-                        s0 = wS * P.ap_sig[q];
-                        s1 = -0.5 * wS * pn[q];
-                        s2 = (nbr >= 0 && !sep) ? wC : 0.0;
+                        nfp = face_params(nt);
+                        nbase = nfp.pb;
+                      }
+                  }
+              }
+            Raw nxt = cur;
+            if (nt < nfaces)
+              nxt = issue(nfp, nbase);
+            // ---- record phase
+            const int c = fp.c;
+            {
+              const double flo = half == 0 ? (pass ? fp.loF0 : fp.lo_t0) : (pass ? fp.loF1 : fp.lo_t1);
+              const double fih = half == 0 ? (pass ? fp.ihF0 : fp.ih_t0) : (pass ? fp.ihF1 : fp.ih_t1);
+              const double xh = (cur.x - flo) * fih;
+              double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+              // a boundary run may hold the points of several planes (one entry per plane): the others get zero weights
+              if (half == 1 && cur.on && cur.n * fp.nsg > 0.5 && fabs(cur.xc - fp.xpl) <= fp.ptol)
+                {
+                  if (pass == 0)
+                    {
+                      s0 = cur.wS * cur.sig;
+                      s1 = -0.5 * cur.wS * cur.n;
+                      s2 = (fp.nbr >= 0 && !fp.sep) ? cur.wC : 0.0;
+                    }
+                  else
+                    s2 = cur.wC;
+                }
+              double Lh[NA];
+              pdhm::legendre01<NA>(cur.on ? xh : 0.5, Lh);
+              double *r = W + pt * FREC;
+              if (half == 0)
+                {
+                  for (int a = 0; a < NA; ++a)
+                    r[a] = Lh[a];
+                  r[NA] = 0.0;
+                }
+              else
+                {
+                  for (int a = 0; a < NA; ++a)
+                    {
+                      r[8 + a] = s0 * Lh[a];
+                      r[16 + a] = s1 * Lh[a];
+                      r[24 + a] = s2 * Lh[a];
+                    }
+                  r[8 + NA] = 0.0;
+                  r[16 + NA] = 0.0;
+                  r[24 + NA] = 0.0;
+                }
+              __syncthreads();
+            }
+            // ---- 8 steps of 4 points, operands one step ahead of the MFMAs (see MomentAcc::volume_chunk_full)
+            {
+              double ra[2], rb0[2], rb1[2], rb2[2];
+              Acc::template lds_read<0>(ra[0], adA);
+              Acc::template lds_read<0>(rb0[0], adB0);
+              Acc::template lds_read<0>(rb1[0], adB1);
+              Acc::template lds_read<0>(rb2[0], adB2);
+              static_for<0, FCH / 4>([&](auto s_) {
+                constexpr int s = s_;
+                constexpr int cu = s & 1, nx = (s + 1) & 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[cu]), "+v"(rb0[cu]), "+v"(rb1[cu]), "+v"(rb2[cu]));
+                if constexpr (s + 1 < FCH / 4)
+                  {
+                    Acc::template lds_read<(s + 1) * FSTEP>(ra[nx], adA);
+                    Acc::template lds_read<(s + 1) * FSTEP>(rb0[nx], adB0);
+                    Acc::template lds_read<(s + 1) * FSTEP>(rb1[nx], adB1);
+                    Acc::template lds_read<(s + 1) * FSTEP>(rb2[nx], adB2);
+                  }
+                __builtin_amdgcn_sched_barrier(0);
+                acc0 = pdh::mfma4(ra[cu], rb0[cu], acc0);
+                acc1 = pdh::mfma4(ra[cu], rb1[cu], acc1);
+                acc2 = pdh::mfma4(ra[cu], rb2[cu], acc2);
+                __builtin_amdgcn_sched_barrier(0);
+              });
+              __syncthreads();
+            }
+            if (last_chunk)
+              {
+                // flush: D lane (i, blk, j) = rows a_i = 4 (blk & 1) + i; acc0: column block blk, acc1: block blk + 1, acc2: t = 2
+                double *M2 = W; // [3][8][8]
+                {
+                  const int i = lane >> 4, j = lane & 3;
+                  const int ai = 4 * (blk & 1) + i;
+                  const int b1 = (blk + 1) & 3;
+                  M2[(blk >> 1) * 64 + ai * 8 + 4 * (blk & 1) + j] = acc0;
+                  M2[(b1 >> 1) * 64 + ai * 8 + 4 * (b1 & 1) + j] = acc1;
+                  M2[2 * 64 + ai * 8 + 4 * ((blk == 1 || blk == 2) ? 1 : 0) + j] = acc2;
+                }
+                acc0 = acc1 = acc2 = 0.0;
+                __syncthreads();
+                if (pass == 0)
+                  {
+                    // expansion into this lane's (a0, a1) rows of the 3-D tensors: M[a0,a1,a2] += L_{a_c}(zeta) M2[a_i][a_j]
+                    const double zeta = (fp.xpl - sel3(c, lo0, lo1, lo2)) * sel3(c, ih0, ih1, ih2);
+                    double Lc[NA];
+                    pdhm::legendre01<NA>(zeta, Lc);
+                    if (c == 2)
+                      {
+                        const double mS = M2[0 * 64 + a0 * 8 + a1], mN = M2[1 * 64 + a0 * 8 + a1];
+                        for (int a = 0; a < NA; ++a)
+                          {
+                            accS[a] += Lc[a] * mS;
+                            accN[2][a] += Lc[a] * mN;
+                          }
                       }
                     else
-                      s2 = wC;
+                      {
+                        // c == 1: (i, j) = (0, 2): factor L_{a1}(zeta), row a0;  c == 0: (i, j) = (1, 2): factor L_{a0}(zeta), row a1
+                        const int asel = c == 1 ? a1 : a0, arow = c == 1 ? a0 : a1;
+                        double lc = Lc[0];
+                        static_for<1, NA>([&](auto a_) {
+                          constexpr int a = a_;
+                          lc = asel == a ? Lc[a] : lc;
+                        });
+                        for (int a = 0; a < NA; ++a)
+                          {
+                            const double mS = M2[0 * 64 + arow * 8 + a], mN = M2[1 * 64 + arow * 8 + a];
+                            accS[a] += lc * mS;
+                            if (c == 1)
+                              accN[1][a] += lc * mN;
+                            else
+                              accN[0][a] += lc * mN;
+                          }
+                      }
                   }
-                double Lh[NA];
-                pdhm::legendre01<NA>(on ? xh : 0.5, Lh);
+                const int fl = t - n_bdry;
+                if (fp.nbr >= 0 && (pass == 1 || !fp.sep) && fl >= 0 && fl < MAXF)
+                  M2c[fl * 64 + lane] = M2[2 * 64 + lane];
                 __syncthreads();
-                double *r = W + pt * FREC;
-                if (half == 0)
-                  {
-                    for (int a = 0; a < NA; ++a)
-                      r[a] = Lh[a];
-                    r[NA] = 0.0;
-                  }
-                else
-                  {
-                    for (int a = 0; a < NA; ++a)
-                      {
-                        r[8 + a] = s0 * Lh[a];
-                        r[16 + a] = s1 * Lh[a];
-                        r[24 + a] = s2 * Lh[a];
-                      }
-                    r[8 + NA] = 0.0;
-                    r[16 + NA] = 0.0;
-                    r[24 + NA] = 0.0;
-                  }
-                __syncthreads();
-                // 8 steps of 4 points, operands one step ahead of the MFMAs (see MomentAcc::volume_chunk_full)
-                double ra[2], rb0[2], rb1[2], rb2[2];
-                Acc::template lds_read<0>(ra[0], adA);
-                Acc::template lds_read<0>(rb0[0], adB0);
-                Acc::template lds_read<0>(rb1[0], adB1);
-                Acc::template lds_read<0>(rb2[0], adB2);
-                static_for<0, FCH / 4>([&](auto s_) {
-                  constexpr int s = s_;
-                  constexpr int cur = s & 1, nxt = (s + 1) & 1;
-                  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[cur]), "+v"(rb0[cur]), "+v"(rb1[cur]), "+v"(rb2[cur]));
-                  if constexpr (s + 1 < FCH / 4)
-                    {
-                      Acc::template lds_read<(s + 1) * FSTEP>(ra[nxt], adA);
-                      Acc::template lds_read<(s + 1) * FSTEP>(rb0[nxt], adB0);
-                      Acc::template lds_read<(s + 1) * FSTEP>(rb1[nxt], adB1);
-                      Acc::template lds_read<(s + 1) * FSTEP>(rb2[nxt], adB2);
-                    }
-                  __builtin_amdgcn_sched_barrier(0);
-                  acc0 = pdh::mfma4(ra[cur], rb0[cur], acc0);
-                  acc1 = pdh::mfma4(ra[cur], rb1[cur], acc1);
-                  acc2 = pdh::mfma4(ra[cur], rb2[cur], acc2);
-                  __builtin_amdgcn_sched_barrier(0);
-                });
               }
-            // flush: D lane (i, blk, j) = rows a_i = 4 (blk & 1) + i; acc0: column block blk, acc1: block blk + 1, acc2: t = 2
-            __syncthreads();
-            double *M2 = W; // [3][8][8]
-            {
-              const int i = lane >> 4, j = lane & 3;
-              const int ai = 4 * (blk & 1) + i;
-              const int b1 = (blk + 1) & 3;
-              M2[(blk >> 1) * 64 + ai * 8 + 4 * (blk & 1) + j] = acc0;
-              M2[(b1 >> 1) * 64 + ai * 8 + 4 * (b1 & 1) + j] = acc1;
-              M2[2 * 64 + ai * 8 + 4 * ((blk == 1 || blk == 2) ? 1 : 0) + j] = acc2;
-            }
-            __syncthreads();
-            if (pass == 0)
-              {
-                // expansion into this lane's (a0, a1) rows of the 3-D tensors: M[a0,a1,a2] += L_{a_c}(zeta) M2[a_i][a_j]
-                const double zeta = (Rw.fr_coord[f] - (c == 0 ? lo[0] : (c == 1 ? lo[1] : lo[2]))) * (c == 0 ? ih[0] : (c == 1 ? ih[1] : ih[2]));
-                double Lc[NA];
-                pdhm::legendre01<NA>(zeta, Lc);
-                if (c == 2)
-                  {
-                    const double mS = M2[0 * 64 + a0 * 8 + a1], mN = M2[1 * 64 + a0 * 8 + a1];
-                    for (int a = 0; a < NA; ++a)
-                      {
-                        accS[a] += Lc[a] * mS;
-                        accN[2][a] += Lc[a] * mN;
-                      }
-                  }
-                else
-                  {
-                    // c == 1: (i, j) = (0, 2): factor L_{a1}(zeta), row a0;  c == 0: (i, j) = (1, 2): factor L_{a0}(zeta), row a1
-                    const int asel = c == 1 ? a1 : a0, arow = c == 1 ? a0 : a1;
-                    double lc = Lc[0];
-                    static_for<1, NA>([&](auto a_) {
-                      constexpr int a = a_;
-                      lc = asel == a ? Lc[a] : lc;
-                    });
-                    for (int a = 0; a < NA; ++a)
-                      {
-                        const double mS = M2[0 * 64 + arow * 8 + a], mN = M2[1 * 64 + arow * 8 + a];
-                        accS[a] += lc * mS;
-                        if (c == 1)
-                          accN[1][a] += lc * mN;
-                        else
-                          accN[0][a] += lc * mN;
-                      }
-                  }
-              }
-            if (nbr >= 0 && (pass == 1 || !sep) && fl >= 0 && fl < MAXF)
-              M2c[fl * 64 + lane] = M2[2 * 64 + lane];
+            t = nt, pass = npass, base = nbase, fp = nfp, cur = nxt;
           }
       }
   }
@@ -317,18 +427,18 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double *tabQ = W;               // [2][PAIRS][RS]
   double *Tst = W + 2 * M::LTAB;  // [16 pairs (k_j,l_j)][8]
   double *Sbuf = Tst + 128;       // [16 u][16 v]
-  auto build_S = [&](int f) {
-    const int fl = f - f_int;
-    const int c = Rw.fr_axis[f];
+  auto build_S = [&](int t) { // t = local face index
+    const int fl = t - n_bdry;
+    const int c = rl_i(t_axis, t);
     const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
-    const int nbr = Rw.fr_nbr[f];
-    const double *bq = P.bbox + (int64_t)nbr * 2 * DIM;
+    const double q0 = rl_d(t_qlo0, t), q1 = rl_d(t_qlo1, t), q2 = rl_d(t_qlo2, t);
+    const double i0 = rl_d(t_qih0, t), i1 = rl_d(t_qih1, t), i2 = rl_d(t_qih2, t);
     bool same[2];
     {
       const int dd = (lane >> 4) & 1;
       const int d = dd == 0 ? ti : tj;
-      const double lo_d = d == 0 ? lo[0] : (d == 1 ? lo[1] : lo[2]), ih_d = d == 0 ? ih[0] : (d == 1 ? ih[1] : ih[2]);
-      const double loq_d = bq[d], ihq_d = 1.0 / (bq[DIM + d] - bq[d]);
+      const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
+      const double loq_d = sel3(d, q0, q1, q2), ihq_d = sel3(d, i0, i1, i2);
       const bool same_d = (loq_d == lo_d) && (ihq_d == ih_d);
       same[0] = __shfl(same_d ? 1 : 0, 0) != 0;
       same[1] = __shfl(same_d ? 1 : 0, 16) != 0;
@@ -347,8 +457,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             e[a] = 0.0;
           for (int gq = 0; gq < NG; ++gq)
             {
-              const double t = mt[M::OFF_GX + gq];
-              const double xp = aP * t + bP, xq = aQ * t + bQ;
+              const double tg = mt[M::OFF_GX + gq];
+              const double xp = aP * tg + bP, xq = aQ * tg + bQ;
               double vk = coefL[k * 4 + 3], vl = coefL[l * 4 + 3];
               for (int m = 2; m >= 0; --m)
                 {
@@ -405,10 +515,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     if (lane < 16)
       {
         // C[k][l] = (1/2 s B'_k(zP)/hP - sigma B_k(zP)) B_l(zQ) - 1/2 s B_k(zP) B'_l(zQ)/hQ    (centred variable)
-        const double x = Rw.fr_coord[f];
-        const double lo_c = c == 0 ? lo[0] : (c == 1 ? lo[1] : lo[2]), ih_c = c == 0 ? ih[0] : (c == 1 ? ih[1] : ih[2]);
-        const double ihq_c = 1.0 / (bq[DIM + c] - bq[c]);
-        const double zp = (x - lo_c) * ih_c - 0.5, zq = (x - bq[c]) * ihq_c - 0.5;
+        const double x = rl_d(t_coord, t);
+        const double lo_c = sel3(c, lo0, lo1, lo2), ih_c = sel3(c, ih0, ih1, ih2);
+        const double loq_c = sel3(c, q0, q1, q2), ihq_c = sel3(c, i0, i1, i2);
+        const double zp = (x - lo_c) * ih_c - 0.5, zq = (x - loq_c) * ihq_c - 0.5;
         const int k = lane >> 2, l = lane & 3;
         double vk = coefL[k * 4 + 3], dk = 0.0, vl = coefL[l * 4 + 3], dl = 0.0;
         for (int m = 2; m >= 0; --m)
@@ -418,7 +528,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             dl = dl * zq + vl;
             vl = vl * zq + coefL[l * 4 + m];
           }
-        const double sg = Rw.fr_nsign[f], sig = Rw.fr_sigma[f];
+        const double sg = rl_d(t_nsign, t), sig = rl_d(t_sigma, t);
         Cbuf[lane] = (0.5 * sg * dk * ih_c - sig * vk) * vl - 0.5 * sg * vk * dl * ihq_c;
       }
     __syncthreads();
@@ -430,12 +540,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   const bool shifted = P.diag_first != 0;
   double carry_own = 0.0;
   if (shifted && m0 > 0)
-    for (int f = f_begin; f < f_end; ++f)
-      if (Rw.fr_blk[f] == m0 - 1)
+    for (int t = n_bdry; t < nfaces; ++t)
+      if (rl_i(t_blk, t) == m0 - 1)
         {
           __syncthreads();
-          build_S(f);
-          carry_own = last_column(Rw.fr_axis[f]);
+          build_S(t);
+          carry_own = last_column(rl_i(t_axis, t));
         }
 
   // ================= P4: diagonal block ============================================================================
@@ -469,13 +579,16 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     double *T1B = W;                  // [4 arrays][2 bf][2 ks][64]
     double *T2B = W + 4 * 2 * 2 * 64; // [2 ks][4 cf][64]
     double *rowst = W;                // [16 rows][64 columns] (after stage 3)
-    const double ih0 = ih[0], ih1 = ih[1], ih2 = ih[2];
     const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
     const int O = di + 4 * dj + 16 * dblk; // this lane's column in the D layout of stage 3
     pdhm::T1Off t1o;
     t1o.init(a0, a1);
 #pragma unroll 1
+#if PDHR_EXP == 2
+    for (int k2 = 0; k2 < 4 && P.n < 0; ++k2)
+#else
     for (int k2 = 0; k2 < 4; ++k2)
+#endif
       {
         __syncthreads();
         if (act)
@@ -582,19 +695,21 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   {
     double carry = 0.0; // lane R: the value that lane 0 stores in row R of the next piece
     bool first_left = true;
-    for (int f = f_begin; f < f_end; ++f)
+#if PDHR_EXP == 1
+    for (int t = n_bdry; t < nfaces && P.n < 0; ++t)
+#else
+    for (int t = n_bdry; t < nfaces; ++t)
+#endif
       {
-        const int b = Rw.fr_blk[f];
-        if (b < 0)
-          continue;
-        const int c = Rw.fr_axis[f];
+        const int b = rl_i(t_blk, t);
+        const int c = rl_i(t_axis, t);
         const bool left = shifted && b < m0;
         __syncthreads();
         if (left && first_left)
           carry = diagv[lane]; // piece 0 starts with the diagonal entry
         if (left)
           first_left = false;
-        build_S(f);
+        build_S(t);
         // this lane's column of the block: shifted pieces hold columns -1 .. 62 (lane 0: the carry)
         const int jcol = left ? (lane > 0 ? lane - 1 : 0) : lane;
         const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
@@ -619,7 +734,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 const double cin = __hiloint2double(__builtin_amdgcn_readlane(chi, R), __builtin_amdgcn_readlane(clo, R));
                 v = lane == 0 ? cin : v;
               }
-            dst[(int64_t)R * rlen] = v;
+#if PDHR_EXP == 5
+            if (P.n < 0)
+#endif
+              dst[(int64_t)R * rlen] = v;
           });
         };
         if (c == 0)
