@@ -770,7 +770,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
 // ---------------------------------------------------------------------------------------------------
 struct RowsHost
 {
-  std::vector<int32_t> fr_ptr, fr_pcnt, fr_nbr, fr_axis, fr_blk;
+  std::vector<int32_t> fr_ptr, fr_pcnt, fr_nbr, fr_axis, fr_blk, fr_flags;
   std::vector<int64_t> fr_pbeg;
   std::vector<double> fr_coord, fr_sigma, fr_nsign;
 };
@@ -865,6 +865,7 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
             R.fr_nbr.push_back(K.run_nbr[t]);
             R.fr_axis.push_back(pl.axis);
             R.fr_blk.push_back(K.run_blk[t]);
+            R.fr_flags.push_back(planes[t].size() > 1 ? 1 : 0);
             R.fr_coord.push_back(pl.coord);
             R.fr_sigma.push_back(K.run_sig[t]);
             R.fr_nsign.push_back(pl.sign);
@@ -1082,12 +1083,25 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
           if ((rc = upload(ctx, RH.fr_ptr, &R.fr_ptr)) != PDH_OK || (rc = upload(ctx, RH.fr_pbeg, &R.fr_pbeg)) != PDH_OK ||
               (rc = upload(ctx, RH.fr_pcnt, &R.fr_pcnt)) != PDH_OK || (rc = upload(ctx, RH.fr_nbr, &R.fr_nbr)) != PDH_OK ||
               (rc = upload(ctx, RH.fr_axis, &R.fr_axis)) != PDH_OK || (rc = upload(ctx, RH.fr_blk, &R.fr_blk)) != PDH_OK ||
+              (rc = upload(ctx, RH.fr_flags, &R.fr_flags)) != PDH_OK ||
               (rc = upload(ctx, RH.fr_coord, &R.fr_coord)) != PDH_OK || (rc = upload(ctx, RH.fr_sigma, &R.fr_sigma)) != PDH_OK ||
               (rc = upload(ctx, RH.fr_nsign, &R.fr_nsign)) != PDH_OK)
             {
               free_problem(ctx);
               return rc;
             }
+          {
+            void *ds = nullptr;
+            const size_t nb = (size_t)std::max(K.n_owned, 1) * 16 * sizeof(long long);
+            if (hipMalloc(&ds, nb) == hipSuccess)
+              {
+                ctx->allocs.push_back(ds);
+                (void)hipMemset(ds, 0, nb);
+                R.stamps = static_cast<long long *>(ds);
+              }
+            else
+              R.stamps = nullptr;
+          }
           ctx->rows_ok = true;
         }
     }
@@ -1268,6 +1282,17 @@ extern "C" int pdh_set_stream(pdh_ctx *ctx, void *stream)
   PDH_HIP(ctx, hipSetDevice(ctx->device));
   PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+  return PDH_OK;
+}
+
+// Diagnostic (builds with -DPDHR_STAMP only): s_memtime stamps of the row kernel's phase boundaries and in-phase sums, [n_owned][16].
+extern "C" int pdh_debug_rows_stamps(pdh_ctx *ctx, long long *out)
+{
+  if (!ctx || !ctx->has_problem || !ctx->rows_ok || !ctx->rows.stamps || !out)
+    return fail(ctx, PDH_ESTATE, "no row-kernel problem resident");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PDH_HIP(ctx, hipMemcpy(out, ctx->rows.stamps, (size_t)ctx->n_owned * 16 * sizeof(long long), hipMemcpyDeviceToHost));
   return PDH_OK;
 }
 

@@ -40,6 +40,22 @@
 #define PDH_MAX_N1D 8
 #define PDH_WAVE 64
 
+// Ordering of LDS traffic inside ONE wave.  Every kernel of this library runs single-wave workgroups; the lanes of a wave
+// exchange data through LDS (records, staging tiles).  The LDS unit executes the DS instructions of a wave in issue
+// order, so a ds_write followed by a ds_read of another lane needs no s_waitcnt and no s_barrier - only the COMPILER must
+// be kept from moving memory operations across the hand-off.  __syncthreads() does that too, but it is also a full
+// fence: s_waitcnt vmcnt(0), i.e. it waits for every global load and store in flight - which silently undid all prefetching
+// of point data and made each hand-off wait for the row stores before it (measured with in-kernel stamps, r02: a 64-point
+// chunk of the row kernel took 5.6k cycles instead of 2.8k).
+#define PDH_WAVE_SYNC()                                                                                             \
+  do                                                                                                                \
+    {                                                                                                               \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                        \
+      __builtin_amdgcn_wave_barrier();                                                                              \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                        \
+    }                                                                                                               \
+  while (0)
+
 struct PdhBasisTab
 {
   double coef[PDH_MAX_N1D][PDH_MAX_N1D]; // coef[k][m]: monomial coefficients of 1-D basis function k

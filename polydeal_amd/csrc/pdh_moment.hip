@@ -1,4 +1,5 @@
 // pdh_moment.hip — instantiations and launcher of the moment-form kernels (pdh_moment.h): 3-D, degree <= 3.
+#include <cstdlib>
 #include "pdh_moment.h"
 #include "pdh_rows.h"
 
@@ -49,8 +50,14 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
 {
   if (count <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL((pdhr::k_rows<4>), dim3((unsigned)count), dim3(PDH_WAVE), pdhr::lds_doubles_rows<4>() * sizeof(double), stream,
-                     *P, *R, mtab, count);
+  // PDH_ROWS_LDS_PAD (bytes, diagnostics only): extra dynamic LDS per workgroup = fewer resident waves per CU, to see how
+  // the kernel's time scales with occupancy (tools/README)
+  static const size_t pad = [] {
+    const char *e = getenv("PDH_ROWS_LDS_PAD");
+    return e ? (size_t)atol(e) : (size_t)0;
+  }();
+  hipLaunchKernelGGL((pdhr::k_rows<4>), dim3((unsigned)count), dim3(PDH_WAVE), pdhr::lds_doubles_rows<4>() * sizeof(double) + pad,
+                     stream, *P, *R, mtab, count);
   return hipGetLastError();
 }
 extern "C" int pdh_rows_max_faces(void) { return pdhr::MAXF; }

@@ -40,12 +40,29 @@
 #define PDHR_EXP 0
 #endif
 
+#ifdef PDHR_STAMP
+#define PDHR_MARK(k)                                                                                                  \
+  do                                                                                                                  \
+    {                                                                                                                 \
+      const long long tm_ = (long long)__builtin_readcyclecounter();                                                  \
+      if (lane == 0 && Rw.stamps)                                                                                     \
+        Rw.stamps[(int64_t)slot * 16 + (k)] = tm_;                                                                     \
+    }                                                                                                                 \
+  while (0)
+#define PDHR_T0() const long long t0_ = (long long)__builtin_readcyclecounter()
+#define PDHR_ACC(var) var += (long long)__builtin_readcyclecounter() - t0_
+#else
+#define PDHR_MARK(k)
+#define PDHR_T0()
+#define PDHR_ACC(var)
+#endif
+
 namespace pdhr
 {
 using pdh::static_for;
 using pdhm::d2_t;
 
-constexpr int MAXF = 8;  // INTERIOR faces per polytope the LDS layout provides for
+constexpr int MAXF = 6;  // INTERIOR faces per polytope the LDS layout provides for (6: 20.3 KB per wave = 8 waves per CU)
 constexpr int FREC = 33; // face record: L_i[8], (s_t L_j)[3][8], pad (odd stride)
 constexpr int FCH = 32;  // face points per chunk
 constexpr int FSTEP = 4 * FREC * 8;
@@ -56,7 +73,7 @@ constexpr int lds_doubles_rows()
   using M = pdhm::MT<N1D>;
   using A = pdhm::MomentAcc<N1D>;
   constexpr int w_rec = A::VCH * A::VREC > FCH * FREC ? A::VCH * A::VREC : FCH * FREC;
-  constexpr int w_con = 4 * 2 * 2 * 64 + 2 * 4 * 64; // T1B + T2B
+  constexpr int w_con = 4 * 2 * 2 * 64 + 2 * 4 * 64 + 64; // T1B + T2B + carry of the own piece
   constexpr int w = w_rec > w_con ? w_rec : w_con;
   return 3 * M::LTAB + MAXF * 64 + 64 /* diagv */ + 16 /* C */ + 16 /* coef */ + w;
 }
@@ -81,6 +98,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   const int slot = blockIdx.x;
   if (slot >= n_owned)
     return;
+  PDHR_MARK(0);
   const int agg = P.own_agg[slot];
   // bounding box as scalars (indexed by a run-time axis through sel3: an array would be demoted to scratch memory)
   const double lo0 = P.bbox[(int64_t)agg * 6 + 0], lo1 = P.bbox[(int64_t)agg * 6 + 1], lo2 = P.bbox[(int64_t)agg * 6 + 2];
@@ -108,7 +126,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   const int nfaces = Rw.fr_ptr[slot + 1] - f_begin; // <= 64 (host)
   // The face table of the polytope lives in the lanes (lane t = face t): ONE round of loads (+ one for the neighbours'
   // boxes) instead of a chain of dependent loads per face; a face's entries are read with v_readlane.
-  int t_pcnt = 0, t_nbr = -1, t_axis = 0, t_blk = -1, t_pblo = 0, t_pbhi = 0;
+  int t_pcnt = 0, t_nbr = -1, t_axis = 0, t_blk = -1, t_pblo = 0, t_pbhi = 0, t_flags = 0;
   double t_coord = 0.0, t_sigma = 0.0, t_nsign = 1.0, t_qlo0 = 0.0, t_qlo1 = 0.0, t_qlo2 = 0.0, t_qih0 = 1.0, t_qih1 = 1.0, t_qih2 = 1.0;
   if (lane < nfaces)
     {
@@ -120,6 +138,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       t_nbr = Rw.fr_nbr[f];
       t_axis = Rw.fr_axis[f];
       t_blk = Rw.fr_blk[f];
+      t_flags = Rw.fr_flags[f];
       t_coord = Rw.fr_coord[f];
       t_sigma = Rw.fr_sigma[f];
       t_nsign = Rw.fr_nsign[f];
@@ -141,46 +160,58 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   int n_bdry = 0; // boundary entries come first; coupling moments are kept per interior face
   while (n_bdry < nfaces && rl_i(t_blk, n_bdry) < 0)
     ++n_bdry;
-  const double lo[DIM] = {lo0, lo1, lo2}, ih[DIM] = {ih0, ih1, ih2}; // compile-time indices only
 
+  PDHR_MARK(1);
   // ================= P1: volume moments ========================================================================
   Acc ma;
   ma.init(lane);
   ma.init_addr(W, lane);
   {
+    // point data two chunks ahead, in two statically addressed register sets (see P2 on why no copies)
     const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
-    double px[DIM] = {0.0, 0.0, 0.0}, pw = 0.0;
-    auto fetch = [&](int64_t base) {
-      const bool on = base + lane < qe;
-      for (int c = 0; c < DIM; ++c)
-        px[c] = on ? P.vq_x[c * P.vq_stride + base + lane] : 0.0;
-      pw = on ? P.vq_w[base + lane] : 0.0;
+    struct VRaw
+    {
+      double x0, x1, x2, w;
     };
-    fetch(qb);
+    auto vissue = [&](int64_t base) {
+      VRaw r;
+      const bool on = base + lane < qe;
+      r.x0 = on ? P.vq_x[0 * P.vq_stride + base + lane] : 0.0;
+      r.x1 = on ? P.vq_x[1 * P.vq_stride + base + lane] : 0.0;
+      r.x2 = on ? P.vq_x[2 * P.vq_stride + base + lane] : 0.0;
+      r.w = on ? P.vq_w[base + lane] : 0.0;
+      return r;
+    };
+    VRaw va = vissue(qb), vb = vissue(qb + Acc::VCH);
+    auto vchunk = [&](VRaw &v, int64_t base) {
+      const int cnt = (int)((qe - base < Acc::VCH) ? (qe - base) : Acc::VCH);
+      double xu[DIM] = {0.5, 0.5, 0.5}, w = 0.0;
+      if (lane < cnt)
+        {
+          xu[0] = (v.x0 - lo0) * ih0;
+          xu[1] = (v.x1 - lo1) * ih1;
+          xu[2] = (v.x2 - lo2) * ih2;
+          w = v.w;
+        }
+      v = vissue(base + 2 * Acc::VCH);
+      Acc::write_volume_record(W + lane * Acc::VREC, xu, w);
+      PDH_WAVE_SYNC();
+      ma.volume_chunk_full(); // dead points carry zero weights
+      PDH_WAVE_SYNC();
+    };
 #if PDHR_EXP == 4
-    for (int64_t base = qb; base < qe && P.n < 0; base += Acc::VCH)
+    for (int64_t base = qb; base < qe && P.n < 0; base += 2 * Acc::VCH)
 #else
-    for (int64_t base = qb; base < qe; base += Acc::VCH)
+    for (int64_t base = qb; base < qe; base += 2 * Acc::VCH)
 #endif
       {
-        const int cnt = (int)((qe - base < Acc::VCH) ? (qe - base) : Acc::VCH);
-        __syncthreads();
-        {
-          double xu[DIM] = {0.5, 0.5, 0.5}, w = 0.0;
-          if (lane < cnt)
-            {
-              for (int c = 0; c < DIM; ++c)
-                xu[c] = (px[c] - lo[c]) * ih[c];
-              w = pw;
-            }
-          fetch(base + Acc::VCH);
-          Acc::write_volume_record(W + lane * Acc::VREC, xu, w);
-        }
-        __syncthreads();
-        ma.volume_chunk_full(); // dead points carry zero weights
+        vchunk(va, base);
+        if (base + Acc::VCH < qe)
+          vchunk(vb, base + Acc::VCH);
       }
   }
 
+  PDHR_MARK(2);
   // ================= P2: faces ==================================================================================
   double accS[NAP], accN[DIM][NAP];
   for (int a = 0; a < NAP; ++a)
@@ -206,7 +237,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       int c, ti, tj, nbr, npass;
       int64_t pb, pe;
       bool sep;
-      double lo_t0, lo_t1, ih_t0, ih_t1, loF0, loF1, ihF0, ihF1, nsg, xpl, ptol;
+      double lo_t0, lo_t1, ih_t0, ih_t1, loF0, loF1, ihF0, ihF1, nsg, xpl, ptol, sig;
+      bool masked;
     };
     auto face_params = [&](int t) {
       FP fp;
@@ -237,12 +269,14 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       fp.nsg = rl_d(t_nsign, t);
       fp.xpl = rl_d(t_coord, t);
       fp.ptol = 1e-9 / sel3(fp.c, ih0, ih1, ih2);
+      fp.sig = rl_d(t_sigma, t);
+      fp.masked = rl_i(t_flags, t) != 0;
       return fp;
     };
     // point data of one chunk, loaded one chunk ahead of its use (half 0: x_i; half 1: x_j and the weights)
     struct Raw
     {
-      double x, wS, wC, sig, n, xc;
+      double x, wS, wC, n, xc;
       bool on;
     };
     auto issue = [&](const FP &fp, int64_t base) {
@@ -250,14 +284,16 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       r.on = base + pt < fp.pe;
       const int64_t q = r.on ? base + pt : fp.pb;
       r.x = P.ap_x[(int64_t)(half == 0 ? fp.ti : fp.tj) * P.ap_stride + q];
-      r.wS = r.wC = r.sig = r.n = r.xc = 0.0;
+      r.wS = r.wC = r.n = r.xc = 0.0;
       if (half == 1)
         {
           r.wS = P.ap_wself[q];
           r.wC = P.ap_wcross[q];
-          r.sig = P.ap_sig[q];
-          r.n = P.ap_n[(int64_t)fp.c * P.ap_stride + q];
-          r.xc = P.ap_x[(int64_t)fp.c * P.ap_stride + q];
+          if (fp.masked)
+            { // only boundary runs that span several planes need the per-point normal and plane coordinate
+              r.n = P.ap_n[(int64_t)fp.c * P.ap_stride + q];
+              r.xc = P.ap_x[(int64_t)fp.c * P.ap_stride + q];
+            }
         }
       return r;
     };
@@ -267,56 +303,97 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     if (nfaces > 0)
 #endif
       {
-        int t = 0, pass = 0;
-        FP fp = face_params(0);
-        int64_t base = fp.pb;
-        Raw cur = issue(fp, base);
+        // Chunk cursors: (face, pass, first point).  The point data of a chunk is requested DEPTH chunks ahead of its use
+        // into a ring of register sets - a global load takes ~7k cycles under the store traffic of this kernel (in-kernel
+        // stamps), a chunk ~3k.  Ring slots are addressed statically (the loop body is instantiated per slot): copying a
+        // prefetched value into another variable would wait for the load.
+        struct Cur
+        {
+          int t, pass;
+          int64_t base;
+          FP fp;
+        };
+        auto step = [&](const Cur &c0) {
+          Cur n = c0;
+          n.base = c0.base + FCH;
+          if (n.base >= c0.fp.pe)
+            {
+              if (c0.pass + 1 < c0.fp.npass)
+                n.pass = c0.pass + 1, n.base = c0.fp.pb;
+              else
+                {
+                  n.t = c0.t + 1, n.pass = 0;
+                  if (n.t < nfaces)
+                    {
+                      n.fp = face_params(n.t);
+                      n.base = n.fp.pb;
+                    }
+                }
+            }
+          return n;
+        };
         double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-        while (t < nfaces)
-          {
-            // the chunk after this one: same face, next pass of the face, or first chunk of the next face
-            int nt = t, npass = pass;
-            int64_t nbase = base + FCH;
-            FP nfp = fp;
-            const bool last_chunk = nbase >= fp.pe;
-            if (last_chunk)
-              {
-                if (pass + 1 < fp.npass)
-                  npass = pass + 1, nbase = fp.pb;
-                else
-                  {
-                    nt = t + 1, npass = 0;
-                    if (nt < nfaces)
-                      {
-                        nfp = face_params(nt);
-                        nbase = nfp.pb;
-                      }
-                  }
-              }
-            Raw nxt = cur;
-            if (nt < nfaces)
-              nxt = issue(nfp, nbase);
-            // ---- record phase
+#ifdef PDHR_STAMP
+        long long tm_issue = 0, tm_rec = 0, tm_mfma = 0, tm_flush = 0;
+#endif
+        Cur cc, lc;
+        cc.t = 0, cc.pass = 0;
+        cc.fp = face_params(0);
+        cc.base = cc.fp.pb;
+        lc = cc;
+        constexpr int DEPTH = 4;
+        Raw ring[DEPTH];
+        static_for<0, DEPTH>([&](auto d_) {
+          constexpr int d = d_;
+          ring[d] = ring[0];
+          if (lc.t < nfaces)
+            {
+              ring[d] = issue(lc.fp, lc.base);
+              lc = step(lc);
+            }
+        });
+        auto chunk = [&](Raw &cur) {
+            const FP fp = cc.fp;
+            const int t = cc.t, pass = cc.pass;
+            const bool last_chunk = cc.base + FCH >= fp.pe;
+            // ---- consume this chunk's point data, THEN request a later chunk's into the same registers
             const int c = fp.c;
+            const bool cur_on = cur.on;
+            double xh, s0 = 0.0, s1 = 0.0, s2 = 0.0;
             {
               const double flo = half == 0 ? (pass ? fp.loF0 : fp.lo_t0) : (pass ? fp.loF1 : fp.lo_t1);
               const double fih = half == 0 ? (pass ? fp.ihF0 : fp.ih_t0) : (pass ? fp.ihF1 : fp.ih_t1);
-              const double xh = (cur.x - flo) * fih;
-              double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+              xh = (cur.x - flo) * fih;
               // a boundary run may hold the points of several planes (one entry per plane): the others get zero weights
-              if (half == 1 && cur.on && cur.n * fp.nsg > 0.5 && fabs(cur.xc - fp.xpl) <= fp.ptol)
+              bool mine = half == 1 && cur.on;
+              if (fp.masked)
+                mine = mine && cur.n * fp.nsg > 0.5 && fabs(cur.xc - fp.xpl) <= fp.ptol;
+              if (mine)
                 {
                   if (pass == 0)
                     {
-                      s0 = cur.wS * cur.sig;
-                      s1 = -0.5 * cur.wS * cur.n;
+                      s0 = cur.wS * fp.sig;
+                      s1 = -0.5 * cur.wS * fp.nsg;
                       s2 = (fp.nbr >= 0 && !fp.sep) ? cur.wC : 0.0;
                     }
                   else
                     s2 = cur.wC;
                 }
+            }
+            {
+              PDHR_T0();
+              if (lc.t < nfaces)
+                {
+                  cur = issue(lc.fp, lc.base);
+                  lc = step(lc);
+                }
+              PDHR_ACC(tm_issue);
+            }
+            // ---- record phase
+            {
+              PDHR_T0();
               double Lh[NA];
-              pdhm::legendre01<NA>(cur.on ? xh : 0.5, Lh);
+              pdhm::legendre01<NA>(cur_on ? xh : 0.5, Lh);
               double *r = W + pt * FREC;
               if (half == 0)
                 {
@@ -336,10 +413,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   r[16 + NA] = 0.0;
                   r[24 + NA] = 0.0;
                 }
-              __syncthreads();
+              PDH_WAVE_SYNC();
+              PDHR_ACC(tm_rec);
             }
             // ---- 8 steps of 4 points, operands one step ahead of the MFMAs (see MomentAcc::volume_chunk_full)
             {
+              PDHR_T0();
               double ra[2], rb0[2], rb1[2], rb2[2];
               Acc::template lds_read<0>(ra[0], adA);
               Acc::template lds_read<0>(rb0[0], adB0);
@@ -362,10 +441,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 acc2 = pdh::mfma4(ra[cu], rb2[cu], acc2);
                 __builtin_amdgcn_sched_barrier(0);
               });
-              __syncthreads();
+              PDH_WAVE_SYNC();
+              PDHR_ACC(tm_mfma);
             }
             if (last_chunk)
               {
+                PDHR_T0();
                 // flush: D lane (i, blk, j) = rows a_i = 4 (blk & 1) + i; acc0: column block blk, acc1: block blk + 1, acc2: t = 2
                 double *M2 = W; // [3][8][8]
                 {
@@ -377,7 +458,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   M2[2 * 64 + ai * 8 + 4 * ((blk == 1 || blk == 2) ? 1 : 0) + j] = acc2;
                 }
                 acc0 = acc1 = acc2 = 0.0;
-                __syncthreads();
+                PDH_WAVE_SYNC();
                 if (pass == 0)
                   {
                     // expansion into this lane's (a0, a1) rows of the 3-D tensors: M[a0,a1,a2] += L_{a_c}(zeta) M2[a_i][a_j]
@@ -397,32 +478,56 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                       {
                         // c == 1: (i, j) = (0, 2): factor L_{a1}(zeta), row a0;  c == 0: (i, j) = (1, 2): factor L_{a0}(zeta), row a1
                         const int asel = c == 1 ? a1 : a0, arow = c == 1 ? a0 : a1;
-                        double lc = Lc[0];
+                        double lc_ = Lc[0];
                         static_for<1, NA>([&](auto a_) {
                           constexpr int a = a_;
-                          lc = asel == a ? Lc[a] : lc;
+                          lc_ = asel == a ? Lc[a] : lc_;
                         });
                         for (int a = 0; a < NA; ++a)
                           {
                             const double mS = M2[0 * 64 + arow * 8 + a], mN = M2[1 * 64 + arow * 8 + a];
-                            accS[a] += lc * mS;
+                            accS[a] += lc_ * mS;
                             if (c == 1)
-                              accN[1][a] += lc * mN;
+                              accN[1][a] += lc_ * mN;
                             else
-                              accN[0][a] += lc * mN;
+                              accN[0][a] += lc_ * mN;
                           }
                       }
                   }
                 const int fl = t - n_bdry;
                 if (fp.nbr >= 0 && (pass == 1 || !fp.sep) && fl >= 0 && fl < MAXF)
                   M2c[fl * 64 + lane] = M2[2 * 64 + lane];
-                __syncthreads();
+                PDH_WAVE_SYNC();
+                PDHR_ACC(tm_flush);
               }
-            t = nt, pass = npass, base = nbase, fp = nfp, cur = nxt;
+            cc = step(cc);
+        };
+        while (cc.t < nfaces)
+          {
+            chunk(ring[0]);
+            if (cc.t >= nfaces)
+              break;
+            chunk(ring[1]);
+            if (cc.t >= nfaces)
+              break;
+            chunk(ring[2]);
+            if (cc.t >= nfaces)
+              break;
+            chunk(ring[3]);
           }
+#ifdef PDHR_STAMP
+        if (lane == 0 && Rw.stamps)
+          {
+            Rw.stamps[(int64_t)slot * 16 + 8] = tm_issue;
+            Rw.stamps[(int64_t)slot * 16 + 9] = tm_rec;
+            Rw.stamps[(int64_t)slot * 16 + 10] = tm_mfma;
+            Rw.stamps[(int64_t)slot * 16 + 11] = tm_flush;
+          }
+#endif
       }
   }
 
+  PDHR_MARK(3);
   // ---- S and C of one face into W (tables for the tangential directions, T, S) ----------------------------------------
   double *tabQ = W;               // [2][PAIRS][RS]
   double *Tst = W + 2 * M::LTAB;  // [16 pairs (k_j,l_j)][8]
@@ -442,7 +547,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       const bool same_d = (loq_d == lo_d) && (ihq_d == ih_d);
       same[0] = __shfl(same_d ? 1 : 0, 0) != 0;
       same[1] = __shfl(same_d ? 1 : 0, 16) != 0;
-      __syncthreads();
+      PDH_WAVE_SYNC();
       if (lane < 32 && !same_d)
         {
           // E^Q_d[k,l,a] = <B_k(xi^P(t)) B_l(xi^Q(t)), L_a>, frame = the shorter interval (pdh_moment.h, k_moffdiag)
@@ -474,7 +579,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             te[a] = e[a];
           te[NA] = 0.0;
         }
-      __syncthreads();
+      PDH_WAVE_SYNC();
     }
     const double *EQi = same[0] ? tabE : tabQ, *EQj = same[1] ? tabE : (tabQ + M::LTAB);
     {
@@ -496,7 +601,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           }
       });
     }
-    __syncthreads();
+    PDH_WAVE_SYNC();
     {
       // S[k_i + 4 k_j][l_i + 4 l_j] = sum_alpha EQi[(k_i,l_i)][alpha] T[(k_j,l_j)][alpha]
       const int pairI = lane & 15, ki = pairI >> 2, li = pairI & 3;
@@ -531,7 +636,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         const double sg = rl_d(t_nsign, t), sig = rl_d(t_sigma, t);
         Cbuf[lane] = (0.5 * sg * dk * ih_c - sig * vk) * vl - 0.5 * sg * vk * dl * ihq_c;
       }
-    __syncthreads();
+    PDH_WAVE_SYNC();
   };
   // last column (63: l = (3,3,3)) of the block just built, row R = lane
   auto last_column = [&](int c) { return Cbuf[digit_c(lane, c) * 4 + 3] * Sbuf[digits_t(lane, c) * 16 + 15]; };
@@ -543,14 +648,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     for (int t = n_bdry; t < nfaces; ++t)
       if (rl_i(t_blk, t) == m0 - 1)
         {
-          __syncthreads();
+          PDH_WAVE_SYNC();
           build_S(t);
           carry_own = last_column(rl_i(t_axis, t));
         }
 
+  PDHR_MARK(4);
   // ================= P4: diagonal block ============================================================================
   double accM[NAP];
-  __syncthreads();
+  PDH_WAVE_SYNC();
   {
     // volume accumulators -> W[(a0,a1) row][a2] (scatter of MomentAcc, volume part)
     const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
@@ -569,7 +675,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         });
     });
   }
-  __syncthreads();
+  PDH_WAVE_SYNC();
   for (int a = 0; a < NA; ++a)
     accM[a] = W[(act ? lane : 0) * NA + a];
   if (P.reaction_c != 0.0)
@@ -579,6 +685,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     double *T1B = W;                  // [4 arrays][2 bf][2 ks][64]
     double *T2B = W + 4 * 2 * 2 * 64; // [2 ks][4 cf][64]
     double *rowst = W;                // [16 rows][64 columns] (after stage 3)
+    double *carryo = W + 4 * 2 * 2 * 64 + 2 * 4 * 64; // [64] carry into the own piece (behind T1B / T2B)
+    carryo[lane] = carry_own;
     const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
     const int O = di + 4 * dj + 16 * dblk; // this lane's column in the D layout of stage 3
     pdhm::T1Off t1o;
@@ -590,7 +698,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     for (int k2 = 0; k2 < 4; ++k2)
 #endif
       {
-        __syncthreads();
+        PDH_WAVE_SYNC();
         if (act)
           static_for<0, 4>([&](auto ll_) {
             constexpr int ll = ll_;
@@ -620,29 +728,29 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           for (int r = 0; r < 4; ++r)
             D3[c][r] = 0.0;
         {
-          __syncthreads();
+          PDH_WAVE_SYNC();
           double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = D
           pdhm::mstage2_term(AE, 0, ih0 * ih0, T1B, lane, D2);
           pdhm::mstage2_scatter(D2, T2B, lane);
-          __syncthreads();
+          PDH_WAVE_SYNC();
           pdhm::mstage3(AD, T2B, lane, D3);
         }
         {
-          __syncthreads();
+          PDH_WAVE_SYNC();
           double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = E
           pdhm::mstage2_term(AD, 0, ih1 * ih1, T1B, lane, D2);
           pdhm::mstage2_term(AE, 1, 1.0, T1B, lane, D2);
           pdhm::mstage2_term(AF, 3, ih1, T1B, lane, D2);
           pdhm::mstage2_scatter(D2, T2B, lane);
-          __syncthreads();
+          PDH_WAVE_SYNC();
           pdhm::mstage3(AE, T2B, lane, D3);
         }
         {
-          __syncthreads();
+          PDH_WAVE_SYNC();
           double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = Fs
           pdhm::mstage2_term(AE, 2, ih0, T1B, lane, D2);
           pdhm::mstage2_scatter(D2, T2B, lane);
-          __syncthreads();
+          PDH_WAVE_SYNC();
           pdhm::mstage3(AF, T2B, lane, D3);
         }
         if (!shifted)
@@ -660,7 +768,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           {
             // diagonal-first layout: piece m0 of row R = [carry | own columns without the diagonal]; the diagonal entry is
             // position 0 of the row (lane 0 of piece 0: written here if the own block is the first one, else kept for P5)
-            __syncthreads();
+            PDH_WAVE_SYNC();
             static_for<0, 4>([&](auto cf_) {
               constexpr int cf = cf_;
               static_for<0, 4>([&](auto s0_) {
@@ -668,8 +776,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 rowst[(s0 + 4 * cf) * 64 + O] = D3[cf][s0];
               });
             });
-            __syncthreads();
-            const int clo = __double2loint(carry_own), chi = __double2hiint(carry_own);
+            PDH_WAVE_SYNC();
 #pragma unroll 4
             for (int r = 0; r < 16; ++r)
               {
@@ -678,7 +785,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 double v = rowst[r * 64 + col];
                 if (m0 > 0)
                   {
-                    const double cin = __hiloint2double(__builtin_amdgcn_readlane(chi, R), __builtin_amdgcn_readlane(clo, R));
+                    const double cin = carryo[R]; // broadcast read
                     if (lane == 0)
                       {
                         diagv[R] = v;
@@ -691,6 +798,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       }
   }
 
+  PDHR_MARK(5);
   // ================= P5: coupling blocks in ascending column order ====================================================
   {
     double carry = 0.0; // lane R: the value that lane 0 stores in row R of the next piece
@@ -704,9 +812,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         const int b = rl_i(t_blk, t);
         const int c = rl_i(t_axis, t);
         const bool left = shifted && b < m0;
-        __syncthreads();
-        if (left && first_left)
-          carry = diagv[lane]; // piece 0 starts with the diagonal entry
+        PDH_WAVE_SYNC();
+        const bool first_piece = left && first_left; // piece 0 starts with the diagonal entry (diagv, written in P4)
         if (left)
           first_left = false;
         build_S(t);
@@ -719,8 +826,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         for (int u = 0; u < 16; ++u)
           sc[u] = Sbuf[u * 16 + vt];
         const double next_carry = left ? last_column(c) : 0.0;
-        const int clo = __double2loint(carry), chi = __double2hiint(carry);
-        double *dst = P.values + rbase + 64 * (int64_t)b + lane;
+        // rows: value = Cl[k_c(R)] * sc[u(R)]; shifted pieces: lane 0 stores the carry of row R instead (read from LDS as a
+        // broadcast - no VALU work besides the select); the row address is a scalar base + lane
+        double *carryv = diagv; // [64] carry of every row for this piece (P4 left the diagonal entries here for piece 0)
+        if (left && !first_piece)
+          carryv[lane] = carry;
+        PDH_WAVE_SYNC();
+        double *rowp = P.values + rbase + 64 * (int64_t)b; // uniform
         auto rows = [&](auto c_) {
           constexpr int cc = c_;
           static_for<0, 64>([&](auto R_) {
@@ -731,13 +843,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             double v = Cl[kc] * sc[u];
             if (left)
               {
-                const double cin = __hiloint2double(__builtin_amdgcn_readlane(chi, R), __builtin_amdgcn_readlane(clo, R));
+                const double cin = carryv[R];
                 v = lane == 0 ? cin : v;
               }
 #if PDHR_EXP == 5
             if (P.n < 0)
 #endif
-              dst[(int64_t)R * rlen] = v;
+              (rowp + (int64_t)R * rlen)[lane] = v;
           });
         };
         if (c == 0)
@@ -746,8 +858,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           rows(std::integral_constant<int, 1>{});
         else
           rows(std::integral_constant<int, 2>{});
+        PDH_WAVE_SYNC();
         carry = next_carry;
       }
   }
+  PDHR_MARK(6);
 }
 } // namespace pdhr

@@ -9,7 +9,9 @@ struct PdhRows
   const int32_t *fr_nbr;   // neighbour polytope, -1 on the boundary
   const int32_t *fr_axis;  // normal axis c
   const int32_t *fr_blk;   // ascending rank of the neighbour's block in the row (-1 on the boundary)
+  const int32_t *fr_flags; // 1: the point range holds points of other planes too (boundary run of a corner polytope)
   const double *fr_coord;  // x_c of the plane
   const double *fr_sigma;  // penalty as stored per point (sigma; sigma/2 on the boundary)
   const double *fr_nsign;  // +-1: own outward normal along c
+  long long *stamps;       // [n_owned][16] s_memtime at the phase boundaries; written by -DPDHR_STAMP builds only
 };

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Phase timing of the row kernel from in-kernel s_memtime stamps (a library built with -DPDHR_STAMP):
+    make -C polydeal_amd/csrc DEFS=-DPDHR_STAMP OUT=../../build/stamp/libpolydeal_hip.so BUILD=../../build/stamp/obj
+    python tools/rows_stamps.py build/stamp/libpolydeal_hip.so
+Prints the mean wave cycles between phase boundaries (100 MHz s_memtime ticks are NOT used: readcyclecounter = shader clock)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import bench  # noqa: E402
+import polydeal_amd as pa  # noqa: E402
+
+lib_path = os.path.abspath(sys.argv[1])
+cells = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+grid, ah, fe = bench.build_handler(pa, 3, cells, 2, "dgq", 3, 4)
+flat = ah.flatten(pa.SipVariant.poisson_example(fe), True, False)
+ctx = pa.Context(0, lib_path=lib_path)
+ctx.set_problem(flat)
+assert ctx.algorithm_in_use() == "rows"
+for _ in range(3):
+    ctx.assemble_device()
+ctx.synchronize()
+n = ctx.stats()["n_owned_agg"]
+out = np.zeros((n, 16), dtype=np.int64)
+ctx.lib.pdh_debug_rows_stamps.argtypes = [C.c_void_p, C.c_void_p]
+rc = ctx.lib.pdh_debug_rows_stamps(ctx.h, out.ctypes.data)
+assert rc == 0
+d = np.diff(out[:, :7], axis=1).astype(np.float64)
+names = ["prologue (tables, face table)", "P1 volume", "P2 faces", "P3 carry", "P4 diagonal block", "P5 coupling blocks"]
+tot = (out[:, 6] - out[:, 0]).astype(np.float64)
+print("waves %d, mean lifetime %.0f ticks (median %.0f)" % (n, tot.mean(), np.median(tot)))
+for k, nm in enumerate(names):
+    print("%-32s mean %9.0f  median %9.0f  (%4.1f %%)" % (nm, d[:, k].mean(), np.median(d[:, k]), 100 * d[:, k].mean() / tot.mean()))
+for k, nm in ((8, "P2: issue of the next chunk's loads"), (9, "P2: record phase"), (10, "P2: MFMA steps"), (11, "P2: flush + expansion")):
+    print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
+span = out[:, 6].max() - out[:, 0].min()
+print("first start -> last end: %d ticks" % span)
