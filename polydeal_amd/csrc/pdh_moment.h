@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
 #endif
       {
         const int cnt = (int)((qe - base < Acc::VCH) ? (qe - base) : Acc::VCH);
-        __syncthreads();
+        PDH_WAVE_SYNC();
         {
           double xu[DIM] = {0.5, 0.5, 0.5}, w = 0.0;
           if (lane < cnt)
@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
           Acc::write_volume_record(work + lane * Acc::VREC, xu, w);
 #endif
         }
-        __syncthreads();
+        PDH_WAVE_SYNC();
 #if PDHM_EXP != 6
         if (cnt == Acc::VCH)
           ma.volume_chunk_full();
@@ -942,7 +942,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
 #endif
       {
         const int cnt = (int)((pe - base < Acc::CH) ? (pe - base) : Acc::CH);
-        __syncthreads();
+        PDH_WAVE_SYNC();
         {
           double xa = 0.5, xb = 0.5, s[4] = {0.0, 0.0, 0.0, 0.0};
           if (pt < cnt)
@@ -969,7 +969,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
           Acc::write_face_record_half(work + pt * Acc::REC, half, xa, xb, s);
 #endif
         }
-        __syncthreads();
+        PDH_WAVE_SYNC();
 #if PDHM_EXP != 6
         if (cnt == Acc::CH)
           ma.face_chunk_full();
@@ -980,9 +980,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
   }
   // gather: this lane's (a0,a1) row of every moment tensor
   double accM[NAP], accS[NAP], accN[DIM][NAP];
-  __syncthreads();
+  PDH_WAVE_SYNC();
   ma.template scatter<true>(work, lane);
-  __syncthreads();
+  PDH_WAVE_SYNC();
   for (int a = 0; a < NA; ++a)
     {
       const int row = act ? lane : 0;
@@ -1013,7 +1013,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
 #pragma unroll 1
         for (int k2 = 0; k2 < PDHM_SLABS; ++k2)
           {
-            __syncthreads();
+            PDH_WAVE_SYNC();
             if (act)
               static_for<0, 4>([&](auto ll_) {
                 constexpr int ll = ll_;
@@ -1045,29 +1045,29 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
               for (int r = 0; r < 4; ++r)
                 D3[c][r] = 0.0;
             {
-              __syncthreads();
+              PDH_WAVE_SYNC();
               double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = D
               mstage2_term(AE, 0, ih0 * ih0, T1B, lane, D2);
               mstage2_scatter(D2, T2B, lane);
-              __syncthreads();
+              PDH_WAVE_SYNC();
               mstage3(AD, T2B, lane, D3);
             }
             {
-              __syncthreads();
+              PDH_WAVE_SYNC();
               double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = E
               mstage2_term(AD, 0, ih1 * ih1, T1B, lane, D2);
               mstage2_term(AE, 1, 1.0, T1B, lane, D2);
               mstage2_term(AF, 3, ih1, T1B, lane, D2);
               mstage2_scatter(D2, T2B, lane);
-              __syncthreads();
+              PDH_WAVE_SYNC();
               mstage3(AE, T2B, lane, D3);
             }
             {
-              __syncthreads();
+              PDH_WAVE_SYNC();
               double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = Fs
               mstage2_term(AE, 2, ih0, T1B, lane, D2);
               mstage2_scatter(D2, T2B, lane);
-              __syncthreads();
+              PDH_WAVE_SYNC();
               mstage3(AF, T2B, lane, D3);
             }
             static_for<0, 4>([&](auto cf_) {
@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
       tabE = lds + zero;
       tabD = lds + M::LTAB + zero;
       tabF = lds + 2 * M::LTAB + zero;
-      __syncthreads();
+      PDH_WAVE_SYNC();
       // stage 1 (in registers: this lane's (a0,a1), contraction over a2)
       if (act)
         for (int ll = 0; ll < N1D; ++ll)
@@ -1144,26 +1144,26 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
         out[r] = 0.0;
       // X = D :  D(dir 0) E(dir 1) on E.M / h0^2
       {
-        __syncthreads();
+        PDH_WAVE_SYNC();
         const Term<N1D> terms[1] = {{tabE, 0, ih0 * ih0}};
         stage2<N1D, 1, false>(terms, T1, T2, lane);
-        __syncthreads();
+        PDH_WAVE_SYNC();
         stage3<N1D, false>(tabD, T2, l0, l1, l2, out);
       }
       // X = E :  D(dir 1) on E.M / h1^2  +  E(dir 1) on the merged array  +  Fs(dir 1) on E.N1 / h1
       {
-        __syncthreads();
+        PDH_WAVE_SYNC();
         const Term<N1D> terms[3] = {{tabD, 0, ih1 * ih1}, {tabE, 1, 1.0}, {tabF, 3, ih1}};
         stage2<N1D, 3, false>(terms, T1, T2, lane);
-        __syncthreads();
+        PDH_WAVE_SYNC();
         stage3<N1D, false>(tabE, T2, l0, l1, l2, out);
       }
       // X = Fs :  E(dir 1) on E.N0 / h0
       {
-        __syncthreads();
+        PDH_WAVE_SYNC();
         const Term<N1D> terms[1] = {{tabE, 2, ih0}};
         stage2<N1D, 1, false>(terms, T1, T2, lane);
-        __syncthreads();
+        PDH_WAVE_SYNC();
         stage3<N1D, false>(tabF, T2, l0, l1, l2, out);
       }
       // rows of the slab: one contiguous segment per row at its CSR position (diagonal-first shift as in store_strip)
@@ -1231,15 +1231,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
 #endif
     {
       const int c = lane / (N1D * N1D), k = (lane / N1D) % N1D, l = lane % N1D;
-      double lo_c = lo[0], ih_c = ih[0], loq_c = loq[0], ihq_c = ihq[0], loF_c = loF[0], ihF_c = ihF[0];
-      if (c == 1)
-        {
-          lo_c = lo[1], ih_c = ih[1], loq_c = loq[1], ihq_c = ihq[1], loF_c = loF[1], ihF_c = ihF[1];
-        }
-      if (c == 2)
-        {
-          lo_c = lo[2], ih_c = ih[2], loq_c = loq[2], ihq_c = ihq[2], loF_c = loF[2], ihF_c = ihF[2];
-        }
+      // this lane's direction: selected with exact 0/1 factors (an if-chain over the arrays is turned into an indexed
+      // scratch-memory access by the compiler: a store -> load round trip through global memory at the head of every item)
+      const double m1 = c == 1 ? 1.0 : 0.0, m2 = c == 2 ? 1.0 : 0.0, m0 = 1.0 - m1 - m2;
+      const double lo_c = m0 * lo[0] + m1 * lo[1] + m2 * lo[2], ih_c = m0 * ih[0] + m1 * ih[1] + m2 * ih[2];
+      const double loq_c = m0 * loq[0] + m1 * loq[1] + m2 * loq[2], ihq_c = m0 * ihq[0] + m1 * ihq[1] + m2 * ihq[2];
+      const double loF_c = m0 * loF[0] + m1 * loF[1] + m2 * loF[2], ihF_c = m0 * ihF[0] + m1 * ihF[1] + m2 * ihF[2];
       const double hF = 1.0 / ihF_c;
       const double aP = hF * ih_c, bP = (loF_c - lo_c) * ih_c - 0.5;    // centred unit coordinate of P at frame coordinate t
       const double aQ = hF * ihq_c, bQ = (loF_c - loq_c) * ihq_c - 0.5; // ... of Q
@@ -1286,6 +1283,29 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
   ma.init_addr(work, lane);
   {
     const int64_t pb = P.it_pbeg[item], pe = pb + P.it_pcnt[item];
+    const int half = lane >> 5, pt = lane & 31;
+    // point data one chunk ahead (half 0: x0, x1; half 1: x2, w, sigma, n0, n1, n2), as in k_mdiag
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0, f4 = 0.0, f5 = 0.0;
+    auto fetch = [&](int64_t base) {
+      const bool on = base + pt < pe;
+      const int64_t q = on ? base + pt : pb;
+      if (half == 0)
+        {
+          f0 = P.ap_x[0 * P.ap_stride + q];
+          f1 = P.ap_x[1 * P.ap_stride + q];
+        }
+      else
+        {
+          f0 = P.ap_x[2 * P.ap_stride + q];
+          f1 = on ? P.ap_wcross[q] : 0.0;
+          f2 = P.ap_sig[q];
+          f3 = P.ap_n[0 * P.ap_stride + q];
+          f4 = P.ap_n[1 * P.ap_stride + q];
+          f5 = P.ap_n[2 * P.ap_stride + q];
+        }
+    };
+    if (pb < pe)
+      fetch(pb);
 #if PDHM_EXP == 2
     for (int64_t base = pb; base < pe && P.n < 0; base += Acc::CH)
 #else
@@ -1293,29 +1313,31 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
 #endif
       {
         const int cnt = (int)((pe - base < Acc::CH) ? (pe - base) : Acc::CH);
-        __syncthreads();
+        PDH_WAVE_SYNC();
         {
-          const int half = lane >> 5, pt = lane & 31;
           double xa = 0.5, xb = 0.5, s[4] = {0.0, 0.0, 0.0, 0.0};
           if (pt < cnt)
             {
               if (half == 0)
                 {
-                  xa = (P.ap_x[0 * P.ap_stride + base + pt] - loF[0]) * ihF[0];
-                  xb = (P.ap_x[1 * P.ap_stride + base + pt] - loF[1]) * ihF[1];
+                  xa = (f0 - loF[0]) * ihF[0];
+                  xb = (f1 - loF[1]) * ihF[1];
                 }
               else
                 {
-                  xa = (P.ap_x[2 * P.ap_stride + base + pt] - loF[2]) * ihF[2];
-                  const double w = P.ap_wcross[base + pt];
-                  s[0] = -w * P.ap_sig[base + pt];
-                  for (int c = 0; c < DIM; ++c)
-                    s[1 + c] = 0.5 * w * P.ap_n[c * P.ap_stride + base + pt];
+                  xa = (f0 - loF[2]) * ihF[2];
+                  const double w = f1;
+                  s[0] = -w * f2;
+                  s[1] = 0.5 * w * f3;
+                  s[2] = 0.5 * w * f4;
+                  s[3] = 0.5 * w * f5;
                 }
             }
+          if (base + Acc::CH < pe)
+            fetch(base + Acc::CH);
           Acc::write_face_record_half(work + pt * Acc::REC, half, xa, xb, s);
         }
-        __syncthreads();
+        PDH_WAVE_SYNC();
 #if PDHM_OFF_FULL
         if (cnt == Acc::CH)
           ma.face_chunk_full();
@@ -1325,9 +1347,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
       }
   }
   double accS[NAP], accN[DIM][NAP];
-  __syncthreads();
+  PDH_WAVE_SYNC();
   ma.template scatter<false>(work, lane);
-  __syncthreads();
+  PDH_WAVE_SYNC();
   for (int a = 0; a < NA; ++a)
     {
       const int row = act ? lane : 0;
@@ -1345,7 +1367,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
       {
         static_assert(N1D == 4, "the MFMA contraction is written for FE_DGQ(3)");
         ASet AE0, AH0, AE1, AH1;
-        __syncthreads(); // per-face tables complete
+        PDH_WAVE_SYNC(); // per-face tables complete
         load_aset<true>(tabEQ, M::RS, lane, AE0);
         load_aset<true>(tabHQ, M::RS, lane, AH0);
         load_aset<true>(tabEQ + M::LTAB, M::RS, lane, AE1);
@@ -1366,7 +1388,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
 #pragma unroll 1
         for (int s2 = 0; s2 < PDHM_SLABS; ++s2)
           {
-            __syncthreads();
+            PDH_WAVE_SYNC();
             if (act)
               static_for<0, 4>([&](auto kk_) {
                 constexpr int kk = kk_;
@@ -1388,20 +1410,20 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
               for (int r = 0; r < 4; ++r)
                 D3[c][r] = 0.0;
             {
-              __syncthreads();
+              PDH_WAVE_SYNC();
               double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = EQ0
               mstage2_term(AE1, 0, 1.0, T1B, lane, D2);
               mstage2_term(AH1, 2, 1.0, T1B, lane, D2);
               mstage2_scatter(D2, T2B, lane);
-              __syncthreads();
+              PDH_WAVE_SYNC();
               mstage3(AE0, T2B, lane, D3);
             }
             {
-              __syncthreads();
+              PDH_WAVE_SYNC();
               double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = HQ0
               mstage2_term(AE1, 1, 1.0, T1B, lane, D2);
               mstage2_scatter(D2, T2B, lane);
-              __syncthreads();
+              PDH_WAVE_SYNC();
               mstage3(AH0, T2B, lane, D3);
             }
             // A[Q,P] = A[P,Q]^T: rows 16 s2 .. 16 s2 + 15 of Q's block, complete
@@ -1418,7 +1440,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
             // A[P,Q]: columns 16 s2 .. 16 s2 + 15 of every row O, through an LDS staging tile (full 128-byte lines)
             {
               constexpr int SR = 17;
-              __syncthreads();
+              PDH_WAVE_SYNC();
               double *stage = work;
               static_for<0, 4>([&](auto cf_) {
                 constexpr int cf = cf_;
@@ -1427,7 +1449,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
                   stage[O * SR + r + 4 * cf] = D3[cf][r];
                 });
               });
-              __syncthreads();
+              PDH_WAVE_SYNC();
               const int cc = lane & 15;
               for (int jb = 0; jb < 64; jb += 4)
                 {
@@ -1477,7 +1499,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
       asm volatile("" : "+s"(zero));
       tabEQ = lds + zero;
       tabHQ = lds + 3 * M::LTAB + zero;
-      __syncthreads();
+      PDH_WAVE_SYNC();
       if (act)
         for (int kk = 0; kk < N1D; ++kk)
           {
@@ -1503,18 +1525,18 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
         out[r] = 0.0;
       // X = EQ0 :  EQ1 on array 0  +  HQ1 on EQ2.N1
       {
-        __syncthreads();
+        PDH_WAVE_SYNC();
         const Term<N1D> terms[2] = {{tabEQ + M::LTAB, 0, 1.0}, {tabHQ + M::LTAB, 2, 1.0}};
         stage2<N1D, 2, true>(terms, T1, T2, lane);
-        __syncthreads();
+        PDH_WAVE_SYNC();
         stage3<N1D, true>(tabEQ, T2, o0, o1, o2, out);
       }
       // X = HQ0 :  EQ1 on EQ2.N0
       {
-        __syncthreads();
+        PDH_WAVE_SYNC();
         const Term<N1D> terms[1] = {{tabEQ + M::LTAB, 1, 1.0}};
         stage2<N1D, 1, true>(terms, T1, T2, lane);
-        __syncthreads();
+        PDH_WAVE_SYNC();
         stage3<N1D, true>(tabHQ, T2, o0, o1, o2, out);
       }
       // A[Q,P] = A[P,Q]^T: rows j of the slab, one contiguous segment per row (columns = this wave's lanes)
@@ -1528,7 +1550,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
       // A[P,Q]: this slab holds columns [col_begin,col_end) of every row i.  Through an LDS staging tile so that one
       // store instruction writes 16-column (128 B) pieces of four rows.
       {
-        __syncthreads();
+        PDH_WAVE_SYNC();
         double *stage = work;
         if (live)
           static_for<0, N1D * N1D>([&](auto r_) {
@@ -1536,7 +1558,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
             if (cols_of[r] >= 0)
               stage[lane * SROW + cols_of[r] - col_begin] = out[r];
           });
-        __syncthreads();
+        PDH_WAVE_SYNC();
         const int cols = col_end - col_begin;
         constexpr int W = N1D * N1D; // lanes per row piece (<= 16)
         const int cc = lane % W;

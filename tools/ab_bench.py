@@ -26,12 +26,14 @@ def main():
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--block", type=int, default=2)
+    ap.add_argument("--alg", default="auto", help="auto | direct | moment | rows (pdh_set_algorithm) for both builds")
     a = ap.parse_args()
     grid, ah, fe = bench.build_handler(pa, a.dim, a.cells, a.block, a.fe, a.degree, a.degree + 1)
     flat = ah.flatten(pa.SipVariant.poisson_example(fe), True, False)
     ctxs = {}
     for name, path in (("A", a.lib_a), ("B", a.lib_b)):
         c = pa.Context(0, lib_path=os.path.abspath(path))
+        c.set_algorithm(a.alg)
         c.set_problem(flat)
         if hasattr(c.lib, "pdh_set_overlap"):
             c.set_overlap(False)  # per-kernel times of kernels that have the device to themselves
