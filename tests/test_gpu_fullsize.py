@@ -109,3 +109,86 @@ def test_3d_p2_32768_polytopes_dgq_mixed_algorithm():
     diagonal blocks and the direct form for the coupling blocks - the identities see both."""
     n_dofs, nnz = run_identities(3, 64, 2, pa.FE_DGQ(3, 2), 3)
     assert n_dofs == 884736 and nnz == 27 * 27 * 223232
+
+
+def test_config3_forced_moment_form_fullsize():
+    """The generic moment kernels (k_mdiag / k_moffdiag) at the bench size: AUTO now takes the row kernel on this Cartesian
+    mesh, so the moment form is forced here and must satisfy the same identities (and agree with the row kernel)."""
+    fe = pa.FE_DGQ(3, 3)
+    grid = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 5)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_block_agglomerates(2)
+    ah.initialize_fe_values(4, 4)
+    ah.distribute_agglomerated_dofs(fe)
+    var = pa.SipVariant.poisson_example(fe)
+    flat = ah.flatten(var, True, False)
+    out = {}
+    for alg in ("moment", "rows"):
+        ctx = pa.Context(0)
+        ctx.set_algorithm(alg)
+        ctx.set_problem(flat)
+        assert ctx.algorithm_in_use() == alg
+        out[alg] = ctx.assemble()
+        ctx.close()
+    sc = np.max(np.abs(out["moment"]))
+    assert np.max(np.abs(out["moment"] - out["rows"])) <= 1e-13 * sc
+
+
+def test_config4_diffusion_reaction_128cubed_dgq2_one_gpu():
+    """BASELINE.json configs[3] at its own size on ONE GPU: 128^3 cells, 262 144 polytopes of 2^3 cells, FE_DGQ(2) (n = 27),
+    examples/diffusion_reaction.cc variant (sigma = 10 p^2 / h, owner id() < id(), reaction c = 0.5): 7 077 888 dofs,
+    1.32 G non-zeros (10.6 GB of values).  Identities with the reaction term, for globally continuous v (jumps vanish):
+        1^T A 1 = sigma |dOmega| + c |Omega| = 6 sigma + c
+        x^T A x = -1 + sigma (1 + 4/3) + c / 3
+        sum of (A 1) over the rows of an interior polytope = c |P|      (sum_i phi_i = 1)
+    and the 8 Morton-octant row ranges (what 8 ranks of the reference own) reproduce the rows of the full assembly."""
+    from polydeal_amd.partition import row_range
+
+    fe = pa.FE_DGQ(3, 2)
+    cells, block, dim = 128, 2, 3
+    grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, 7)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_block_agglomerates(block)
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(fe)
+    n = fe.n_dofs_per_cell
+    assert ah.n_agglomerates == 262144 and ah.n_dofs == 7077888
+    var = pa.SipVariant.diffusion_reaction(fe)
+    c = var.reaction_c
+    flat = ah.flatten(var, True, False)
+    assert flat.nnz == n * n * (262144 + 2 * 3 * 64 * 64 * 63)
+    ctx = pa.Context(0)
+    ctx.set_problem(flat)
+    vals = ctx.assemble()
+    assert np.all(np.isfinite(vals))
+    rp = flat.arrays()["rowptr"]
+    # octants: contiguous eighths of the rows (masters are numbered in Morton order)
+    worst = 0.0
+    scale = float(np.max(np.abs(vals)))
+    for r in range(8):
+        r0, r1 = row_range(ah.n_agglomerates, n, r, 8)
+        ctx.set_problem(flat, r0, r1)
+        part = ctx.assemble()
+        worst = max(worst, float(np.max(np.abs(part - vals[rp[r0]:rp[r1]]))))
+        del part
+    ctx.close()
+    assert worst <= 1e-13 * scale, worst / scale
+    _, ci = ah.sparsity_pattern(True)
+    A = sp.csr_matrix((vals, ci, rp), shape=(ah.n_dofs, ah.n_dofs))
+    sigma = var.penalty_constant / ah.diameter(0)
+    v1, vx, off = coefficient_vectors(ah, fe)
+    y1 = A @ v1
+    q1 = float(v1 @ y1)
+    qx = float(vx @ (A @ vx))
+    e1 = 6 * sigma + c
+    ex = -1.0 + sigma * (1.0 + 4.0 / 3.0) + c / 3.0
+    assert abs(q1 - e1) <= 1e-11 * abs(e1), (q1, e1)
+    assert abs(qx - ex) <= 1e-11 * abs(ex), (qx, ex)
+    # interior polytopes: row sums of A 1 over the polytope = c |P|
+    nb = cells // block
+    ids = np.arange(ah.n_agglomerates)
+    sums = y1.reshape(ah.n_agglomerates, n).sum(axis=1)  # rows of a polytope are contiguous, polytopes in dof order
+    volP = (block / cells) ** 3
+    # a polytope is interior iff its row sum needs no boundary term; count them through the value itself
+    interior = np.abs(sums - c * volP) <= 1e-11 * scale
+    assert interior.sum() == (nb - 2) ** 3, interior.sum()

@@ -435,8 +435,48 @@ def test_poisson_output_L2_error_evaluated_on_gpu():
     assert "L2 error:" + gc.fmt(err) == gc.golden_lines("poisson.output")[0]
 
 
+def test_multilevel_block_hierarchy_p3():
+    """configs[4] stand-in at ITS degree (meshes/piston_3.inp is not in the reference snapshot): three R-tree-like block
+    levels (64, 8 and 1 cells per polytope) of a jittered 8^3 grid with FE_DGQ(3), one assemble_dg_matrix per level
+    (examples/simplex_agglomerated_multigrid.cc:378-390), every level against the oracle entry by entry."""
+    import polydeal_amd as pa
+    from polydeal_amd.levels import assemble_levels, block_hierarchy
+
+    grid = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 3).distort(0.15, seed=11)
+    fe = pa.FE_DGQ(3, 3)
+    levels = block_hierarchy(grid, fe, [4, 2, 1])
+    mats = assemble_levels(levels, fe)
+    assert [ah.n_agglomerates for ah in levels] == [8, 64, 512]
+    og = po.hyper_cube_refined(3, 0.0, 1.0, 3)
+    for c in range(og.n_cells):
+        og.vertices[c] = grid.cell_vertices(c)
+    for b, (rp, ci, vals) in zip([4, 2, 1], mats):
+        oah = po.AgglomerationHandler(og)
+        for g in po.block_agglomerates(og, b):
+            oah.define_agglomerate(g)
+        oah.initialize_fe_values(4, 4)
+        oah.distribute_agglomerated_dofs(po.FE_DGQ(3, 3))
+        orp, oci, ref = po.assemble_csr(oah, po.variant_assemble_dg_matrix())
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+        assert np.max(np.abs(vals - ref)) <= TOL * np.max(np.abs(ref))
+    # the same hierarchy on the undistorted grid runs through the row kernel: levels must agree with the moment form
+    grid2 = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 3)
+    for ah in block_hierarchy(grid2, fe, [4, 2, 1]):
+        flat = ah.flatten(pa.SipVariant.assemble_dg_matrix(), True, False)
+        out = {}
+        for alg in ("rows", "moment"):
+            ctx = pa.Context(0)
+            ctx.set_algorithm(alg)
+            ctx.set_problem(flat)
+            assert ctx.algorithm_in_use() == alg
+            out[alg] = ctx.assemble()
+            ctx.close()
+        assert np.max(np.abs(out["rows"] - out["moment"])) <= 1e-13 * np.max(np.abs(out["moment"]))
+
+
 @pytest.mark.parametrize("dim,lg,bc,bf,p,dist", [
     (2, 3, 4, 2, 1, 0.0), (2, 3, 4, 1, 3, 0.2), (2, 4, 8, 2, 7, 0.1), (3, 2, 4, 2, 2, 0.1), (3, 2, 2, 1, 3, 0.0),
+    (3, 3, 4, 2, 3, 0.15), (3, 3, 2, 1, 3, 0.15),  # the level pairs of the p = 3 hierarchy below (configs[4] stand-in)
 ])
 def test_injection_matrix_parity(dim, lg, bc, bf, p, dist):
     """Utils::fill_injection_matrix (include/utils.h:95-270) through the host mirror + pdh_shape_values vs the
@@ -682,7 +722,7 @@ def test_overlapped_and_serial_launch_agree():
     assert np.max(np.abs(out[("direct", False)] - out[("moment", False)])) <= 1e-13 * sc
 
 
-@pytest.mark.parametrize("r,lg", [(2, 2), (4, 3)])
+@pytest.mark.parametrize("r,lg", [(2, 2), (4, 3), (8, 4)])
 def test_moment_form_with_neighbours_of_very_different_size(r, lg):
     """One r^3-cell polytope (index 0, so that its faces are processed from ITS side) among single-cell polytopes.
     The face moments are taken per direction in the shorter of the two bounding-box intervals; in the big polytope's own
