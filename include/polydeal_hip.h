@@ -186,6 +186,9 @@ int pdh_check_exchange(const pdh_problem *problem, int32_t row_begin, int32_t ro
                        int64_t *recv_count);
 /* Copy of the owned rows' values as they stand in HBM (after pdh_assemble_device / pdh_exchange_apply). */
 int pdh_copy_values(pdh_ctx *ctx, double *values);
+/* One pass over the values in HBM: out4 = { sum, sum of |.|, max |.|, number of non-finite entries } of the owned rows -
+ * a validity signal for matrices too large to copy back (for FE_DGQ the sum is 1^T A 1, known in closed form).        */
+int pdh_values_checksum(pdh_ctx *ctx, double *out4);
 
 /* Two algebraically identical forms of the same sums exist (results differ by rounding only, both are tested against
  * the oracle): DIRECT contracts basis values over the quadrature points for all n^2 pairs (f64 MFMA, pdh_kernels.h);

@@ -46,7 +46,7 @@ EXPORTS = [
     "pdh_device_values", "pdh_synchronize", "pdh_stream", "pdh_set_profiling", "pdh_kernel_times_ms",
     "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values", "pdh_set_algorithm", "pdh_algorithm_in_use", "pdh_set_overlap",
     "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
-    "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows",
+    "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows", "pdh_values_checksum",
 ]
 
 _lib = None
@@ -95,6 +95,7 @@ def _bind(lib):
     lib.pdh_check_exchange.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, C.c_int, P(C.c_int64), P(C.c_int64)]
     lib.pdh_copy_values.argtypes = [C.c_void_p, C.c_void_p]
     lib.pdh_check_rows.argtypes = [P(pdh_problem), C.c_int32, C.c_int32]
+    lib.pdh_values_checksum.argtypes = [C.c_void_p, P(C.c_double)]
     lib.pdh_shape_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
@@ -203,6 +204,12 @@ class Context:
         out = np.empty(self.n_values, dtype=np.float64)
         self._chk(self.lib.pdh_assemble(self.h, out.ctypes.data))
         return out
+
+    def checksum(self):
+        """{sum, abs_sum, max_abs, non_finite} of the values as they stand in HBM (one device pass, nothing copied back)."""
+        o = (C.c_double * 4)()
+        self._chk(self.lib.pdh_values_checksum(self.h, o))
+        return {"sum": float(o[0]), "abs_sum": float(o[1]), "max_abs": float(o[2]), "non_finite": int(o[3])}
 
     def values(self):
         """The CSR values as they stand in HBM (no re-assembly)."""

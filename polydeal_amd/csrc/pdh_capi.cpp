@@ -198,7 +198,7 @@ static int upload(pdh_ctx *ctx, const std::vector<T> &h, const T **dptr)
   return PDH_OK;
 }
 
-extern "C" const char *pdh_version(void) { return "polydeal_hip 0.1 gfx950"; }
+extern "C" const char *pdh_version(void) { return "polydeal_hip 0.2 gfx950"; }
 
 extern "C" const char *pdh_last_error(const pdh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err_noctx.c_str(); }
 
@@ -1337,6 +1337,29 @@ extern "C" int pdh_copy_values(pdh_ctx *ctx, double *values)
   PDH_HIP(ctx, hipSetDevice(ctx->device));
   PDH_HIP(ctx, hipMemcpyAsync(values, ctx->dev.values, ctx->n_values * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PDH_OK;
+}
+
+extern "C" hipError_t pdh_launch_checksum(const double *values, int64_t n, double *d_out4, hipStream_t stream);
+
+// sum, sum of |.|, max |.| and number of non-finite entries of the owned rows' values as they stand in HBM
+extern "C" int pdh_values_checksum(pdh_ctx *ctx, double *out4)
+{
+  if (!ctx || !ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "no problem resident");
+  if (!out4)
+    return fail(ctx, PDH_EINVAL, "out4 is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  double *d = nullptr;
+  PDH_HIP(ctx, hipMalloc((void **)&d, 4 * sizeof(double)));
+  hipError_t e = pdh_launch_checksum(ctx->dev.values, ctx->n_values, d, ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(out4, d, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess)
+    return fail(ctx, PDH_EDEVICE, std::string("pdh_values_checksum: ") + hipGetErrorString(e));
   return PDH_OK;
 }
 

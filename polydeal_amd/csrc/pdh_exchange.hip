@@ -54,3 +54,49 @@ extern "C" hipError_t pdh_launch_ghost_apply(const PdhDev *P, const double *recv
                      n_r22, r22_ptr, r22_src, r22_slot);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Validity signal for matrices too large to copy back (pdh_values_checksum): sum, sum of |.|, max |.| and the number of
+// non-finite entries of the owned rows' values, in one pass over HBM.  For FE_DGQ the sum of all entries is 1^T A 1, which
+// the SIP form fixes in closed form (sigma |dOmega| + c |Omega| for Nitsche boundaries) - bench.py checks it every run.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_checksum(const double *__restrict__ v, const int64_t n, double *__restrict__ out)
+{
+  double s = 0.0, sa = 0.0, mx = 0.0, bad = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    {
+      const double x = v[i];
+      if (isfinite(x))
+        {
+          s += x;
+          sa += fabs(x);
+          mx = fmax(mx, fabs(x));
+        }
+      else
+        bad += 1.0;
+    }
+  for (int o = 32; o > 0; o >>= 1)
+    {
+      s += __shfl_down(s, o);
+      sa += __shfl_down(sa, o);
+      bad += __shfl_down(bad, o);
+      mx = fmax(mx, __shfl_down(mx, o));
+    }
+  if ((threadIdx.x & 63) == 0)
+    {
+      atomicAdd(out + 0, s);
+      atomicAdd(out + 1, sa);
+      atomicAdd(out + 3, bad);
+      // max through the integer order of non-negative doubles
+      atomicMax(reinterpret_cast<unsigned long long *>(out + 2), (unsigned long long)__double_as_longlong(mx));
+    }
+}
+
+extern "C" hipError_t pdh_launch_checksum(const double *values, int64_t n, double *d_out4, hipStream_t stream)
+{
+  hipError_t e = hipMemsetAsync(d_out4, 0, 4 * sizeof(double), stream);
+  if (e != hipSuccess || n <= 0)
+    return e;
+  hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, stream, values, n, d_out4);
+  return hipGetLastError();
+}

@@ -39,6 +39,9 @@ for kname in sorted({k for (k, c) in out}):
     if (kname, "FETCH_SIZE") in out and (kname, "WRITE_SIZE") in out and kname.startswith("k_"):
         entry[kname + "_bytes"] = tr(kname)
 entry["round"] = tag
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import polydeal_amd  # noqa: E402
+entry["lib_version"] = polydeal_amd.load_library().pdh_version().decode()
 entry["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/%s_pmc_summary.json); bytes = "
                  "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of coalesced streaming reads "
                  "(MI355X_MICROARCH.md, HBM); checked: 2*FETCH matches the algorithmic read bytes of k_diag within a few %%" % tag)
