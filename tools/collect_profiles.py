@@ -34,9 +34,9 @@ def tr(k):
 tpath = "profiles/traffic.json"
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
 wl = "3D cells=64 block=2 dgq p=3"
-entry = t.get(wl, {})
+entry = {}  # only what THIS run measured: byte counts of older kernels must not survive under a new library version
 for kname in sorted({k for (k, c) in out}):
-    if (kname, "FETCH_SIZE") in out and (kname, "WRITE_SIZE") in out and kname.startswith("k_"):
+    if (kname, "FETCH_SIZE") in out and (kname, "WRITE_SIZE") in out and kname.startswith("k_") and "(" not in kname:
         entry[kname + "_bytes"] = tr(kname)
 entry["round"] = tag
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
