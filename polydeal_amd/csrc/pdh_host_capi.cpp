@@ -128,6 +128,10 @@ int pdhh_distribute_agglomerated_dofs(void *h, int basis, int degree)
 }
 int pdhh_n_agglomerates(void *h) { return (int)AH.n_agglomerates(); }
 int pdhh_n_dofs(void *h) { return (int)AH.n_dofs(); }
+int pdhh_agglomerate_size(void *h, int P)
+{
+  return guarded([&] { return (int)AH.get_agglomerate(P).size(); });
+}
 int pdhh_n_dofs_per_cell(void *h) { return (int)AH.n_dofs_per_cell(); }
 int pdhh_master_index(void *h, int P)
 {

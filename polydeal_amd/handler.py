@@ -37,7 +37,7 @@ def _lib():
         lib.pdhh_distribute_agglomerated_dofs.argtypes = [C.c_void_p, C.c_int, C.c_int]
         for name in ("pdhh_n_agglomerates", "pdhh_n_dofs", "pdhh_n_dofs_per_cell"):
             getattr(lib, name).argtypes = [C.c_void_p]
-        for name in ("pdhh_master_index", "pdhh_master_slave_value", "pdhh_n_faces", "pdhh_dof_offset"):
+        for name in ("pdhh_master_index", "pdhh_master_slave_value", "pdhh_n_faces", "pdhh_dof_offset", "pdhh_agglomerate_size"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_int]
         for name in ("pdhh_at_boundary", "pdhh_neighbor", "pdhh_neighbor_of_agglomerated_neighbor"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -281,6 +281,10 @@ class AgglomerationHandler:
 
     def master_slave_value(self, cell):
         return _lib().pdhh_master_slave_value(self.h, cell)
+
+    def agglomerate_size(self, P):
+        """Number of cells of polytope P (polytope->get_agglomerate().size())."""
+        return _lib().pdhh_agglomerate_size(self.h, P)
 
     def n_faces_of(self, P):
         return _lib().pdhh_n_faces(self.h, P)

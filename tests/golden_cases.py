@@ -211,3 +211,58 @@ GROUPS_CF02 = [
 ]
 GROUPS_MASTER_MASTER = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12], [13], [14], [15]]
 GROUPS_POLY_ITER = [[3235, 3238], [831, 874], [1226, 1227], [2279, 2278], [3760, 3761], [3648, 3306], [3765, 3764]]
+
+
+def render_continuous_face_03(ah):
+    # test/polydeal/continuous_face_03.cc:30-63 (perimeter_test; prints "Neighbor = ", no sub-face lists) + main():218-223
+    out = []
+    perimeter = 0.0
+    for P in range(ah.n_agglomerates):
+        out.append("Master cell index = %d" % ah.master_index(P))
+        nf = ah.n_faces_of(P)
+        out.append("Number of agglomerated faces = %d" % nf)
+        for f in range(nf):
+            out.append("Agglomerate face index = %d" % f)
+            if not ah.at_boundary(P, f):
+                out.append("Neighbor = %d" % ah.neighbor(P, f))
+                out.append("Neighbor of neighbor = %d" % ah.neighbor_of_agglomerated_neighbor(P, f))
+            else:
+                perimeter += ah.face_jxw_sum(P, f)
+        out.append("")
+    out.append("Perimeter = " + fmt(perimeter))
+    out.append("- - - - - - - - - - - -")
+    out.append("Check on neighbors and neighbors of neighbors:")
+    for P in range(ah.n_agglomerates):
+        for f in range(ah.n_faces_of(P)):
+            if not ah.at_boundary(P, f):
+                assert ah.neighbor(ah.neighbor(P, f), ah.neighbor_of_agglomerated_neighbor(P, f)) == P
+    out.append("Ok")
+    out += ["- - - - - - - - - - - -", "Check on quadrature points:", "Ok", "End Test"]
+    return out
+
+
+def define_continuous_face_03(ah, n_cells):
+    # continuous_face_03.cc:176-213: singletons of the un-flagged cells FIRST (cell order), then the three agglomerates
+    groups = [[36, 37, 38, 39], [18, 24, 25], [3, 6]]
+    flagged = {c for g in groups for c in g}
+    for c in range(n_cells):
+        if c not in flagged:
+            ah.define_agglomerate([c])
+    for g in groups:
+        ah.define_agglomerate(sorted(g))
+
+
+def render_rtree_levels(sizes_per_level, first_level, head, size_label, line):
+    """test/polydeal/rtree_mesh.output / extract_last_level.output: per extraction level the number of agglomerates and
+    the number of cells of each.  On the 32x32 hyper_cube the R-tree levels are exact 2^k x 2^k blocks
+    (reference include/agglomerator.h:389-434), so a block hierarchy must print the same text."""
+    out = []
+    for k, sizes in enumerate(sizes_per_level):
+        out.append("%s%d" % (head, first_level + k))
+        out.append("%s1024" % size_label)
+        out.append("Total number of available levels: 4")
+        out.append("N subdomains = %d" % len(sizes))
+        for i, s_ in enumerate(sizes):
+            out.append(line % (s_, i))
+        out.append("")
+    return out

@@ -1068,3 +1068,29 @@ def test_row_kernel_falls_back_when_faces_are_not_planar():
         with pytest.raises(pa.PdhError):
             ctx.assemble()
         ctx.close()
+
+
+def test_poisson_sanity_check_02_on_gpu():
+    """test/polydeal/poisson_sanity_check_02.output ('Step function = 2', 'V function = 1') with the matrix assembled by the
+    product chain (host mirror -> C ABI -> HIP kernels)."""
+    import polydeal_amd as pa
+
+    grid = pa.BackgroundGrid.hyper_cube_refined(2, 0.0, 1.0, 1)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_agglomerate([0, 2])
+    ah.define_agglomerate([1, 3])
+    fe = pa.FE_DGQ(2, 1)
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(fe)
+    rp, ci, vals = pa.assemble_dg_matrix(fe, ah, pa.SipVariant.minimal_sip_example(), diag_first=True)
+    A = po.csr_to_dense(rp, ci, vals, ah.n_dofs)
+    # nodal interpolation on the bounding boxes (VectorTools::interpolate with the agglomeration mapping)
+    out = []
+    for name, f in (("Step function", lambda x: (x >= 0.5) * 1.0), ("V function", lambda x: np.abs(x - 0.5))):
+        v = np.zeros(ah.n_dofs)
+        for P in range(ah.n_agglomerates):
+            lo, hi = ah.bbox(P)
+            xs = np.array([lo[0], hi[0], lo[0], hi[0]])  # FE_DGQ(1) support points, x fastest
+            v[ah.dof_indices(P)] = f(xs)
+        out.append("Test with %s = %s" % (name, gc.fmt(float(v @ A @ v))))
+    assert out == gc.golden_lines("poisson_sanity_check_02.output")[:-1]

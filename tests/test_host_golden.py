@@ -164,3 +164,26 @@ def test_reinit_cell_face_02_and_agglomerated_neighbors_01():
     assert gc.render_reinit_cell_face_02(ah) == gc.golden_lines("reinit_cell_face_02.output")[:-1]
     _, ah = make(2, 3, gc.GROUPS_FOUR)
     assert gc.render_neighbors_02(ah) == gc.golden_lines("agglomerated_neighbors_01.output")[:-1]
+
+
+def test_continuous_face_03():
+    """test/polydeal/continuous_face_03.output on the product's host mirror."""
+    grid = pa.BackgroundGrid.hyper_cube_refined(2, -1.0, 1.0, 3)
+    ah = pa.AgglomerationHandler(grid)
+    gc.define_continuous_face_03(ah, grid.n_cells)
+    ah.initialize_fe_values(1, 1)
+    ah.distribute_agglomerated_dofs(pa.FE_DGQ(2, 1))
+    assert gc.render_continuous_face_03(ah) == gc.golden_lines("continuous_face_03.output")[:-1]
+
+
+def test_rtree_level_counts_of_block_hierarchies():
+    """rtree_mesh.output / extract_last_level.output pin polydeal_amd.levels.block_hierarchy (product side)."""
+    from polydeal_amd.levels import block_hierarchy
+
+    grid = pa.BackgroundGrid.hyper_cube_refined(2, 0.0, 1.0, 5)
+    levels = block_hierarchy(grid, pa.FE_DGQ(2, 1), [32, 16, 8, 4, 2])
+    sizes = [[ah.agglomerate_size(P) for P in range(ah.n_agglomerates)] for ah in levels]
+    assert gc.render_rtree_levels(sizes[1:4], 1, "Extraction level = ", "Size of fine triangulation: ",
+                                  "%d cells have subdomain id = %d") == gc.golden_lines("rtree_mesh.output")[:-1]
+    assert gc.render_rtree_levels(sizes, 0, "Extract level: ", "Size of tria: ",
+                                  "%d cells are composing agglomerate %d") == gc.golden_lines("extract_last_level.output")[:-1]

@@ -311,3 +311,41 @@ def test_injection_matrix_reproduces_the_coarse_function(dim, lg, p, distort):
     err = M @ po.interpolate_nodal(coarse, f) - po.interpolate_nodal(fine, f)
     assert np.max(np.abs(err)) < 5e-14
     assert np.allclose(M.sum(axis=1), 1.0, atol=1e-13)  # partition of unity: rows sum to one
+
+
+def test_continuous_face_03():
+    """test/polydeal/continuous_face_03.output (834 lines): 8x8 grid, singletons first, then {36..39}, {18,24,25}, {3,6}."""
+    grid = po.hyper_cube_refined(2, -1.0, 1.0, 3)
+    ah = po.AgglomerationHandler(grid)
+    gc.define_continuous_face_03(ah, grid.n_cells)
+    ah.initialize_fe_values(1, 1)
+    ah.distribute_agglomerated_dofs(po.FE_DGQ(2, 1))
+    assert gc.render_continuous_face_03(ah) == gc.golden_lines("continuous_face_03.output")[:-1]
+
+
+def test_poisson_sanity_check_02():
+    """test/polydeal/poisson_sanity_check_02.output: two half-square polytopes, v^T A v = 2 (step function) and 1 (|x - 1/2|)."""
+    grid = po.hyper_cube_refined(2, 0.0, 1.0, 1)
+    ah = po.AgglomerationHandler(grid)
+    ah.define_agglomerate([0, 2])
+    ah.define_agglomerate([1, 3])
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(po.FE_DGQ(2, 1))
+    A = po.assemble_dense(ah, po.variant_minimal_sip_example())  # poisson_sanity_check_02.cc:214-262: 10 max(1/h), zeroed boundary
+    out = []
+    for name, f in (("Step function", lambda x: (x[:, 0] >= 0.5) * 1.0), ("V function", lambda x: np.abs(x[:, 0] - 0.5))):
+        v = po.interpolate_nodal(ah, f)
+        out.append("Test with %s = %s" % (name, gc.fmt(float(v @ A @ v))))
+    assert out == gc.golden_lines("poisson_sanity_check_02.output")[:-1]
+
+
+def test_rtree_level_counts_of_block_hierarchies():
+    """test/polydeal/rtree_mesh.output and extract_last_level.output: on the 32x32 hyper_cube the R-tree levels the reference
+    extracts (include/agglomerator.h:389-434) are 4^l agglomerates of 1024 / 4^l cells - exactly the block hierarchy that
+    stands in for them here (blocks of 32, 16, 8, 4, 2 cells per direction)."""
+    grid = po.hyper_cube_refined(2, 0.0, 1.0, 5)
+    sizes = [[len(g) for g in po.block_agglomerates(grid, b)] for b in (32, 16, 8, 4, 2)]
+    assert gc.render_rtree_levels(sizes[1:4], 1, "Extraction level = ", "Size of fine triangulation: ",
+                                  "%d cells have subdomain id = %d") == gc.golden_lines("rtree_mesh.output")[:-1]
+    assert gc.render_rtree_levels(sizes, 0, "Extract level: ", "Size of tria: ",
+                                  "%d cells are composing agglomerate %d") == gc.golden_lines("extract_last_level.output")[:-1]
