@@ -156,6 +156,12 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
                         note="sum of all entries = 1^T A 1 = sum_bdry sigma |F| + c |Omega| for FE_DGQ")
     vals = ctx.assemble() if stats["n_values"] <= 64_000_000 else None
     chk = validity
+    aux = None
+    if world == 1 and args.aux_kernels and alg == "auto":
+        try:
+            aux = time_aux_kernels(torch, ctx, flat, n, stats)
+        except Exception as exc:
+            aux = {"error": repr(exc)}
     ctx.close()
     ghost = None
     if world > 1 and args.exchange_extra and alg == "auto":
@@ -165,7 +171,46 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
             ghost = {"error": repr(exc)}
     return dict(n_dofs=ah.n_dofs, n_agg=n_agg, n=n, dt=dt, kms=kms, nl=nl, stats=stats, work=work, mfma=mfma,
                 t_setup=t_setup, nnz=flat.nnz if world == 1 else None, checksum=chk, alg=alg_used, dt_overlap=dt_overlap,
-                ghost=ghost, local=world > 1)
+                ghost=ghost, local=world > 1, aux=aux)
+
+
+def time_aux_kernels(torch, ctx, flat, n, stats):
+    """The callers' other device work on the resident problem, through the device-pointer entry points (nothing allocated or
+    copied per call): right-hand side (k_rhs; examples/poisson.cc:745-759, 788-828) and evaluation of u_h and grad u_h at the
+    volume quadrature points (k_eval; PolyUtils::compute_global_error, include/poly_utils.h:1686-1731).  Both are HBM-bound."""
+    import numpy as np
+    arr = flat.arrays()
+    d = flat.c.dim
+    nq, nqf = flat.nq_tot, flat.nqf_tot
+    dev = "cuda"
+    f_vol = torch.rand(max(nq, 1), dtype=torch.float64, device=dev)
+    g_b = torch.rand(max(nqf, 1), dtype=torch.float64, device=dev)
+    rhs = torch.zeros(stats["n_owned_agg"] * n, dtype=torch.float64, device=dev)
+    sol = torch.rand(stats["n_owned_agg"] * n, dtype=torch.float64, device=dev)
+    pts = torch.from_numpy(np.ascontiguousarray(arr["vq_x"])).to(dev)
+    ptr = torch.from_numpy(np.ascontiguousarray(arr["vq_ptr"])).to(dev)
+    u = torch.zeros(nq, dtype=torch.float64, device=dev)
+    g = torch.zeros(d * nq, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    reps = 5
+
+    def timed(fn):
+        fn()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    t_rhs = timed(lambda: ctx.assemble_rhs_device(f_vol.data_ptr(), g_b.data_ptr(), rhs.data_ptr()))
+    t_ev = timed(lambda: ctx.evaluate_device(sol.data_ptr(), ptr.data_ptr(), pts.data_ptr(), nq, u.data_ptr(), g.data_ptr()))
+    nbd = float(np.diff(arr["fq_ptr"])[arr["face_out"] < 0].sum()) if flat.c.n_faces else 0.0
+    by_rhs = 8.0 * (d + 2) * nq + 8.0 * (2 * d + 4) * stats["n_face_side_points"] + 8.0 * nbd + 8.0 * rhs.numel()
+    by_ev = 8.0 * d * nq + 8.0 * (d + 1) * nq + 8.0 * sol.numel()
+    return {"k_rhs": {"ms": 1e3 * t_rhs, "algorithmic_bytes": by_rhs, "GBs": by_rhs / t_rhs * 1e-9, "frac_of_hbm_peak": by_rhs / t_rhs * 1e-9 / HBM_PEAK_GBS},
+            "k_eval": {"ms": 1e3 * t_ev, "points": nq, "algorithmic_bytes": by_ev, "GBs": by_ev / t_ev * 1e-9,
+                       "frac_of_hbm_peak": by_ev / t_ev * 1e-9 / HBM_PEAK_GBS, "note": "u_h and grad u_h at the volume quadrature points"}}
 
 
 def run_ghost_exchange(pa, torch, dist, args, flat, r0, r1, rank, world, local_rank, steps, warmup, ref_vals):
@@ -299,6 +344,8 @@ def main():
                          "(roofline.overlapped_ms_per_step); off by default so that a rocprofv3 trace of the default command "
                          "contains serialised launches only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux-kernels", dest="aux_kernels", action="store_false",
+                    help="skip the timing of the right-hand-side and evaluation kernels (extra.aux_kernels)")
     ap.add_argument("--no-exchange-extra", dest="exchange_extra", action="store_false",
                     help="N>1: skip the second measurement with the reference's ghost-block exchange (M21/M22 shipped over RCCL)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -351,6 +398,8 @@ def main():
                  "dofs_per_polytope": r2["n"], "n_dofs": r2["n_dofs"],
                  "value": r2["n_dofs"] / (r2["dt"] / args.steps), "ms_per_step": 1e3 * r2["dt"] / args.steps,
                  "algorithm": r2["alg"], "kernel_ms": {"diagonal_blocks": r2["kms"][0], "coupling_blocks": r2["kms"][1]}}
+    if main_res.get("aux") is not None:
+        extra["aux_kernels"] = main_res["aux"]
     direct = None
     if main_res["alg"] != "direct" and not args.no_extra:
         # the same workload through the direct (MFMA contraction) form, for the record

@@ -151,6 +151,18 @@ int pdh_evaluate(pdh_ctx *ctx, const double *solution, const int64_t *pt_ptr, co
 int pdh_shape_values(pdh_ctx *ctx, int dim, int degree, int basis, int n_boxes, const double *bbox,
                      const int64_t *pt_ptr, const double *pts, double *values);
 
+/* Device-resident variants of the three calls above: every pointer is DEVICE memory, nothing is allocated or copied,
+ * the kernels are queued on pdh_stream() and the call returns (pdh_synchronize waits).  Arrays are in the CALLER's order,
+ * exactly as for the host variants: d_f_vol [Nq_tot] / d_g_bdry [Nqf_tot] sampled at vq_x / fq_x of the resident
+ * description (NULL = absent), d_rhs [row_end-row_begin]; d_pt_ptr [n_agg+1], d_pts [dim][n_points] (component stride
+ * n_points), d_u [n_points], d_grad [dim][n_points] or NULL - only the points of polytopes owned by the context are written.
+ * The host variants are these plus the transfers through grow-only scratch buffers of the context.              */
+int pdh_assemble_rhs_device(pdh_ctx *ctx, const double *d_f_vol, const double *d_g_bdry, double *d_rhs);
+int pdh_evaluate_device(pdh_ctx *ctx, const double *d_solution, const int64_t *d_pt_ptr, const double *d_pts, int64_t n_points,
+                        double *d_u, double *d_grad);
+int pdh_shape_values_device(pdh_ctx *ctx, int dim, int degree, int basis, int n_boxes, const double *d_bbox,
+                            const int64_t *d_pt_ptr, const double *d_pts, int64_t n_points, double *d_values);
+
 /* Access to device-resident results and synchronisation. */
 int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values);
 int pdh_synchronize(pdh_ctx *ctx);

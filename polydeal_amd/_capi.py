@@ -47,6 +47,7 @@ EXPORTS = [
     "pdh_problem_stats", "pdh_check_problem", "pdh_version", "pdh_assemble_rhs", "pdh_kernel_work", "pdh_evaluate", "pdh_shape_values", "pdh_set_algorithm", "pdh_algorithm_in_use", "pdh_set_overlap",
     "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
     "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows", "pdh_values_checksum",
+    "pdh_assemble_rhs_device", "pdh_evaluate_device", "pdh_shape_values_device",
 ]
 
 _lib = None
@@ -96,6 +97,10 @@ def _bind(lib):
     lib.pdh_copy_values.argtypes = [C.c_void_p, C.c_void_p]
     lib.pdh_check_rows.argtypes = [P(pdh_problem), C.c_int32, C.c_int32]
     lib.pdh_values_checksum.argtypes = [C.c_void_p, P(C.c_double)]
+    lib.pdh_assemble_rhs_device.argtypes = [C.c_void_p] * 4
+    lib.pdh_evaluate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.pdh_shape_values_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_void_p]
     lib.pdh_shape_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
@@ -226,6 +231,14 @@ class Context:
         self._chk(self.lib.pdh_assemble_rhs(self.h, None if fv is None else fv.ctypes.data,
                                             None if gb is None else gb.ctypes.data, out.ctypes.data))
         return out
+
+    def assemble_rhs_device(self, d_f_vol, d_g_bdry, d_rhs):
+        """Device pointers (ints or None), caller order; asynchronous on the context's stream."""
+        self._chk(self.lib.pdh_assemble_rhs_device(self.h, C.c_void_p(d_f_vol or 0), C.c_void_p(d_g_bdry or 0), C.c_void_p(d_rhs)))
+
+    def evaluate_device(self, d_solution, d_pt_ptr, d_pts, n_points, d_u, d_grad=None):
+        self._chk(self.lib.pdh_evaluate_device(self.h, C.c_void_p(d_solution), C.c_void_p(d_pt_ptr), C.c_void_p(d_pts), n_points,
+                                               C.c_void_p(d_u), C.c_void_p(d_grad or 0)))
 
     def evaluate(self, solution, pt_ptr, pts, want_grad=False):
         """u_h (and grad u_h) at caller-given real points; pt_ptr [n_agg+1], pts [dim][N]."""

@@ -29,11 +29,12 @@ PDH_DECL(0) PDH_DECL(1) PDH_DECL(2) PDH_DECL(3) PDH_DECL(4) PDH_DECL(5) PDH_DECL
 }
 
 extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int count, const double *f_vol,
-                                     const double *g_face, double *rhs, hipStream_t stream);
+                                     const double *g_face, double *rhs, const int64_t *vq_src, const int64_t *ap_src,
+                                     hipStream_t stream);
 
 extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *P, int count, const double *coef,
                                       const int64_t *pt_ptr, const double *pts, int64_t pts_stride, double *out_u,
-                                      double *out_g, hipStream_t stream);
+                                      double *out_g, int by_agg, hipStream_t stream);
 
 extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_boxes, const int64_t *pt_ptr,
                                        const double *pts, int64_t pts_stride, double *out, hipStream_t stream);
@@ -101,6 +102,32 @@ struct pdh_ctx
   std::vector<FaceRun> face_runs;
   int64_t n_rows_owned = 0;
   int32_t n_agg_total = 0;
+  // caller-order maps for the right-hand side (device): first caller volume point of every slot; caller face point of every
+  // packed face point (-1: not on the boundary); sizes of the caller's point arrays
+  const int64_t *d_vq_src = nullptr, *d_ap_src = nullptr;
+  int64_t n_vq_caller = 0, n_fq_caller = 0;
+  // grow-only device scratch for the host-pointer variants of rhs / evaluate / shape_values (no hipMalloc per call)
+  struct Scratch { void *p = nullptr; size_t bytes = 0; };
+  Scratch scratch[6];
+  void *scratch_get(int i, size_t bytes)
+  {
+    Scratch &s = scratch[i];
+    if (bytes > s.bytes)
+      {
+        if (s.p)
+          (void)hipFree(s.p);
+        s.p = nullptr;
+        s.bytes = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&s.p, want) != hipSuccess)
+          return nullptr;
+        s.bytes = want;
+      }
+    return s.p;
+  }
+  // cached multi-index table of pdh_shape_values (per dim/degree/basis)
+  int shape_key = -1;
+  int32_t *d_shape_midx = nullptr;
   int64_t mfma_diag = 0, mfma_offdiag = 0; // MFMA instructions per launch
   // ghost-block exchange variant (pdh_set_exchange_mode); n_diag_slots = n_owned + pseudo slots of the outgoing M22 sums
   int exchange_mode = PDH_EXCHANGE_NONE;
@@ -242,6 +269,11 @@ extern "C" void pdh_destroy(pdh_ctx *ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   free_problem(ctx);
+  for (auto &sc : ctx->scratch)
+    if (sc.p)
+      (void)hipFree(sc.p);
+  if (ctx->d_shape_midx)
+    (void)hipFree(ctx->d_shape_midx);
   for (auto &ev : ctx->events)
     if (ev)
       (void)hipEventDestroy(ev);
@@ -1029,6 +1061,20 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   ctx->lds_diag = pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
   ctx->lds_off = pdh::lds_bytes_offdiag(p->dim, K.n1d, K.NT);
   ctx->vq_src = K.vq_src;
+  {
+    std::vector<int64_t> ap_src(K.ap_wself.size(), -1);
+    for (size_t r = 0; r < K.run_ap.size(); ++r)
+      if (K.run_bdry[r])
+        for (int32_t t = 0; t < K.run_cnt[r]; ++t)
+          ap_src[K.run_ap[r] + t] = K.run_fq[r] + t;
+    if ((rc = upload(ctx, K.vq_src, &ctx->d_vq_src)) != PDH_OK || (rc = upload(ctx, ap_src, &ctx->d_ap_src)) != PDH_OK)
+      {
+        free_problem(ctx);
+        return rc;
+      }
+    ctx->n_vq_caller = p->vq_ptr[p->n_agg];
+    ctx->n_fq_caller = p->n_faces ? p->fq_ptr[p->n_faces] : 0;
+  }
   ctx->face_runs.clear();
   for (size_t r = 0; r < K.run_ap.size(); ++r)
     ctx->face_runs.push_back({K.run_ap[r], K.run_fq[r], K.run_cnt[r], K.run_bdry[r]});
@@ -1378,6 +1424,21 @@ extern "C" int pdh_assemble_sip(pdh_ctx *ctx, const pdh_problem *p, double *valu
   return pdh_assemble_sip_local(ctx, p, 0, p->n_rows, values);
 }
 
+// ---- right-hand side -------------------------------------------------------------------------------------------------
+extern "C" int pdh_assemble_rhs_device(pdh_ctx *ctx, const double *d_f_vol, const double *d_g_bdry, double *d_rhs)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (!ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "pdh_assemble_rhs called before pdh_set_problem");
+  if (!d_rhs)
+    return fail(ctx, PDH_EINVAL, "rhs is NULL");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, pdh_launch_rhs(ctx->dev.dim, ctx->dev.n1d, &ctx->dev, ctx->n_owned, d_f_vol, d_g_bdry, d_rhs, ctx->d_vq_src,
+                              ctx->d_ap_src, ctx->stream));
+  return PDH_OK;
+}
+
 extern "C" int pdh_assemble_rhs(pdh_ctx *ctx, const double *f_vol, const double *g_bdry, double *rhs)
 {
   if (!ctx)
@@ -1387,54 +1448,40 @@ extern "C" int pdh_assemble_rhs(pdh_ctx *ctx, const double *f_vol, const double 
   if (!rhs)
     return fail(ctx, PDH_EINVAL, "rhs is NULL");
   PDH_HIP(ctx, hipSetDevice(ctx->device));
-  // repack the caller's samples into the device point order
-  std::vector<double> fv, gf;
-  double *d_f = nullptr, *d_g = nullptr, *d_rhs = nullptr;
-  auto cleanup = [&]() {
-    if (d_f)
-      (void)hipFree(d_f);
-    if (d_g)
-      (void)hipFree(d_g);
-    if (d_rhs)
-      (void)hipFree(d_rhs);
-  };
+  // the caller's samples go up as they are (caller order; the kernel indexes them through the maps made at set_problem)
+  double *d_f = nullptr, *d_g = nullptr;
+  double *d_rhs = static_cast<double *>(ctx->scratch_get(2, std::max<int64_t>(ctx->n_rows_owned, 1) * sizeof(double)));
   if (f_vol)
-    {
-      fv.resize((size_t)std::max<int64_t>(ctx->n_vq, 1));
-      std::vector<int64_t> vptr((size_t)ctx->n_owned + 1);
-      PDH_HIP(ctx, hipMemcpy(vptr.data(), ctx->dev.vq_ptr, vptr.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-      for (int sl = 0; sl < ctx->n_owned; ++sl)
-        for (int64_t q = vptr[sl]; q < vptr[sl + 1]; ++q)
-          fv[q] = f_vol[ctx->vq_src[sl] + (q - vptr[sl])];
-      PDH_HIP(ctx, hipMalloc((void **)&d_f, fv.size() * sizeof(double)));
-      PDH_HIP(ctx, hipMemcpy(d_f, fv.data(), fv.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
+    d_f = static_cast<double *>(ctx->scratch_get(0, std::max<int64_t>(ctx->n_vq_caller, 1) * sizeof(double)));
   if (g_bdry)
-    {
-      gf.assign((size_t)std::max<int64_t>(ctx->n_ap, 1), 0.0);
-      for (const auto &run : ctx->face_runs)
-        if (run.boundary)
-          for (int32_t t = 0; t < run.count; ++t)
-            gf[run.ap_begin + t] = g_bdry[run.fq_begin + t];
-      hipError_t e = hipMalloc((void **)&d_g, gf.size() * sizeof(double));
-      if (e == hipSuccess)
-        e = hipMemcpy(d_g, gf.data(), gf.size() * sizeof(double), hipMemcpyHostToDevice);
-      if (e != hipSuccess)
-        {
-          cleanup();
-          return fail(ctx, PDH_EDEVICE, std::string("rhs upload: ") + hipGetErrorString(e));
-        }
-    }
-  hipError_t e = hipMalloc((void **)&d_rhs, std::max<int64_t>(ctx->n_rows_owned, 1) * sizeof(double));
-  if (e == hipSuccess)
-    e = pdh_launch_rhs(ctx->dev.dim, ctx->dev.n1d, &ctx->dev, ctx->n_owned, d_f, d_g, d_rhs, ctx->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(rhs, d_rhs, ctx->n_rows_owned * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess)
-    e = hipStreamSynchronize(ctx->stream);
-  cleanup();
-  if (e != hipSuccess)
-    return fail(ctx, PDH_EDEVICE, std::string("pdh_assemble_rhs: ") + hipGetErrorString(e));
+    d_g = static_cast<double *>(ctx->scratch_get(1, std::max<int64_t>(ctx->n_fq_caller, 1) * sizeof(double)));
+  if (!d_rhs || (f_vol && !d_f) || (g_bdry && !d_g))
+    return fail(ctx, PDH_EDEVICE, "pdh_assemble_rhs: out of device memory");
+  if (f_vol)
+    PDH_HIP(ctx, hipMemcpyAsync(d_f, f_vol, ctx->n_vq_caller * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (g_bdry)
+    PDH_HIP(ctx, hipMemcpyAsync(d_g, g_bdry, ctx->n_fq_caller * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const int rc = pdh_assemble_rhs_device(ctx, d_f, d_g, d_rhs);
+  if (rc != PDH_OK)
+    return rc;
+  PDH_HIP(ctx, hipMemcpyAsync(rhs, d_rhs, ctx->n_rows_owned * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PDH_OK;
+}
+
+// ---- evaluation ------------------------------------------------------------------------------------------------------
+extern "C" int pdh_evaluate_device(pdh_ctx *ctx, const double *d_solution, const int64_t *d_pt_ptr, const double *d_pts,
+                                   int64_t n_points, double *d_u, double *d_grad)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (!ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "pdh_evaluate called before pdh_set_problem");
+  if (!d_solution || !d_pt_ptr || !d_pts || !d_u || n_points < 0)
+    return fail(ctx, PDH_EINVAL, "solution, pt_ptr, pts and u are required");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  PDH_HIP(ctx, pdh_launch_eval(ctx->dev.dim, ctx->dev.n1d, d_grad ? 1 : 0, &ctx->dev, ctx->n_owned, d_solution, d_pt_ptr, d_pts,
+                               n_points, d_u, d_grad, 1, ctx->stream));
   return PDH_OK;
 }
 
@@ -1447,72 +1494,89 @@ extern "C" int pdh_evaluate(pdh_ctx *ctx, const double *solution, const int64_t 
     return fail(ctx, PDH_ESTATE, "pdh_evaluate called before pdh_set_problem");
   if (!solution || !pt_ptr || !pts || !u)
     return fail(ctx, PDH_EINVAL, "solution, pt_ptr, pts and u are required");
+  const int nA = ctx->n_agg_total, dim = ctx->dev.dim;
+  if (pt_ptr[0] != 0)
+    return fail(ctx, PDH_EINVAL, "pt_ptr[0] must be 0");
+  for (int a = 0; a < nA; ++a)
+    if (pt_ptr[a + 1] < pt_ptr[a])
+      return fail(ctx, PDH_EINVAL, "pt_ptr must be non-decreasing");
+  const int64_t N = pt_ptr[nA];
+  if (N == 0)
+    return PDH_OK;
   PDH_HIP(ctx, hipSetDevice(ctx->device));
-  // points of the owned polytopes, compacted in slot order
+  double *d_sol = static_cast<double *>(ctx->scratch_get(0, std::max<int64_t>(ctx->n_rows_owned, 1) * sizeof(double)));
+  double *d_pts = static_cast<double *>(ctx->scratch_get(1, (size_t)N * dim * sizeof(double)));
+  int64_t *d_ptr = static_cast<int64_t *>(ctx->scratch_get(2, ((size_t)nA + 1) * sizeof(int64_t)));
+  double *d_u = static_cast<double *>(ctx->scratch_get(3, (size_t)N * sizeof(double)));
+  double *d_g = grad ? static_cast<double *>(ctx->scratch_get(4, (size_t)N * dim * sizeof(double))) : nullptr;
+  if (!d_sol || !d_pts || !d_ptr || !d_u || (grad && !d_g))
+    return fail(ctx, PDH_EDEVICE, "pdh_evaluate: out of device memory");
+  PDH_HIP(ctx, hipMemcpyAsync(d_sol, solution, ctx->n_rows_owned * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_pts, pts, (size_t)N * dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_ptr, pt_ptr, ((size_t)nA + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  const int rc = pdh_evaluate_device(ctx, d_sol, d_ptr, d_pts, N, d_u, d_g);
+  if (rc != PDH_OK)
+    return rc;
+  // only the points of polytopes owned here are produced; the others are left untouched in the caller's arrays
+  std::vector<double> hu((size_t)N), hg(grad ? (size_t)N * dim : 0);
+  PDH_HIP(ctx, hipMemcpyAsync(hu.data(), d_u, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (grad)
+    PDH_HIP(ctx, hipMemcpyAsync(hg.data(), d_g, (size_t)N * dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   std::vector<int32_t> own((size_t)ctx->n_owned);
-  PDH_HIP(ctx, hipMemcpy(own.data(), ctx->dev.own_agg, own.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-  std::vector<int64_t> lptr((size_t)ctx->n_owned + 1, 0);
-  for (int sl = 0; sl < ctx->n_owned; ++sl)
-    {
-      const int64_t c = pt_ptr[own[sl] + 1] - pt_ptr[own[sl]];
-      if (c < 0)
-        return fail(ctx, PDH_EINVAL, "pt_ptr must be non-decreasing");
-      lptr[sl + 1] = lptr[sl] + c;
-    }
-  const int dim = ctx->dev.dim;
-  const int64_t n_loc = lptr.back(), n_all = pt_ptr[ctx->n_agg_total];
-  std::vector<double> lp((size_t)std::max<int64_t>(n_loc, 1) * dim);
-  for (int sl = 0; sl < ctx->n_owned; ++sl)
-    for (int64_t q = 0; q < lptr[sl + 1] - lptr[sl]; ++q)
-      for (int c = 0; c < dim; ++c)
-        lp[(size_t)c * n_loc + lptr[sl] + q] = pts[(size_t)c * n_all + pt_ptr[own[sl]] + q];
-  double *d_sol = nullptr, *d_pts = nullptr, *d_u = nullptr, *d_g = nullptr;
-  int64_t *d_ptr = nullptr;
-  auto cleanup = [&]() {
-    for (void *p : {(void *)d_sol, (void *)d_pts, (void *)d_u, (void *)d_g, (void *)d_ptr})
-      if (p)
-        (void)hipFree(p);
-  };
-  hipError_t e = hipMalloc((void **)&d_sol, std::max<int64_t>(ctx->n_rows_owned, 1) * sizeof(double));
-  if (e == hipSuccess)
-    e = hipMemcpy(d_sol, solution, ctx->n_rows_owned * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess)
-    e = hipMalloc((void **)&d_pts, lp.size() * sizeof(double));
-  if (e == hipSuccess)
-    e = hipMemcpy(d_pts, lp.data(), lp.size() * sizeof(double), hipMemcpyHostToDevice);
-  if (e == hipSuccess)
-    e = hipMalloc((void **)&d_ptr, lptr.size() * sizeof(int64_t));
-  if (e == hipSuccess)
-    e = hipMemcpy(d_ptr, lptr.data(), lptr.size() * sizeof(int64_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess)
-    e = hipMalloc((void **)&d_u, std::max<int64_t>(n_loc, 1) * sizeof(double));
-  if (e == hipSuccess && grad)
-    e = hipMalloc((void **)&d_g, (size_t)std::max<int64_t>(n_loc, 1) * dim * sizeof(double));
-  if (e == hipSuccess)
-    e = pdh_launch_eval(dim, ctx->dev.n1d, grad ? 1 : 0, &ctx->dev, ctx->n_owned, d_sol, d_ptr, d_pts, n_loc, d_u, d_g,
-                        ctx->stream);
-  std::vector<double> hu((size_t)std::max<int64_t>(n_loc, 1)), hg;
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(hu.data(), d_u, n_loc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess && grad)
-    {
-      hg.resize((size_t)std::max<int64_t>(n_loc, 1) * dim);
-      e = hipMemcpyAsync(hg.data(), d_g, (size_t)n_loc * dim * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    }
-  if (e == hipSuccess)
-    e = hipStreamSynchronize(ctx->stream);
-  cleanup();
-  if (e != hipSuccess)
-    return fail(ctx, PDH_EDEVICE, std::string("pdh_evaluate: ") + hipGetErrorString(e));
-  // scatter back into the caller's point order (points of polytopes not owned here are left untouched)
-  for (int sl = 0; sl < ctx->n_owned; ++sl)
-    for (int64_t q = 0; q < lptr[sl + 1] - lptr[sl]; ++q)
+  PDH_HIP(ctx, hipMemcpyAsync(own.data(), ctx->dev.own_agg, own.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int a : own)
+    for (int64_t q = pt_ptr[a]; q < pt_ptr[a + 1]; ++q)
       {
-        u[pt_ptr[own[sl]] + q] = hu[lptr[sl] + q];
+        u[q] = hu[q];
         if (grad)
           for (int c = 0; c < dim; ++c)
-            grad[(size_t)c * n_all + pt_ptr[own[sl]] + q] = hg[(size_t)c * n_loc + lptr[sl] + q];
+            grad[(size_t)c * N + q] = hg[(size_t)c * N + q];
       }
+  return PDH_OK;
+}
+
+// ---- basis values on boxes (injection matrices) -----------------------------------------------------------------------
+extern "C" int pdh_shape_values_device(pdh_ctx *ctx, int dim, int degree, int basis, int n_boxes, const double *d_bbox,
+                                       const int64_t *d_pt_ptr, const double *d_pts, int64_t n_points, double *d_values)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (dim < 2 || dim > 3 || degree < 0 || (basis != PDH_BASIS_DGQ && basis != PDH_BASIS_AGGLODGP))
+    return fail(ctx, PDH_EINVAL, "dim must be 2 or 3, degree >= 0, basis DGQ or AGGLODGP");
+  const int n = pdh::n_dofs_per_cell(dim, degree, basis);
+  const int n1d = degree + 1;
+  if (n > 64 || n1d > (dim == 2 ? 8 : 6))
+    return fail(ctx, PDH_EUNSUPPORTED, "no kernel instantiated for this (dim, basis, degree)");
+  if (n_boxes <= 0 || n_points <= 0)
+    return PDH_OK;
+  if (!d_bbox || !d_pt_ptr || !d_pts || !d_values)
+    return fail(ctx, PDH_EINVAL, "bbox, pt_ptr, pts and values are required");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  const int key = (dim * 16 + degree) * 2 + basis;
+  if (ctx->shape_key != key)
+    {
+      const auto mi = pdh::multi_indices(dim, degree, basis);
+      std::vector<int32_t> midx(64, (int32_t)0xffffffffu);
+      for (int i = 0; i < n; ++i)
+        midx[i] = (int32_t)mi[i];
+      if (!ctx->d_shape_midx)
+        PDH_HIP(ctx, hipMalloc((void **)&ctx->d_shape_midx, 64 * sizeof(int32_t)));
+      PDH_HIP(ctx, hipMemcpy(ctx->d_shape_midx, midx.data(), 64 * sizeof(int32_t), hipMemcpyHostToDevice));
+      ctx->shape_key = key;
+    }
+  PdhDev D;
+  std::memset(&D, 0, sizeof(D));
+  D.dim = dim;
+  D.n = n;
+  D.n1d = n1d;
+  const pdh::Basis1D b1 = (basis == PDH_BASIS_DGQ) ? pdh::lagrange_basis(degree) : pdh::legendre_basis(degree);
+  for (int k = 0; k < n1d; ++k)
+    for (int m = 0; m < n1d; ++m)
+      D.tab.coef[k][m] = (double)b1.coef[k][m];
+  D.bbox = d_bbox;
+  D.midx = ctx->d_shape_midx;
+  PDH_HIP(ctx, pdh_launch_shape(dim, n1d, &D, n_boxes, d_pt_ptr, d_pts, n_points, d_values, ctx->stream));
   return PDH_OK;
 }
 
@@ -1526,8 +1590,7 @@ extern "C" int pdh_shape_values(pdh_ctx *ctx, int dim, int degree, int basis, in
   if (n_boxes < 0 || (n_boxes > 0 && (!bbox || !pt_ptr || !pts || !values)))
     return fail(ctx, PDH_EINVAL, "bbox, pt_ptr, pts and values are required");
   const int n = pdh::n_dofs_per_cell(dim, degree, basis);
-  const int n1d = degree + 1;
-  if (n > 64 || n1d > (dim == 2 ? 8 : 6))
+  if (n > 64 || degree + 1 > (dim == 2 ? 8 : 6))
     return fail(ctx, PDH_EUNSUPPORTED, "no kernel instantiated for this (dim, basis, degree)");
   if (n_boxes == 0)
     return PDH_OK;
@@ -1545,51 +1608,20 @@ extern "C" int pdh_shape_values(pdh_ctx *ctx, int dim, int degree, int basis, in
   if (N == 0)
     return PDH_OK;
   PDH_HIP(ctx, hipSetDevice(ctx->device));
-  PdhDev D;
-  std::memset(&D, 0, sizeof(D));
-  D.dim = dim;
-  D.n = n;
-  D.n1d = n1d;
-  const pdh::Basis1D b1 = (basis == PDH_BASIS_DGQ) ? pdh::lagrange_basis(degree) : pdh::legendre_basis(degree);
-  for (int k = 0; k < n1d; ++k)
-    for (int m = 0; m < n1d; ++m)
-      D.tab.coef[k][m] = (double)b1.coef[k][m];
-  const auto mi = pdh::multi_indices(dim, degree, basis);
-  std::vector<int32_t> midx(64, (int32_t)0xffffffffu);
-  for (int i = 0; i < n; ++i)
-    midx[i] = (int32_t)mi[i];
-  double *d_bbox = nullptr, *d_pts = nullptr, *d_out = nullptr;
-  int64_t *d_ptr = nullptr;
-  int32_t *d_midx = nullptr;
-  auto cleanup = [&]() {
-    for (void *p : {(void *)d_bbox, (void *)d_pts, (void *)d_out, (void *)d_ptr, (void *)d_midx})
-      if (p)
-        (void)hipFree(p);
-  };
-  auto up = [&](void **d, const void *h, size_t bytes) {
-    hipError_t e = hipMalloc(d, bytes);
-    return e == hipSuccess ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : e;
-  };
-  hipError_t e = up((void **)&d_bbox, bbox, (size_t)n_boxes * 2 * dim * sizeof(double));
-  if (e == hipSuccess)
-    e = up((void **)&d_pts, pts, (size_t)N * dim * sizeof(double));
-  if (e == hipSuccess)
-    e = up((void **)&d_ptr, pt_ptr, ((size_t)n_boxes + 1) * sizeof(int64_t));
-  if (e == hipSuccess)
-    e = up((void **)&d_midx, midx.data(), midx.size() * sizeof(int32_t));
-  if (e == hipSuccess)
-    e = hipMalloc((void **)&d_out, (size_t)N * n * sizeof(double));
-  D.bbox = d_bbox;
-  D.midx = d_midx;
-  if (e == hipSuccess)
-    e = pdh_launch_shape(dim, n1d, &D, n_boxes, d_ptr, d_pts, N, d_out, ctx->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(values, d_out, (size_t)N * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess)
-    e = hipStreamSynchronize(ctx->stream);
-  cleanup();
-  if (e != hipSuccess)
-    return fail(ctx, PDH_EDEVICE, std::string("pdh_shape_values: ") + hipGetErrorString(e));
+  double *d_bbox = static_cast<double *>(ctx->scratch_get(0, (size_t)n_boxes * 2 * dim * sizeof(double)));
+  double *d_pts = static_cast<double *>(ctx->scratch_get(1, (size_t)N * dim * sizeof(double)));
+  int64_t *d_ptr = static_cast<int64_t *>(ctx->scratch_get(2, ((size_t)n_boxes + 1) * sizeof(int64_t)));
+  double *d_out = static_cast<double *>(ctx->scratch_get(3, (size_t)N * n * sizeof(double)));
+  if (!d_bbox || !d_pts || !d_ptr || !d_out)
+    return fail(ctx, PDH_EDEVICE, "pdh_shape_values: out of device memory");
+  PDH_HIP(ctx, hipMemcpyAsync(d_bbox, bbox, (size_t)n_boxes * 2 * dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_pts, pts, (size_t)N * dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_ptr, pt_ptr, ((size_t)n_boxes + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  const int rc = pdh_shape_values_device(ctx, dim, degree, basis, n_boxes, d_bbox, d_ptr, d_pts, N, d_out);
+  if (rc != PDH_OK)
+    return rc;
+  PDH_HIP(ctx, hipMemcpyAsync(values, d_out, (size_t)N * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PDH_OK;
 }
 

@@ -15,8 +15,10 @@ template <int DIM, int N1D, bool GRAD>
 __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_owned, const double *__restrict__ coef,
                                                    const int64_t *__restrict__ pt_ptr, const double *__restrict__ pts,
                                                    const int64_t pts_stride, double *__restrict__ out_u,
-                                                   double *__restrict__ out_g)
+                                                   double *__restrict__ out_g, const int by_agg)
 {
+  // by_agg: pt_ptr / pts / out are the CALLER's arrays, indexed by the polytope numbers of the description ([n_agg+1]);
+  // otherwise they are compacted over the owned slots
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using RC = Rec<DIM, N1D>;
   constexpr int STRIDE = RC::LEN + 1; // odd number of doubles per lane: own-record reads are conflict-free
@@ -33,7 +35,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_o
     }
   const double *cf = coef + P.own_row[slot];
   double *rec = lds + lane * STRIDE;
-  const int64_t qb = pt_ptr[slot], qe = pt_ptr[slot + 1];
+  const int64_t qb = pt_ptr[by_agg ? agg : slot], qe = pt_ptr[(by_agg ? agg : slot) + 1];
   for (int64_t base = qb; base < qe; base += PDH_WAVE)
     {
       const int64_t q = base + lane;
@@ -157,7 +159,7 @@ extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_
 
 extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *P, int count, const double *coef,
                                       const int64_t *pt_ptr, const double *pts, int64_t pts_stride, double *out_u,
-                                      double *out_g, hipStream_t stream)
+                                      double *out_g, int by_agg, hipStream_t stream)
 {
   if (count <= 0)
     return hipSuccess;
@@ -168,10 +170,10 @@ extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *
       const size_t lds = (size_t)PDH_WAVE * (pdh::Rec<D, N>::LEN + 1) * sizeof(double);                              \
       if (grad)                                                                                                      \
         hipLaunchKernelGGL((pdh::k_eval<D, N, true>), grid, block, lds, stream, *P, count, coef, pt_ptr, pts,         \
-                           pts_stride, out_u, out_g);                                                                \
+                           pts_stride, out_u, out_g, by_agg);                                                        \
       else                                                                                                           \
         hipLaunchKernelGGL((pdh::k_eval<D, N, false>), grid, block, lds, stream, *P, count, coef, pt_ptr, pts,        \
-                           pts_stride, out_u, out_g);                                                                \
+                           pts_stride, out_u, out_g, by_agg);                                                        \
       return hipGetLastError();                                                                                      \
     }
   PDH_EVAL_CASE(2, 1) PDH_EVAL_CASE(2, 2) PDH_EVAL_CASE(2, 3) PDH_EVAL_CASE(2, 4)

@@ -14,8 +14,12 @@ namespace pdh
 {
 template <int DIM, int N1D>
 __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_owned, const double *__restrict__ f_vol,
-                                                  const double *__restrict__ g_face, double *__restrict__ rhs)
+                                                  const double *__restrict__ g_face, double *__restrict__ rhs,
+                                                  const int64_t *__restrict__ vq_src, const int64_t *__restrict__ ap_src)
 {
+  // f_vol / g_face are indexed in the CALLER's point order (the order of vq_x / fq_x of the description): vq_src[slot] is
+  // the caller index of the slot's first volume point, ap_src[q] the caller index of packed face point q (-1: not a boundary
+  // point).  nullptr maps: the arrays are already in packed order.
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using RC = Rec<DIM, N1D>;
   const int lane = threadIdx.x;
@@ -56,7 +60,8 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
               for (int c = 0; c < DIM; ++c)
                 x[c] = P.vq_x[c * P.vq_stride + base + lane];
               eval_point_record<DIM, N1D, false>(P.tab, lo, h, x, 1.0, nullptr, rec + lane * RC::LEN);
-              aux[lane * AUXN] = f_vol[base + lane] * P.vq_w[base + lane];
+              const int64_t src = vq_src ? vq_src[slot] + (base + lane - qb) : base + lane;
+              aux[lane * AUXN] = f_vol[src] * P.vq_w[base + lane];
             }
           __syncthreads();
           for (int q = 0; q < cnt; ++q)
@@ -85,7 +90,8 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
                 x[c] = P.ap_x[c * P.ap_stride + base + lane];
               eval_point_record<DIM, N1D, false>(P.tab, lo, h, x, 1.0, nullptr, rec + lane * RC::LEN);
               // packed boundary points carry w = 2 JxW and sigma/2:  2w (sigma/2 g phi - 1/2 g grad phi.n)
-              const double gw = g_face[base + lane] * P.ap_wself[base + lane];
+              const int64_t src = ap_src ? ap_src[base + lane] : base + lane;
+              const double gw = (src >= 0 ? g_face[src] : 0.0) * P.ap_wself[base + lane];
               aux[lane * AUXN] = gw * P.ap_sig[base + lane];
               for (int c = 0; c < DIM; ++c)
                 aux[lane * AUXN + 1 + c] = -0.5 * gw * P.ap_n[c * P.ap_stride + base + lane];
@@ -123,7 +129,8 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
 } // namespace pdh
 
 extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int count, const double *f_vol,
-                                     const double *g_face, double *rhs, hipStream_t stream)
+                                     const double *g_face, double *rhs, const int64_t *vq_src, const int64_t *ap_src,
+                                     hipStream_t stream)
 {
   if (count <= 0)
     return hipSuccess;
@@ -132,7 +139,7 @@ extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int coun
   if (dim == D && n1d == N)                                                                                \
     {                                                                                                      \
       const size_t lds = (size_t)PDH_WAVE * (pdh::Rec<D, N>::LEN + 1 + D) * sizeof(double);                \
-      hipLaunchKernelGGL((pdh::k_rhs<D, N>), grid, block, lds, stream, *P, count, f_vol, g_face, rhs);      \
+      hipLaunchKernelGGL((pdh::k_rhs<D, N>), grid, block, lds, stream, *P, count, f_vol, g_face, rhs, vq_src, ap_src);      \
       return hipGetLastError();                                                                            \
     }
   PDH_RHS_CASE(2, 1) PDH_RHS_CASE(2, 2) PDH_RHS_CASE(2, 3) PDH_RHS_CASE(2, 4)
