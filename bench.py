@@ -74,6 +74,7 @@ def build_handler(pa, dim, cells, block, basis, degree, nq):
 def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto"):
     t0 = time.time()
     grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1)
+    t_handler = time.time() - t0
     var = make_variant(pa, args.variant, fe)
     n = fe.n_dofs_per_cell
     n_agg = ah.n_agglomerates
@@ -87,6 +88,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
         flat = ah.flatten_local(var, r0, r1, diag_first=True, with_colind=False, row_splits=splits)
     else:
         flat = ah.flatten(var, diag_first=True, with_colind=False)
+    t_flatten = time.time() - t0 - t_handler
     ctx = pa.Context(local_rank)
     ctx.set_algorithm(alg)
     # The library overlaps its two kernels on large problems (two streams, ~3 % faster).  The timed region runs them one
@@ -96,6 +98,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     ctx.set_problem(flat, r0, r1)
     alg_used = ctx.algorithm_in_use()
     t_setup = time.time() - t0
+    setup_parts = {"handler_s": t_handler, "flatten_s": t_flatten, "set_problem_s": t_setup - t_handler - t_flatten}
     for _ in range(warmup):
         ctx.assemble_device()
     ctx.synchronize()
@@ -171,7 +174,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
             ghost = {"error": repr(exc)}
     return dict(n_dofs=ah.n_dofs, n_agg=n_agg, n=n, dt=dt, kms=kms, nl=nl, stats=stats, work=work, mfma=mfma,
                 t_setup=t_setup, nnz=flat.nnz if world == 1 else None, checksum=chk, alg=alg_used, dt_overlap=dt_overlap,
-                ghost=ghost, local=world > 1, aux=aux)
+                ghost=ghost, local=world > 1, aux=aux, setup_parts=setup_parts)
 
 
 def time_aux_kernels(torch, ctx, flat, n, stats):
@@ -546,7 +549,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "extra": extra,
-            "setup_s": r["t_setup"], "checksum": r["checksum"], "traffic_note": traffic_note,
+            "setup_s": r["t_setup"], "setup_parts": r["setup_parts"], "checksum": r["checksum"], "traffic_note": traffic_note,
         }
         print(json.dumps(out))
     if world > 1:

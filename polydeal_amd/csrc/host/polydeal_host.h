@@ -30,7 +30,11 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <exception>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -399,6 +403,148 @@ inline void face_quadrature(const BackgroundGrid &g, int cell, int f, int nqf, Q
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Flattening helpers: the same arithmetic as cell_quadrature / face_quadrature, written straight into the
+// structure-of-arrays of a pdh_problem at a known offset (no per-point allocation), so that the points of different
+// polytopes / faces can be generated by several host threads.  PDH_HOST_THREADS overrides the thread count.
+// ---------------------------------------------------------------------------------------------------
+template <class F>
+inline void parallel_for(size_t n, F &&fn)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *e = std::getenv("PDH_HOST_THREADS"))
+    nt = (unsigned)std::max(1, std::atoi(e));
+  nt = std::max(1u, std::min<unsigned>(nt, 64u));
+  if (nt == 1 || n < 256)
+    {
+      for (size_t i = 0; i < n; ++i)
+        fn(i);
+      return;
+    }
+  std::vector<std::thread> th;
+  std::exception_ptr err;
+  std::mutex mx;
+  const size_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t)
+    {
+      const size_t b = (size_t)t * chunk, e = std::min(n, b + chunk);
+      if (b >= e)
+        break;
+      th.emplace_back([&, b, e] {
+        try
+          {
+            for (size_t i = b; i < e; ++i)
+              fn(i);
+          }
+        catch (...)
+          {
+            std::lock_guard<std::mutex> lk(mx);
+            err = std::current_exception();
+          }
+      });
+    }
+  for (auto &t : th)
+    t.join();
+  if (err)
+    std::rethrow_exception(err);
+}
+
+// volume points of one cell -> X[c * stride + at + q], W[at + q]
+inline void cell_quadrature_soa(const BackgroundGrid &g, int cell, int nq, const double *x1, const double *w1, double *X,
+                                size_t stride, size_t at, double *W)
+{
+  const int dim = g.dim;
+  const int np = (dim == 2) ? nq * nq : nq * nq * nq;
+  for (int q = 0; q < np; ++q)
+    {
+      const int i[3] = {q % nq, (q / nq) % nq, q / (nq * nq)};
+      double xi[3], x[3], J[3][3], w = 1.0;
+      for (int c = 0; c < dim; ++c)
+        {
+          xi[c] = x1[i[c]];
+          w *= w1[i[c]];
+        }
+      q1_map(g, cell, xi, x, J);
+      double det;
+      if (dim == 2)
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      else
+        det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+              J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+      for (int c = 0; c < dim; ++c)
+        X[c * stride + at + q] = x[c];
+      W[at + q] = w * std::fabs(det);
+    }
+}
+
+// face points of (cell, f): X, N (may be null), W at offset `at`
+inline void face_quadrature_soa(const BackgroundGrid &g, int cell, int f, int nqf, const double *x1, const double *w1, double *X,
+                                double *N, size_t stride, size_t at, double *W)
+{
+  const int dim = g.dim, ax = f / 2, side = f & 1;
+  const int np = (dim == 2) ? nqf : nqf * nqf;
+  int tang[2];
+  if (dim == 2)
+    tang[0] = tang[1] = 1 - ax;
+  else if (ax == 0)
+    tang[0] = 1, tang[1] = 2;
+  else if (ax == 1)
+    tang[0] = 2, tang[1] = 0;
+  else
+    tang[0] = 0, tang[1] = 1;
+  for (int q = 0; q < np; ++q)
+    {
+      double xi[3] = {0, 0, 0}, x[3], J[3][3], w;
+      xi[ax] = side;
+      if (dim == 2)
+        {
+          xi[tang[0]] = x1[q];
+          w = w1[q];
+        }
+      else
+        {
+          xi[tang[0]] = x1[q % nqf];
+          xi[tang[1]] = x1[q / nqf];
+          w = w1[q % nqf] * w1[q / nqf];
+        }
+      q1_map(g, cell, xi, x, J);
+      double nr[3] = {0, 0, 0}, area;
+      if (dim == 2)
+        {
+          const double t0 = J[0][tang[0]], t1 = J[1][tang[0]];
+          area = std::sqrt(t0 * t0 + t1 * t1);
+          nr[0] = t1;
+          nr[1] = -t0;
+        }
+      else
+        {
+          const double a[3] = {J[0][tang[0]], J[1][tang[0]], J[2][tang[0]]};
+          const double b[3] = {J[0][tang[1]], J[1][tang[1]], J[2][tang[1]]};
+          nr[0] = a[1] * b[2] - a[2] * b[1];
+          nr[1] = a[2] * b[0] - a[0] * b[2];
+          nr[2] = a[0] * b[1] - a[1] * b[0];
+          area = std::sqrt(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]);
+        }
+      double nn = 0.0, dot = 0.0;
+      for (int c = 0; c < dim; ++c)
+        nn += nr[c] * nr[c];
+      nn = std::sqrt(nn);
+      for (int c = 0; c < dim; ++c)
+        {
+          nr[c] /= nn;
+          dot += nr[c] * J[c][ax] * (side ? 1.0 : -1.0);
+        }
+      const double sgn = dot < 0 ? -1.0 : 1.0;
+      if (X)
+        for (int c = 0; c < dim; ++c)
+          {
+            X[c * stride + at + q] = x[c];
+            N[c * stride + at + q] = sgn * nr[c];
+          }
+      W[at + q] = w * area;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // SIP variants of the reference's callers (SURVEY.md 8(a), table "Variants")
 // ---------------------------------------------------------------------------------------------------
 struct SipVariant
@@ -675,89 +821,7 @@ public:
 
   void flatten(const SipVariant &var, FlatProblem &F, bool diag_first = true, bool with_colind = false) const
   {
-    if (!connectivity_ready)
-      throw std::logic_error("distribute_agglomerated_dofs must be called first");
-    if (nq <= 0 || nqf <= 0)
-      throw std::logic_error("initialize_fe_values must be called first");
-    const int dim = tria->dim, nA = (int)master_cells.size();
-    F = FlatProblem();
-    F.c.dim = dim;
-    F.c.degree = fe.degree;
-    F.c.basis = fe.basis;
-    F.c.n_agg = nA;
-    F.c.n_rows = (int32_t)n_dofs_;
-    F.c.diag_first = diag_first ? 1 : 0;
-    F.c.reaction_c = var.reaction_c;
-    F.bbox.resize((size_t)nA * 2 * dim);
-    F.dof_offset.assign(dof_offset.begin(), dof_offset.end());
-    F.vq_ptr.assign(1, 0);
-    QPoints vol;
-    for (int P = 0; P < nA; ++P)
-      {
-        for (int c = 0; c < dim; ++c)
-          {
-            F.bbox[(size_t)P * 2 * dim + c] = bboxes[P][c];
-            F.bbox[(size_t)P * 2 * dim + dim + c] = bboxes[P][3 + c];
-          }
-        agglomerated_quadrature(P, vol);
-        F.vq_ptr.push_back((int64_t)vol.w.size());
-      }
-    const size_t nqt = vol.w.size();
-    F.vq_w = std::move(vol.w);
-    F.vq_x.resize(nqt * dim);
-    for (size_t q = 0; q < nqt; ++q)
-      for (int c = 0; c < dim; ++c)
-        F.vq_x[c * nqt + q] = vol.x[q * dim + c];
-    vol = QPoints();
-
-    QPoints fin, fout;
-    F.fq_ptr.assign(1, 0);
-    for (int P = 0; P < nA; ++P)
-      for (unsigned f = 0; f < n_faces(P); ++f)
-        {
-          if (at_boundary(P, f))
-            {
-              if (var.boundary == 1)
-                continue;
-              const size_t before = fin.w.size();
-              face_quadrature_of(P, f, fin);
-              fout.w.insert(fout.w.end(), fin.w.begin() + before, fin.w.end()); // unused on the boundary
-              F.face_in.push_back(P);
-              F.face_out.push_back(-1);
-              F.face_sigma.push_back(sigma(var, P, invalid_index));
-            }
-          else
-            {
-              const int Q = neighbor(P, f);
-              if (!owns(var, P, Q))
-                continue;
-              const int nofn = neighbor_of_agglomerated_neighbor(P, f);
-              face_quadrature_of(P, f, fin);
-              QPoints tmp;
-              face_quadrature_of(Q, (unsigned)nofn, tmp); // side 1: only its JxW is used (poly_utils.h:1906-1922)
-              if (fout.w.size() + tmp.w.size() != fin.w.size())
-                throw std::logic_error("interface lists of the two sides differ in length");
-              fout.w.insert(fout.w.end(), tmp.w.begin(), tmp.w.end());
-              F.face_in.push_back(P);
-              F.face_out.push_back(Q);
-              F.face_sigma.push_back(sigma(var, P, Q));
-            }
-          F.fq_ptr.push_back((int64_t)fin.w.size());
-        }
-    F.c.n_faces = (int32_t)F.face_in.size();
-    const size_t nft = fin.w.size();
-    F.fq_w = std::move(fin.w);
-    F.fq_w_out = std::move(fout.w);
-    F.fq_x.resize(nft * dim);
-    F.fq_n.resize(nft * dim);
-    for (size_t q = 0; q < nft; ++q)
-      for (int c = 0; c < dim; ++c)
-        {
-          F.fq_x[c * nft + q] = fin.x[q * dim + c];
-          F.fq_n[c * nft + q] = fin.n[q * dim + c];
-        }
-    create_agglomeration_sparsity_pattern(F.rowptr, with_colind ? &F.colind : nullptr, diag_first);
-    F.bind();
+    flatten_impl(var, F, 0, (int)n_dofs_, false, diag_first, with_colind, nullptr, nullptr, false);
   }
 
   // Rank-local description (pdh_problem::local = 1) of the dof rows [row_begin,row_end): what one MPI rank of the
@@ -772,6 +836,16 @@ public:
   void flatten_local(const SipVariant &var, FlatProblem &F, int row_begin, int row_end, bool diag_first = true,
                      bool with_colind = false, std::vector<int> *local_of = nullptr,
                      const std::vector<int> *row_splits = nullptr, bool epetra_columns = false) const
+  {
+    flatten_impl(var, F, row_begin, row_end, true, diag_first, with_colind, local_of, row_splits, epetra_columns);
+  }
+
+  // Shared implementation.  Bookkeeping (which polytopes / faces, offsets of their points) runs serially; the quadrature
+  // points themselves - 16.8 M volume and 12 M face-side points on BASELINE configs[2] - are generated by all host
+  // threads straight into the structure-of-arrays of the description.
+  void flatten_impl(const SipVariant &var, FlatProblem &F, int row_begin, int row_end, bool local, bool diag_first,
+                    bool with_colind, std::vector<int> *local_of, const std::vector<int> *row_splits,
+                    bool epetra_columns) const
   {
     if (!connectivity_ready)
       throw std::logic_error("distribute_agglomerated_dofs must be called first");
@@ -806,12 +880,13 @@ public:
     F.c.n_agg = nL;
     F.c.n_rows = (int32_t)n_dofs_;
     F.c.diag_first = diag_first ? 1 : 0;
-    F.c.local = 1;
+    F.c.local = local ? 1 : 0;
     F.c.reaction_c = var.reaction_c;
     F.bbox.resize((size_t)nL * 2 * dim);
     F.dof_offset.resize(nL);
+    const int64_t npc = (dim == 2) ? (int64_t)nq * nq : (int64_t)nq * nq * nq;       // points per cell
+    const int64_t npf = (dim == 2) ? (int64_t)nqf : (int64_t)nqf * nqf;             // points per sub-face
     F.vq_ptr.assign(1, 0);
-    QPoints vol;
     for (int l = 0; l < nL; ++l)
       {
         const int P = glob[l];
@@ -821,19 +896,31 @@ public:
             F.bbox[(size_t)l * 2 * dim + dim + c] = bboxes[P][3 + c];
           }
         F.dof_offset[l] = dof_offset[P];
-        if (l < n_owned)
-          agglomerated_quadrature(P, vol);
-        F.vq_ptr.push_back((int64_t)vol.w.size());
+        const int64_t cnt = l < n_owned ? npc * (int64_t)(master2slaves.at(master_cells[P]).size() + 1) : 0;
+        F.vq_ptr.push_back(F.vq_ptr.back() + cnt);
       }
-    const size_t nqt = vol.w.size();
-    F.vq_w = std::move(vol.w);
+    const size_t nqt = (size_t)F.vq_ptr.back();
+    F.vq_w.resize(nqt);
     F.vq_x.resize(nqt * dim);
-    for (size_t q = 0; q < nqt; ++q)
-      for (int c = 0; c < dim; ++c)
-        F.vq_x[c * nqt + q] = vol.x[q * dim + c];
-    vol = QPoints();
+    std::vector<double> x1, w1, xf1, wf1;
+    qgauss_1d_compute(nq, x1, w1);
+    qgauss_1d_compute(nqf, xf1, wf1);
+    parallel_for((size_t)n_owned, [&](size_t l) {
+      size_t at = (size_t)F.vq_ptr[l];
+      for (int cell : get_agglomerate(glob[l])) // slaves in insertion order, then the master (:622-707)
+        {
+          cell_quadrature_soa(*tria, cell, nq, x1.data(), w1.data(), F.vq_x.data(), nqt, at, F.vq_w.data());
+          at += (size_t)npc;
+        }
+    });
 
-    QPoints fin, fout;
+    // faces: every face with an owned side, described from its owner side I (normal, JxW_0, sigma as the owner sees them)
+    struct Job
+    {
+      int I, O;                       // global polytopes: owner side, other side (-1 boundary)
+      const std::vector<std::pair<int, int>> *li, *lo; // (cell, face) lists of the two sides, matching order
+    };
+    std::vector<Job> jobs;
     F.fq_ptr.assign(1, 0);
     for (int i = 0; i < n_owned; ++i)
       {
@@ -844,12 +931,12 @@ public:
               {
                 if (var.boundary == 1)
                   continue;
-                const size_t before = fin.w.size();
-                face_quadrature_of(P, f, fin);
-                fout.w.insert(fout.w.end(), fin.w.begin() + before, fin.w.end());
+                const auto &li = get_interface(P, P);
+                jobs.push_back({P, -1, &li, nullptr});
                 F.face_in.push_back(i);
                 F.face_out.push_back(-1);
                 F.face_sigma.push_back(sigma(var, P, invalid_index));
+                F.fq_ptr.push_back(F.fq_ptr.back() + npf * (int64_t)li.size());
               }
             else
               {
@@ -857,35 +944,41 @@ public:
                 const bool p_owns = owns(var, P, Q);
                 if (!p_owns && owned(Q))
                   continue; // listed when Q's faces are walked
-                // the face is described from its owner side I (normal, JxW_0, sigma as the reference's owner sees them)
                 const int I = p_owns ? P : Q, O = p_owns ? Q : P;
-                const unsigned fI = p_owns ? f : (unsigned)neighbor_of_agglomerated_neighbor(P, f);
-                const int fO = neighbor_of_agglomerated_neighbor(I, fI);
-                face_quadrature_of(I, fI, fin);
-                QPoints tmp;
-                face_quadrature_of(O, (unsigned)fO, tmp);
-                if (fout.w.size() + tmp.w.size() != fin.w.size())
+                const auto &li = get_interface(I, O), &lo = get_interface(O, I);
+                if (li.size() != lo.size())
                   throw std::logic_error("interface lists of the two sides differ in length");
-                fout.w.insert(fout.w.end(), tmp.w.begin(), tmp.w.end());
+                jobs.push_back({I, O, &li, &lo});
                 F.face_in.push_back(loc[I]);
                 F.face_out.push_back(loc[O]);
                 F.face_sigma.push_back(sigma(var, I, O));
+                F.fq_ptr.push_back(F.fq_ptr.back() + npf * (int64_t)li.size());
               }
-            F.fq_ptr.push_back((int64_t)fin.w.size());
           }
       }
     F.c.n_faces = (int32_t)F.face_in.size();
-    const size_t nft = fin.w.size();
-    F.fq_w = std::move(fin.w);
-    F.fq_w_out = std::move(fout.w);
+    const size_t nft = (size_t)F.fq_ptr.back();
+    F.fq_w.resize(nft);
+    F.fq_w_out.resize(nft);
     F.fq_x.resize(nft * dim);
     F.fq_n.resize(nft * dim);
-    for (size_t q = 0; q < nft; ++q)
-      for (int c = 0; c < dim; ++c)
+    parallel_for(jobs.size(), [&](size_t j) {
+      const Job &J = jobs[j];
+      size_t at = (size_t)F.fq_ptr[j];
+      for (size_t k = 0; k < J.li->size(); ++k)
         {
-          F.fq_x[c * nft + q] = fin.x[q * dim + c];
-          F.fq_n[c * nft + q] = fin.n[q * dim + c];
+          face_quadrature_soa(*tria, (*J.li)[k].first, (*J.li)[k].second, nqf, xf1.data(), wf1.data(), F.fq_x.data(),
+                              F.fq_n.data(), nft, at, F.fq_w.data());
+          if (J.lo) // side 1: only its JxW is used (poly_utils.h:1906-1922)
+            face_quadrature_soa(*tria, (*J.lo)[k].first, (*J.lo)[k].second, nqf, xf1.data(), wf1.data(), nullptr, nullptr, nft,
+                                at, F.fq_w_out.data());
+          else
+            for (int64_t q = 0; q < npf; ++q)
+              F.fq_w_out[at + q] = F.fq_w[at + q]; // unused on the boundary
+          at += (size_t)npf;
         }
+    });
+
     // column numbering that orders a row
     std::vector<int> colnum(nL);
     for (int l = 0; l < nL; ++l)
@@ -900,7 +993,7 @@ public:
           colnum[loc[gh[g]]] = (row_end - row_begin) + (int)g * n;
         F.col_offset.assign(colnum.begin(), colnum.end());
       }
-    // pattern of the owned rows (create_agglomeration_sparsity_pattern restricted to locally_owned_dofs, :933-935)
+    // pattern of the owned rows (create_agglomeration_sparsity_pattern, :910-1022; restricted to locally_owned_dofs, :933-935)
     const int nrow = row_end - row_begin;
     F.rowptr.assign((size_t)nrow + 1, 0);
     std::vector<std::vector<int>> blocks(n_owned);
@@ -921,7 +1014,7 @@ public:
     if (with_colind)
       {
         F.colind.resize((size_t)F.rowptr[nrow]);
-        for (int i = 0; i < n_owned; ++i)
+        parallel_for((size_t)n_owned, [&](size_t i) {
           for (int r = 0; r < n; ++r)
             {
               const int row = dof_offset[glob[i]] + r;
@@ -934,6 +1027,7 @@ public:
                   if (!(diag_first && colnum[l] + j == own_col))
                     *out++ = colnum[l] + j;
             }
+        });
       }
     if (row_splits)
       { // owning rank of every polytope: row_splits[r] <= dof_offset < row_splits[r+1]

@@ -20,6 +20,39 @@
 
 #include "pdh_combos.h"
 
+#include <cstdlib>
+#include <thread>
+
+// setup-time loops over all quadrature points run on all host threads (PDH_HOST_THREADS overrides the count)
+template <class F>
+static void host_parallel_for(size_t n, F &&fn)
+{
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *e = std::getenv("PDH_HOST_THREADS"))
+    nt = (unsigned)std::max(1, std::atoi(e));
+  nt = std::max(1u, std::min<unsigned>(nt, 64u));
+  if (nt == 1 || n < 256)
+    {
+      for (size_t i = 0; i < n; ++i)
+        fn(i);
+      return;
+    }
+  std::vector<std::thread> th;
+  const size_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t)
+    {
+      const size_t b = (size_t)t * chunk, e = std::min(n, b + chunk);
+      if (b >= e)
+        break;
+      th.emplace_back([&fn, b, e] {
+        for (size_t i = b; i < e; ++i)
+          fn(i);
+      });
+    }
+  for (auto &t : th)
+    t.join();
+}
+
 extern "C" {
 typedef hipError_t (*pdh_launch_fn)(int dim, int n1d, int nt, int lb, int which, const PdhDev *P, int count, size_t lds,
                                     hipStream_t stream);
@@ -384,9 +417,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           return fail(ctx, PDH_EINVAL, "bounding box is not finite");
       if (p->vq_ptr[a + 1] < p->vq_ptr[a])
         return fail(ctx, PDH_EINVAL, "vq_ptr must be non-decreasing");
-      for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q)
-        if (!(p->vq_w[q] >= 0.0))
-          return fail(ctx, PDH_EINVAL, "quadrature weights (JxW) must be non-negative");
+      // (the weights themselves are checked below, by all host threads)
       for (int c = 0; c < dim; ++c)
         if (!(p->bbox[(size_t)a * 2 * dim + dim + c] > p->bbox[(size_t)a * 2 * dim + c]))
           return fail(ctx, PDH_EINVAL, "degenerate bounding box");
@@ -402,9 +433,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
         return fail(ctx, PDH_EINVAL, "face_sigma is not finite");
       if (p->fq_ptr[f + 1] < p->fq_ptr[f])
         return fail(ctx, PDH_EINVAL, "fq_ptr must be non-decreasing");
-      for (int64_t q = p->fq_ptr[f]; q < p->fq_ptr[f + 1]; ++q)
-        if (!(p->fq_w[q] >= 0.0) || (p->fq_w_out && !(p->fq_w_out[q] >= 0.0)))
-          return fail(ctx, PDH_EINVAL, "face quadrature weights (JxW) must be non-negative");
+      // (weights: checked below)
       ++fptr[in + 1];
       if (out >= 0)
         ++fptr[out + 1];
@@ -424,6 +453,24 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
 
   const int64_t nq_tot = p->vq_ptr[nA];
   const int64_t nqf_tot = nF ? p->fq_ptr[nF] : 0;
+  {
+    // JxW must be non-negative (and not NaN): chunks of 64k points per task
+    const size_t nchunk = (size_t)((nq_tot + nqf_tot) / 65536 + 1);
+    std::vector<char> bad(nchunk, 0);
+    host_parallel_for(nchunk, [&](size_t k) {
+      const int64_t b = (int64_t)k * 65536, e = std::min<int64_t>(b + 65536, nq_tot + nqf_tot);
+      for (int64_t i = b; i < e; ++i)
+        {
+          if (i < nq_tot)
+            bad[k] |= !(p->vq_w[i] >= 0.0);
+          else
+            bad[k] |= !(p->fq_w[i - nq_tot] >= 0.0) || (p->fq_w_out && !(p->fq_w_out[i - nq_tot] >= 0.0));
+        }
+    });
+    for (char b : bad)
+      if (b)
+        return fail(ctx, PDH_EINVAL, "quadrature weights (JxW) must be non-negative");
+  }
   const int64_t val_base = p->rowptr[row_begin - rp_shift];
   K.n_values = p->rowptr[row_end - rp_shift] - val_base;
 
@@ -510,28 +557,13 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
   std::vector<int64_t> run_slot_end; // runs.size() after every slot
   std::vector<std::pair<int32_t, int32_t>> blocks; // (column number, polytope)
   std::vector<int32_t> slot_of(nA, -1);
+  // the points themselves are copied after this (serial) bookkeeping pass, by all host threads
+  int64_t nap_run = 0, nvq_run = 0;
+  std::vector<int64_t> run_at; // first packed point of every run
   auto append_run_points = [&](int a, int f) {
-    const bool side0 = (p->face_in[f] == a);
-    const int other = side0 ? p->face_out[f] : p->face_in[f];
-    const double sig = p->face_sigma[f];
-    for (int64_t q = p->fq_ptr[f]; q < p->fq_ptr[f + 1]; ++q)
-      {
-        const double w_in = p->fq_w[q];
-        const double w_out = p->fq_w_out ? p->fq_w_out[q] : w_in;
-        if (other < 0)
-          { // Nitsche boundary: same form with 2 JxW and sigma / 2 (exact scalings)
-            K.ap_wself.push_back(2.0 * w_in);
-            K.ap_wcross.push_back(0.0);
-            K.ap_sig.push_back(0.5 * sig);
-          }
-        else
-          {
-            K.ap_wself.push_back(side0 ? w_in : w_out); // M11 uses JxW_0, M22 JxW_1 (poly_utils.h:1898, 1922)
-            K.ap_wcross.push_back(w_out);               // M12, M21 use JxW_1 (poly_utils.h:1906, 1914)
-            K.ap_sig.push_back(sig);
-          }
-      }
     runs.push_back({a, f});
+    run_at.push_back(nap_run);
+    nap_run += p->fq_ptr[f + 1] - p->fq_ptr[f];
   };
   for (int a = 0; a < nA; ++a)
     {
@@ -594,9 +626,8 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
         }
       // volume points
       K.vq_src.push_back(p->vq_ptr[a]);
-      for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q)
-        K.vq_w.push_back(p->vq_w[q]);
-      K.vq_ptr.push_back((int64_t)K.vq_w.size());
+      nvq_run += p->vq_ptr[a + 1] - p->vq_ptr[a];
+      K.vq_ptr.push_back(nvq_run);
       // own-side face points + coupling items
       for (int64_t t = fptr[a]; t < fptr[a + 1]; ++t)
         {
@@ -619,7 +650,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
               K.r21_rlen.push_back((int32_t)rl);
               continue;
             }
-          K.run_ap.push_back((int64_t)K.ap_wself.size());
+          K.run_ap.push_back(nap_run);
           K.run_fq.push_back(qb);
           K.run_cnt.push_back((int32_t)(qe - qb));
           K.run_bdry.push_back(other < 0 ? 1 : 0);
@@ -643,7 +674,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
                 {
                   K.it_own.push_back(slot);
                   K.it_nbr.push_back(other);
-                  K.it_pbeg.push_back((int64_t)K.ap_wself.size());
+                  K.it_pbeg.push_back(nap_run);
                   K.it_pcnt.push_back((int32_t)(qe - qb));
                   size_t rank = 0;
                   for (size_t u = 0; u < blocks.size(); ++u)
@@ -660,7 +691,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
             }
           append_run_points(a, f);
         }
-      K.ap_ptr.push_back((int64_t)K.ap_wself.size());
+      K.ap_ptr.push_back(nap_run);
       run_slot_end.push_back((int64_t)runs.size());
     }
   if ((int64_t)K.own_agg.size() * n != (int64_t)(row_end - row_begin))
@@ -676,14 +707,14 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
       K.row_base.push_back(K.n_values + send22_block[j] * (int64_t)n * n);
       K.row_len.push_back(n);
       K.diag_L.push_back(0);
-      K.vq_ptr.push_back((int64_t)K.vq_w.size());
+      K.vq_ptr.push_back(nvq_run);
       for (int64_t t = fptr[q]; t < fptr[q + 1]; ++t)
         {
           const int f = flist[t];
           if (p->face_out[f] == q && owned(p->face_in[f]))
             append_run_points(q, f);
         }
-      K.ap_ptr.push_back((int64_t)K.ap_wself.size());
+      K.ap_ptr.push_back(nap_run);
       run_slot_end.push_back((int64_t)runs.size());
     }
   {
@@ -767,29 +798,55 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
         K.r22_ptr.assign(1, 0);
     }
 
-  // second pass: coordinates / normals in SoA with the final strides
-  const int64_t nvq = (int64_t)K.vq_w.size(), nap = (int64_t)K.ap_wself.size();
+  // second pass: weights, coordinates and normals in SoA with the final strides - disjoint ranges, all host threads
+  const int64_t nvq = nvq_run, nap = nap_run;
+  K.vq_w.resize((size_t)nvq);
   K.vq_x.resize((size_t)dim * nvq);
+  K.ap_wself.resize((size_t)nap);
+  K.ap_wcross.resize((size_t)nap);
+  K.ap_sig.resize((size_t)nap);
   K.ap_x.resize((size_t)dim * nap);
   K.ap_n.resize((size_t)dim * nap);
-  int64_t vq = 0, ap = 0;
-  for (int sl = 0; sl < K.n_owned; ++sl)
-    {
-      const int a = K.own_agg[sl];
-      for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q, ++vq)
+  host_parallel_for((size_t)K.n_owned, [&](size_t sl) {
+    const int a = K.own_agg[sl];
+    int64_t vq = K.vq_ptr[sl];
+    for (int64_t q = p->vq_ptr[a]; q < p->vq_ptr[a + 1]; ++q, ++vq)
+      {
+        K.vq_w[vq] = p->vq_w[q];
         for (int c = 0; c < dim; ++c)
           K.vq_x[c * nvq + vq] = p->vq_x[c * nq_tot + q];
-    }
-  for (const Run &r : runs)
-    {
-      const double sgn = (p->face_in[r.f] == r.a) ? 1.0 : -1.0;
-      for (int64_t q = p->fq_ptr[r.f]; q < p->fq_ptr[r.f + 1]; ++q, ++ap)
+      }
+  });
+  host_parallel_for(runs.size(), [&](size_t ri) {
+    const Run &r = runs[ri];
+    const bool side0 = (p->face_in[r.f] == r.a);
+    const int other = side0 ? p->face_out[r.f] : p->face_in[r.f];
+    const double sig = p->face_sigma[r.f];
+    const double sgn = side0 ? 1.0 : -1.0;
+    int64_t ap = run_at[ri];
+    for (int64_t q = p->fq_ptr[r.f]; q < p->fq_ptr[r.f + 1]; ++q, ++ap)
+      {
+        const double w_in = p->fq_w[q];
+        const double w_out = p->fq_w_out ? p->fq_w_out[q] : w_in;
+        if (other < 0)
+          { // Nitsche boundary: same form with 2 JxW and sigma / 2 (exact scalings)
+            K.ap_wself[ap] = 2.0 * w_in;
+            K.ap_wcross[ap] = 0.0;
+            K.ap_sig[ap] = 0.5 * sig;
+          }
+        else
+          {
+            K.ap_wself[ap] = side0 ? w_in : w_out; // M11 uses JxW_0, M22 JxW_1 (poly_utils.h:1898, 1922)
+            K.ap_wcross[ap] = w_out;               // M12, M21 use JxW_1 (poly_utils.h:1906, 1914)
+            K.ap_sig[ap] = sig;
+          }
         for (int c = 0; c < dim; ++c)
           {
             K.ap_x[c * nap + ap] = p->fq_x[c * nqf_tot + q];
             K.ap_n[c * nap + ap] = sgn * p->fq_n[c * nqf_tot + q];
           }
-    }
+      }
+  });
   return PDH_OK;
 }
 
@@ -825,7 +882,9 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
   // becomes one entry per plane over the same point range, and the kernel masks the points of the other planes.
   struct Plane { int axis; double sign, coord; };
   std::vector<std::vector<Plane>> planes(nruns);
-  for (size_t r = 0; r < nruns; ++r)
+  std::vector<const char *> why_run(nruns, nullptr);
+  host_parallel_for(nruns, [&](size_t r) {
+    auto no = [&](const char *m) { why_run[r] = m; };
     {
       const int64_t b = K.run_ap[r];
       const int cnt = K.run_cnt[r];
@@ -879,6 +938,10 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
               return no("face not planar");
           }
     }
+  });
+  for (size_t r = 0; r < nruns; ++r)
+    if (why_run[r])
+      return no(why_run[r]);
   // runs are stored slot by slot; order the faces of a slot: boundary first, then ascending block rank
   R.fr_ptr.assign(1, 0);
   size_t r = 0;
