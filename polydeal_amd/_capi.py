@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpolydeal_hip.so")
+# PDH_LIB: another build of the library (diagnostic builds with experiment switches; tools/README.md)
+LIB_PATH = os.environ.get("PDH_LIB") or os.path.join(_HERE, "lib", "libpolydeal_hip.so")
 
 PDH_BASIS_DGQ = 0
 PDH_BASIS_AGGLODGP = 1

@@ -722,38 +722,51 @@ __device__ __forceinline__ void load_aset(const double *tab, int stride, int lan
   });
 }
 
+// T1B / T2B hold the B operands of stages 2 / 3 in the order the MFMA lanes read them: 64 consecutive doubles per
+// fragment.  The PRODUCING stage writes them scattered, and in the plain order its 16-lane write groups hit 2 (T1B: the
+// bank depends on a0 only, 7-way conflicts) or 2 (T2B: 8-way) of the 16 double-wide banks: measured with SQ counters on the
+// row kernel, two thirds of all its bank-conflict cycles came from these stores.  Both layouts are therefore rotated
+// inside every aligned block of 16 doubles by an amount the reader can recompute from its lane:
+//   T1B: position 16 (a1 & 3) + x  ->  16 (a1 & 3) + ((x + rot(a1)) & 15),  rot = {0,7,2,14,12,5,10,3}  (searched: <= 2-way)
+//   T2B: position 16 j + x         ->  16 j + ((x + j + 8 ks) & 15)                                  (conflict-free)
+// A reader's 32-lane group still covers 32 distinct doubles of one 256-byte row: conflict-free as before.
+__device__ __forceinline__ int t1b_rot(int a1) { return (int)((0x3A5CE270u >> (4 * a1)) & 15u); }
+
 // position of T1[arr][hi][a0][a1] in the B-operand order of stage 2
 __device__ __forceinline__ int t1b_index(int arr, int hi, int a0, int a1)
 {
-  return ((arr * 2 + (hi >> 1)) * 2 + (a1 >> 2)) * 64 + (a1 & 3) * 16 + (2 * (hi & 1) + (a0 >> 2)) * 4 + (a0 & 3);
+  return ((arr * 2 + (hi >> 1)) * 2 + (a1 >> 2)) * 64 + (a1 & 3) * 16 + ((8 * (hi & 1) + a0 + t1b_rot(a1)) & 15);
 }
 
 // Offsets of this lane's stage-1 outputs inside one [hi] slice of T1B (everything that depends on (a0,a1) only, computed
 // once per kernel): the value itself and the zero pads the lane owns (a1 = 6: column 7; a0 = 6: row 7; both: the corner).
 struct T1Off
 {
-  int val, padc, padr, padx; // pad offsets are -1 when the lane does not own that pad
+  int val[2], padc[2], padr[2], padx[2]; // [hi & 1]; pad offsets are -1 when the lane does not own that pad
   __device__ __forceinline__ void init(int a0, int a1)
   {
-    val = t1b_index(0, 0, a0, a1);
-    padc = a1 == 6 ? t1b_index(0, 0, a0, 7) : -1;
-    padr = a0 == 6 ? t1b_index(0, 0, 7, a1) : -1;
-    padx = (a0 == 6 && a1 == 6) ? t1b_index(0, 0, 7, 7) : -1;
+    for (int h = 0; h < 2; ++h)
+      {
+        val[h] = t1b_index(0, h, a0, a1);
+        padc[h] = a1 == 6 ? t1b_index(0, h, a0, 7) : -1;
+        padr[h] = a0 == 6 ? t1b_index(0, h, 7, a1) : -1;
+        padx[h] = (a0 == 6 && a1 == 6) ? t1b_index(0, h, 7, 7) : -1;
+      }
   }
 };
 
-// ARR, HI compile-time: T1B offset of the slice = ARR * 256 + (HI >> 1) * 128 + (HI & 1) * 8
+// ARR, HI compile-time: T1B offset of the slice = ARR * 256 + (HI >> 1) * 128 (+ the lane's offset for HI & 1)
 template <int ARR, int HI>
 __device__ __forceinline__ void t1b_store(double *T1B, const T1Off &o, double v)
 {
-  constexpr int base = ARR * 256 + (HI >> 1) * 128 + (HI & 1) * 8;
-  T1B[base + o.val] = v;
-  if (o.padc >= 0)
-    T1B[base + o.padc] = 0.0;
-  if (o.padr >= 0)
-    T1B[base + o.padr] = 0.0;
-  if (o.padx >= 0)
-    T1B[base + o.padx] = 0.0;
+  constexpr int base = ARR * 256 + (HI >> 1) * 128, h = HI & 1;
+  T1B[base + o.val[h]] = v;
+  if (o.padc[h] >= 0)
+    T1B[base + o.padc[h]] = 0.0;
+  if (o.padr[h] >= 0)
+    T1B[base + o.padr[h]] = 0.0;
+  if (o.padx[h] >= 0)
+    T1B[base + o.padx[h]] = 0.0;
 }
 
 // one term of stage 2: D2[bf][r] += (scale * A) . T1B[arr]      (ASets are passed by reference and indexed statically
@@ -769,7 +782,7 @@ __device__ __forceinline__ void mstage2_term(const ASet &A, int arr, double scal
     });
     static_for<0, 2>([&](auto bf_) {
       constexpr int bf = bf_;
-      const double b = T1B[((arr * 2 + bf) * 2 + ks) * 64 + lane];
+      const double b = T1B[((arr * 2 + bf) * 2 + ks) * 64 + ((lane & 48) | ((lane + t1b_rot(4 * ks + (lane >> 4))) & 15))];
       static_for<0, 4>([&](auto r_) {
         constexpr int r = r_;
         D2[bf][r] = pdh::mfma4(ar[r], b, D2[bf][r]);
@@ -787,7 +800,7 @@ __device__ __forceinline__ void mstage2_scatter(const double (&D2)[2][4], double
     constexpr int bf = bf_;
     static_for<0, 4>([&](auto r_) {
       constexpr int r = r_;
-      T2B[((blk & 1) * 4 + r) * 64 + j * 16 + (2 * bf + (blk >> 1)) * 4 + i] = D2[bf][r];
+      T2B[((blk & 1) * 4 + r) * 64 + j * 16 + (((2 * bf + (blk >> 1)) * 4 + i + j + 8 * (blk & 1)) & 15)] = D2[bf][r];
     });
   });
 }
@@ -799,7 +812,7 @@ __device__ __forceinline__ void mstage3(const ASet &X, const double *T2B, int la
     constexpr int ks = ks_;
     static_for<0, 4>([&](auto cf_) {
       constexpr int cf = cf_;
-      const double b = T2B[(ks * 4 + cf) * 64 + lane];
+      const double b = T2B[(ks * 4 + cf) * 64 + ((lane & 48) | ((lane + (lane >> 4) + 8 * ks) & 15))];
       static_for<0, 4>([&](auto r_) {
         constexpr int r = r_;
         D3[cf][r] = pdh::mfma4(X.a[r][ks], b, D3[cf][r]);

@@ -769,11 +769,14 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             // diagonal-first layout: piece m0 of row R = [carry | own columns without the diagonal]; the diagonal entry is
             // position 0 of the row (lane 0 of piece 0: written here if the own block is the first one, else kept for P5)
             PDH_WAVE_SYNC();
+            // (columns rotated inside blocks of 16 by the block number: a write group's 16 lanes hold O = i + 4 j + 16 blk,
+            // i fixed - four banks without the rotation)
+            const int Osw = (O & 48) | ((O + (O >> 4)) & 15);
             static_for<0, 4>([&](auto cf_) {
               constexpr int cf = cf_;
               static_for<0, 4>([&](auto s0_) {
                 constexpr int s0 = s0_;
-                rowst[(s0 + 4 * cf) * 64 + O] = D3[cf][s0];
+                rowst[(s0 + 4 * cf) * 64 + Osw] = D3[cf][s0];
               });
             });
             PDH_WAVE_SYNC();
@@ -782,7 +785,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               {
                 const int R = r + 16 * k2;
                 const int col = lane == 0 ? R : (lane - 1 + (lane - 1 >= R ? 1 : 0));
-                double v = rowst[r * 64 + col];
+                double v = rowst[r * 64 + ((col & 48) | ((col + (col >> 4)) & 15))];
                 if (m0 > 0)
                   {
                     const double cin = carryo[R]; // broadcast read
