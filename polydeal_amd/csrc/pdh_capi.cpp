@@ -857,6 +857,63 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
 // is made on the packed points themselves, so any description qualifies that has the geometry - there is no mesh-type
 // flag.  Planarity is required to a few ulp: the kernel evaluates the bases at ONE plane coordinate per face (the mean).
 // ---------------------------------------------------------------------------------------------------
+// Are the volume points of every owned polytope tensor-product rules of n^dim points on axis-aligned boxes (pdh_problem::
+// vq_tensor_n)?  Checked on the packed points to a few ulp; dim = 3.
+static bool volume_rules_are_tensor(const pdh_problem *p, const Packed &K, int n)
+{
+  if (n <= 0 || n > 8 || p->dim != 3)
+    return false;
+  const int64_t m = (int64_t)n * n * n, nvq = (int64_t)K.vq_w.size();
+  std::vector<char> bad((size_t)K.n_owned, 0);
+  host_parallel_for((size_t)K.n_owned, [&](size_t sl) {
+    const int64_t b0 = K.vq_ptr[sl], e0 = K.vq_ptr[sl + 1];
+    if ((e0 - b0) % m)
+      {
+        bad[sl] = 1;
+        return;
+      }
+    const int a = K.own_agg[sl];
+    for (int64_t b = b0; b < e0; b += m)
+      {
+        const double w000 = K.vq_w[b];
+        if (!(w000 > 0.0))
+          {
+            bad[sl] = 1;
+            return;
+          }
+        for (int k = 0; k < n; ++k)
+          for (int j = 0; j < n; ++j)
+            for (int i = 0; i < n; ++i)
+              {
+                const int64_t q = b + i + (int64_t)n * (j + (int64_t)n * k);
+                const int idx[3] = {i, j, k};
+                const int64_t step[3] = {1, n, (int64_t)n * n};
+                double wf = w000;
+                for (int d = 0; d < 3; ++d)
+                  {
+                    const double X = K.vq_x[d * nvq + b + idx[d] * step[d]];
+                    const double h = p->bbox[(size_t)a * 6 + 3 + d] - p->bbox[(size_t)a * 6 + d];
+                    if (std::fabs(K.vq_x[d * nvq + q] - X) > 8e-16 * (std::fabs(X) + h))
+                      {
+                        bad[sl] = 1;
+                        return;
+                      }
+                    wf *= K.vq_w[b + idx[d] * step[d]] / w000;
+                  }
+                if (std::fabs(K.vq_w[q] - wf) > 1e-13 * wf)
+                  {
+                    bad[sl] = 1;
+                    return;
+                  }
+              }
+      }
+  });
+  for (char c : bad)
+    if (c)
+      return false;
+  return true;
+}
+
 struct RowsHost
 {
   std::vector<int32_t> fr_ptr, fr_pcnt, fr_nbr, fr_axis, fr_blk, fr_flags;
@@ -1211,6 +1268,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
             else
               R.stamps = nullptr;
           }
+          R.vq_tensor_n = volume_rules_are_tensor(p, K, p->vq_tensor_n) ? p->vq_tensor_n : 0;
           ctx->rows_ok = true;
         }
     }

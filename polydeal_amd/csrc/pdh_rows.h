@@ -166,6 +166,63 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   Acc ma;
   ma.init(lane);
   ma.init_addr(W, lane);
+  double accM[NAP];
+  for (int a = 0; a < NAP; ++a)
+    accM[a] = 0.0;
+  const int tn = Rw.vq_tensor_n;
+  if (tn > 0)
+    {
+      // Verified tensor rules (pdh_problem::vq_tensor_n): the points come cell by cell, x_(i,j,k) = (X_i, Y_j, Z_k),
+      // JxW = a_i b_j c_k, so the cell's moment tensor is the outer product of three 1-D moment vectors
+      //   m_d[a] = sum_i W_d[i] L_a(x^_d[i]),   W_0 = w_(i,0,0), W_1 = w_(0,j,0) / w_000, W_2 = w_(0,0,k) / w_000
+      // - 3 n sums per cell instead of n^3 points through the MFMA.  Lanes (cell of the batch, direction) form the vectors,
+      // then every lane adds its (a0, a1) row:  M[a0,a1,.] += m_0[a0] m_1[a1] m_2[.].
+      const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
+      const int m3 = tn * tn * tn;
+      const int ncell = (int)((qe - qb) / m3);
+      double *mv = W; // [16 cells][3][8]
+#if PDHR_EXP == 4
+      for (int c0 = 0; c0 < ncell && P.n < 0; c0 += 16)
+#else
+      for (int c0 = 0; c0 < ncell; c0 += 16)
+#endif
+        {
+          const int nb = ncell - c0 < 16 ? ncell - c0 : 16;
+          PDH_WAVE_SYNC();
+          if (lane < 3 * nb)
+            {
+              const int cl = lane / 3, d = lane - 3 * cl;
+              const int64_t base = qb + (int64_t)(c0 + cl) * m3;
+              const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
+              const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
+              const double w000 = P.vq_w[base];
+              const double sc = d == 0 ? 1.0 : 1.0 / w000;
+              double mo[NA];
+              for (int a = 0; a < NA; ++a)
+                mo[a] = 0.0;
+              for (int i = 0; i < tn; ++i)
+                {
+                  const double x = (P.vq_x[(int64_t)d * P.vq_stride + base + i * step] - lo_d) * ih_d;
+                  const double w = P.vq_w[base + i * step] * sc;
+                  double Lx[NA];
+                  pdhm::legendre01<NA>(x, Lx);
+                  for (int a = 0; a < NA; ++a)
+                    mo[a] += w * Lx[a];
+                }
+              for (int a = 0; a < NA; ++a)
+                mv[(cl * 3 + d) * 8 + a] = mo[a];
+            }
+          PDH_WAVE_SYNC();
+          for (int cl = 0; cl < nb; ++cl)
+            {
+              const double pm = mv[(cl * 3 + 0) * 8 + a0] * mv[(cl * 3 + 1) * 8 + a1];
+              for (int a = 0; a < NA; ++a)
+                accM[a] += pm * mv[(cl * 3 + 2) * 8 + a];
+            }
+        }
+      PDH_WAVE_SYNC();
+    }
+  else
   {
     // point data two chunks ahead, in two statically addressed register sets (see P2 on why no copies)
     const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
@@ -655,8 +712,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
 
   PDHR_MARK(4);
   // ================= P4: diagonal block ============================================================================
-  double accM[NAP];
   PDH_WAVE_SYNC();
+  if (tn == 0)
+  {
   {
     // volume accumulators -> W[(a0,a1) row][a2] (scatter of MomentAcc, volume part)
     const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
@@ -678,6 +736,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   PDH_WAVE_SYNC();
   for (int a = 0; a < NA; ++a)
     accM[a] = W[(act ? lane : 0) * NA + a];
+  }
   if (P.reaction_c != 0.0)
     for (int a = 0; a < NA; ++a)
       accS[a] += P.reaction_c * accM[a];

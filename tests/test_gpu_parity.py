@@ -1024,6 +1024,15 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world):
     vr, used = _values(kw, "rows")
     assert used == "rows"
     assert np.max(np.abs(vr - ref)) <= TOL * sc, np.max(np.abs(vr - ref)) / sc
+    # with the hint that the volume points are tensor rules of 4^3 points per sub-cell (verified by the library): the
+    # volume moments are then integrated cell by cell in factorised form
+    vt, used_t = _values(dict(kw, vq_tensor_n=4), "rows")
+    assert used_t == "rows"
+    assert np.max(np.abs(vt - ref)) <= TOL * sc, np.max(np.abs(vt - ref)) / sc
+    assert np.max(np.abs(vt - vr)) > 0.0  # really another path
+    # a wrong hint must be harmless (the check on the points fails, the general path is taken)
+    vw, _ = _values(dict(kw, vq_tensor_n=2), "rows")
+    assert np.array_equal(vw, vr)
     vm, used_m = _values(kw, "moment")
     assert used_m == "moment" and np.max(np.abs(vr - vm)) <= 1e-13 * sc
     # per block, not only against the global maximum
