@@ -104,7 +104,9 @@ typedef struct pdh_problem
    * integrates the volume moments cell by cell in factorised form (3 n sums instead of n^3 points).  A wrong hint is
    * harmless: the check fails and the general path is taken.                                                      */
   int32_t vq_tensor_n;
-  int32_t reserved2;
+  /* The same for the face points: groups of fq_tensor_n^(dim-1) points, each a tensor rule on an axis-aligned rectangle
+   * (either tangential direction may run fastest).  Verified on the points like vq_tensor_n.                        */
+  int32_t fq_tensor_n;
 } pdh_problem;
 
 /* Lifetime -------------------------------------------------------------------------------------- */

@@ -38,7 +38,7 @@ class pdh_problem(C.Structure):
         ("face_sigma", C.c_void_p),
         ("rowptr", C.c_void_p), ("colind", C.c_void_p),
         ("col_offset", C.c_void_p), ("agg_rank", C.c_void_p),
-        ("vq_tensor_n", C.c_int32), ("reserved2", C.c_int32),
+        ("vq_tensor_n", C.c_int32), ("fq_tensor_n", C.c_int32),
     ]
 
 
@@ -145,13 +145,14 @@ class Problem:
     """Owns the NumPy arrays behind a pdh_problem (keeps them alive while the struct is in use)."""
 
     def __init__(self, *, dim, degree, basis, n_agg, n_faces, n_rows, diag_first=1, reaction_c=0.0, local=0, vq_tensor_n=0,
-                 **arrays):
+                 fq_tensor_n=0, **arrays):
         self.arrays = {}
         self.c = pdh_problem()
         self.c.dim, self.c.degree, self.c.basis = dim, degree, basis
         self.c.n_agg, self.c.n_faces, self.c.n_rows = n_agg, n_faces, n_rows
         self.c.diag_first, self.c.reaction_c, self.c.local = int(diag_first), float(reaction_c), int(local)
         self.c.vq_tensor_n = int(vq_tensor_n)
+        self.c.fq_tensor_n = int(fq_tensor_n)
         for name, dt in _DTYPES.items():
             a = arrays.get(name)
             if a is None:

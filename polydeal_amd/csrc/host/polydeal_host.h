@@ -882,6 +882,7 @@ public:
     F.c.diag_first = diag_first ? 1 : 0;
     F.c.local = local ? 1 : 0;
     F.c.reaction_c = var.reaction_c;
+    F.c.fq_tensor_n = nqf; // likewise QGauss<dim-1>(nqf) per sub-face
     F.c.vq_tensor_n = nq; // QGauss<dim>(nq) per sub-cell; the library verifies the tensor structure (fails on distorted cells)
     F.bbox.resize((size_t)nL * 2 * dim);
     F.dof_offset.resize(nL);

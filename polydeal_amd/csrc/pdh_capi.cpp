@@ -914,14 +914,97 @@ static bool volume_rules_are_tensor(const pdh_problem *p, const Packed &K, int n
   return true;
 }
 
+// Sub-face rules: groups of n^2 points of a run, tensor in the two tangential axes (ti < tj); returns for every run whether
+// tj runs fastest (flag) - or false if some group is not a tensor rule.  dim = 3; axis[r] = normal axis of the run's plane(s)
+// is not needed: the tangential axes are found per group from the first point's normal.
+static bool face_rules_are_tensor(const pdh_problem *p, const Packed &K, int n, std::vector<signed char> &fast_j)
+{
+  if (n <= 0 || n > 8 || p->dim != 3)
+    return false;
+  const int64_t nap = (int64_t)K.ap_wself.size();
+  const int m = n * n;
+  const size_t nruns = K.run_ap.size();
+  fast_j.assign(3 * nruns, -1); // per run and normal axis: does t_j run fastest? (-1: no group with that axis)
+  std::vector<char> bad(nruns, 0);
+  host_parallel_for(nruns, [&](size_t r) {
+    const int64_t b0 = K.run_ap[r];
+    const int cnt = K.run_cnt[r];
+    if (cnt % m)
+      {
+        bad[r] = 1;
+        return;
+      }
+    const int a = K.own_agg[K.run_slot[r]];
+    for (int64_t b = b0; b < b0 + cnt; b += m)
+      {
+        int c = 0;
+        for (int d = 0; d < 3; ++d)
+          if (std::fabs(K.ap_n[d * nap + b]) > 0.5)
+            c = d;
+        const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
+        // which tangential coordinate changes between the first two points?
+        const double h_i = p->bbox[(size_t)a * 6 + 3 + ti] - p->bbox[(size_t)a * 6 + ti];
+        const bool i_moves = n > 1 && std::fabs(K.ap_x[ti * nap + b + 1] - K.ap_x[ti * nap + b]) > 1e-9 * h_i;
+        const int f = (n == 1 || i_moves) ? 0 : 1;
+        signed char &fast = fast_j[3 * r + c];
+        if (fast < 0)
+          fast = (signed char)f;
+        else if (fast != f)
+          {
+            bad[r] = 1; // the kernel takes one orientation per plane of a run
+            return;
+          }
+        const int64_t st_i = f == 0 ? 1 : n, st_j = f == 0 ? n : 1;
+        for (int which = 0; which < 2; ++which)
+          {
+            const std::vector<double> &w = which ? K.ap_wcross : K.ap_wself;
+            const double w00 = w[b];
+            if (which && K.run_nbr[r] < 0)
+              continue;
+            if (!(w00 > 0.0))
+              {
+                bad[r] = 1;
+                return;
+              }
+            for (int be = 0; be < n; ++be)
+              for (int al = 0; al < n; ++al)
+                {
+                  const int64_t q = b + al * st_i + be * st_j;
+                  const double Xi = K.ap_x[ti * nap + b + al * st_i], Xj = K.ap_x[tj * nap + b + be * st_j];
+                  const double h_j = p->bbox[(size_t)a * 6 + 3 + tj] - p->bbox[(size_t)a * 6 + tj];
+                  if (std::fabs(K.ap_x[ti * nap + q] - Xi) > 8e-16 * (std::fabs(Xi) + h_i) ||
+                      std::fabs(K.ap_x[tj * nap + q] - Xj) > 8e-16 * (std::fabs(Xj) + h_j))
+                    {
+                      bad[r] = 1;
+                      return;
+                    }
+                  const double wf = w[b + al * st_i] * (w[b + be * st_j] / w00);
+                  if (std::fabs(w[q] - wf) > 1e-13 * wf)
+                    {
+                      bad[r] = 1;
+                      return;
+                    }
+                }
+          }
+      }
+  });
+  for (char c : bad)
+    if (c)
+      return false;
+  return true;
+}
+
 struct RowsHost
 {
   std::vector<int32_t> fr_ptr, fr_pcnt, fr_nbr, fr_axis, fr_blk, fr_flags;
   std::vector<int64_t> fr_pbeg;
   std::vector<double> fr_coord, fr_sigma, fr_nsign;
+  bool fq_tensor_ok = false;
 };
 static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R, std::string *why = nullptr)
 {
+  std::vector<signed char> fast_j;
+  R.fq_tensor_ok = face_rules_are_tensor(p, K, p->fq_tensor_n, fast_j);
   auto no = [&](const char *m) {
     if (why)
       *why = m;
@@ -1017,7 +1100,7 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
             R.fr_nbr.push_back(K.run_nbr[t]);
             R.fr_axis.push_back(pl.axis);
             R.fr_blk.push_back(K.run_blk[t]);
-            R.fr_flags.push_back(planes[t].size() > 1 ? 1 : 0);
+            R.fr_flags.push_back((planes[t].size() > 1 ? 1 : 0) | ((R.fq_tensor_ok && fast_j[3 * t + pl.axis] == 1) ? 2 : 0));
             R.fr_coord.push_back(pl.coord);
             R.fr_sigma.push_back(K.run_sig[t]);
             R.fr_nsign.push_back(pl.sign);
@@ -1269,6 +1352,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
               R.stamps = nullptr;
           }
           R.vq_tensor_n = volume_rules_are_tensor(p, K, p->vq_tensor_n) ? p->vq_tensor_n : 0;
+          R.fq_tensor_n = RH.fq_tensor_ok ? p->fq_tensor_n : 0;
           ctx->rows_ok = true;
         }
     }

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       int64_t pb, pe;
       bool sep;
       double lo_t0, lo_t1, ih_t0, ih_t1, loF0, loF1, ihF0, ihF1, nsg, xpl, ptol, sig;
-      bool masked;
+      bool masked, fast_j;
     };
     auto face_params = [&](int t) {
       FP fp;
@@ -327,7 +327,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       fp.xpl = rl_d(t_coord, t);
       fp.ptol = 1e-9 / sel3(fp.c, ih0, ih1, ih2);
       fp.sig = rl_d(t_sigma, t);
-      fp.masked = rl_i(t_flags, t) != 0;
+      fp.masked = (rl_i(t_flags, t) & 1) != 0;
+      fp.fast_j = (rl_i(t_flags, t) & 2) != 0; // tensor sub-face rules: the j direction runs fastest
       return fp;
     };
     // point data of one chunk, loaded one chunk ahead of its use (half 0: x_i; half 1: x_j and the weights)
@@ -354,6 +355,176 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         }
       return r;
     };
+    // expansion of a face's 2-D moments M2 = [3][8][8] into this lane's (a0, a1) rows of the 3-D tensors
+    auto expand = [&](const FP &fp, const double *M2) {
+      const int c = fp.c;
+      // expansion into this lane's (a0, a1) rows of the 3-D tensors: M[a0,a1,a2] += L_{a_c}(zeta) M2[a_i][a_j]
+      const double zeta = (fp.xpl - sel3(c, lo0, lo1, lo2)) * sel3(c, ih0, ih1, ih2);
+      double Lc[NA];
+      pdhm::legendre01<NA>(zeta, Lc);
+      if (c == 2)
+        {
+          const double mS = M2[0 * 64 + a0 * 8 + a1], mN = M2[1 * 64 + a0 * 8 + a1];
+          for (int a = 0; a < NA; ++a)
+            {
+              accS[a] += Lc[a] * mS;
+              accN[2][a] += Lc[a] * mN;
+            }
+        }
+      else
+        {
+          // c == 1: (i, j) = (0, 2): factor L_{a1}(zeta), row a0;  c == 0: (i, j) = (1, 2): factor L_{a0}(zeta), row a1
+          const int asel = c == 1 ? a1 : a0, arow = c == 1 ? a0 : a1;
+          double lc_ = Lc[0];
+          static_for<1, NA>([&](auto a_) {
+            constexpr int a = a_;
+            lc_ = asel == a ? Lc[a] : lc_;
+          });
+          for (int a = 0; a < NA; ++a)
+            {
+              const double mS = M2[0 * 64 + arow * 8 + a], mN = M2[1 * 64 + arow * 8 + a];
+              accS[a] += lc_ * mS;
+              if (c == 1)
+                accN[1][a] += lc_ * mN;
+              else
+                accN[0][a] += lc_ * mN;
+            }
+        }
+    };
+    const int fn = Rw.fq_tensor_n;
+    const int nf2 = fn > 0 ? fn * fn : 1;
+    const int my_nsub = (fn > 0 && lane < nfaces) ? t_pcnt / nf2 : 0;
+    // (an entry with more than 32 sub-faces does not fit the 64 lane tasks of a batch: such polytopes take the MFMA path)
+    const bool face_tensor = fn > 0 && __ballot(my_nsub > 32) == 0ull;
+    if (face_tensor)
+      {
+        // Verified tensor rules on the sub-faces (pdh_problem::fq_tensor_n): every group of fn^2 points is a rule
+        // x = (X_alpha, Y_beta), JxW = a_alpha b_beta on an axis-aligned rectangle, so a sub-face's 2-D moments are the outer
+        // product of two 1-D moment vectors.  sigma and the normal are constant on the face: the two diagonal-block tensors
+        // are multiples of ONE sum G = sum_sub m_i (x) m_j; the coupling tensor uses JxW of the other side (and the frame F).
+        // Lane tasks = (face entry, sub-face, direction), up to 64 at a time (all faces of a box polytope in one batch): the
+        // global loads of a whole batch are in flight together.
+        double *mv = W;         // [64 tasks][self 8 | cross 8]
+        double *M2 = W + 1024;  // [3][8][8]
+        int tb = 0;
+#if PDHR_EXP == 3
+        while (tb < nfaces && P.n < 0)
+#else
+        while (tb < nfaces)
+#endif
+          {
+            int te = tb, ntask = 0;
+            while (te < nfaces)
+              {
+                const int ns2 = 2 * rl_i(my_nsub, te);
+                if (ntask + ns2 > 64)
+                  break;
+                ntask += ns2;
+                ++te;
+              }
+            // this lane's task
+            int mt = -1, rel = 0;
+            {
+              int s0 = 0;
+              for (int t = tb; t < te; ++t)
+                {
+                  const int ns2 = 2 * rl_i(my_nsub, t);
+                  if (lane >= s0 && lane < s0 + ns2)
+                    {
+                      mt = t;
+                      rel = lane - s0;
+                    }
+                  s0 += ns2;
+                }
+            }
+            PDH_WAVE_SYNC();
+            {
+              const int src = mt >= 0 ? mt : 0;
+              // the entry's parameters live in lane `src` of the face table
+              const int c = __shfl(t_axis, src), flags = __shfl(t_flags, src), nbr = __shfl(t_nbr, src);
+              const double nsg = __shfl(t_nsign, src), xpl = __shfl(t_coord, src);
+              const int64_t pb = ((int64_t)__shfl(t_pbhi, src) << 32) | (uint32_t)__shfl(t_pblo, src);
+              const double q0 = __shfl(t_qlo0, src), q1 = __shfl(t_qlo1, src), q2 = __shfl(t_qlo2, src);
+              const double i0 = __shfl(t_qih0, src), i1 = __shfl(t_qih1, src), i2 = __shfl(t_qih2, src);
+              if (mt >= 0)
+                {
+                  const int sb = rel >> 1, dir = rel & 1;
+                  const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
+                  const int ax = dir ? tj : ti;
+                  const bool fast_j = (flags & 2) != 0, masked = (flags & 1) != 0;
+                  const bool is_fast = (dir == 1) == fast_j;
+                  const int64_t stp = is_fast ? 1 : fn;
+                  const int64_t base = pb + (int64_t)sb * nf2;
+                  const double lo_d = sel3(ax, lo0, lo1, lo2), ih_d = sel3(ax, ih0, ih1, ih2);
+                  // frame of the coupling moments in this direction: the shorter of the two box intervals
+                  double loF_d = lo_d, ihF_d = ih_d;
+                  if (nbr >= 0)
+                    {
+                      const double lq = sel3(ax, q0, q1, q2), iq = sel3(ax, i0, i1, i2);
+                      if (iq > ih_d)
+                        loF_d = lq, ihF_d = iq;
+                    }
+                  bool member = true;
+                  if (masked) // boundary run of a corner polytope: sub-faces of the other planes do not count
+                    member = P.ap_n[(int64_t)c * P.ap_stride + base] * nsg > 0.5 &&
+                             fabs(P.ap_x[(int64_t)c * P.ap_stride + base] - xpl) <= 1e-9 / sel3(c, ih0, ih1, ih2);
+                  const double sS = dir ? 1.0 / P.ap_wself[base] : 1.0, sC = dir ? 1.0 / P.ap_wcross[base] : 1.0;
+                  double ms[NA], mc[NA];
+                  for (int a = 0; a < NA; ++a)
+                    ms[a] = mc[a] = 0.0;
+                  for (int al = 0; al < fn; ++al)
+                    {
+                      const int64_t q = base + al * stp;
+                      const double x = P.ap_x[(int64_t)ax * P.ap_stride + q];
+                      const double wS = member ? P.ap_wself[q] * sS : 0.0;
+                      const double wC = (member && nbr >= 0) ? P.ap_wcross[q] * sC : 0.0;
+                      double Lx[NA];
+                      pdhm::legendre01<NA>((x - lo_d) * ih_d, Lx);
+                      for (int a = 0; a < NA; ++a)
+                        ms[a] += wS * Lx[a];
+                      if (ihF_d != ih_d || loF_d != lo_d)
+                        pdhm::legendre01<NA>((x - loF_d) * ihF_d, Lx);
+                      for (int a = 0; a < NA; ++a)
+                        mc[a] += wC * Lx[a];
+                    }
+                  for (int a = 0; a < NA; ++a)
+                    {
+                      mv[lane * 16 + a] = ms[a];
+                      mv[lane * 16 + 8 + a] = mc[a];
+                    }
+                }
+            }
+            PDH_WAVE_SYNC();
+            int s0 = 0;
+            for (int t = tb; t < te; ++t)
+              {
+                const FP fp = face_params(t);
+                const int ns = rl_i(my_nsub, t);
+                double G = 0.0, Gc = 0.0;
+                for (int sb = 0; sb < ns; ++sb)
+                  {
+                    G += mv[(s0 + 2 * sb) * 16 + a0] * mv[(s0 + 2 * sb + 1) * 16 + a1];
+                    Gc += mv[(s0 + 2 * sb) * 16 + 8 + a0] * mv[(s0 + 2 * sb + 1) * 16 + 8 + a1];
+                  }
+                s0 += 2 * ns;
+                if (act)
+                  {
+                    M2[0 * 64 + a0 * 8 + a1] = fp.sig * G;
+                    M2[1 * 64 + a0 * 8 + a1] = -0.5 * fp.nsg * G;
+                    M2[2 * 64 + a0 * 8 + a1] = Gc;
+                  }
+                PDH_WAVE_SYNC();
+                expand(fp, M2);
+                const int fl = t - n_bdry;
+                if (fp.nbr >= 0 && fl >= 0 && fl < MAXF)
+                  M2c[fl * 64 + lane] = M2[2 * 64 + lane];
+                PDH_WAVE_SYNC();
+              }
+            tb = te;
+          }
+        PDH_WAVE_SYNC();
+      }
+    else
 #if PDHR_EXP == 3
     if (nfaces > 0 && P.n < 0)
 #else
@@ -517,40 +688,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 acc0 = acc1 = acc2 = 0.0;
                 PDH_WAVE_SYNC();
                 if (pass == 0)
-                  {
-                    // expansion into this lane's (a0, a1) rows of the 3-D tensors: M[a0,a1,a2] += L_{a_c}(zeta) M2[a_i][a_j]
-                    const double zeta = (fp.xpl - sel3(c, lo0, lo1, lo2)) * sel3(c, ih0, ih1, ih2);
-                    double Lc[NA];
-                    pdhm::legendre01<NA>(zeta, Lc);
-                    if (c == 2)
-                      {
-                        const double mS = M2[0 * 64 + a0 * 8 + a1], mN = M2[1 * 64 + a0 * 8 + a1];
-                        for (int a = 0; a < NA; ++a)
-                          {
-                            accS[a] += Lc[a] * mS;
-                            accN[2][a] += Lc[a] * mN;
-                          }
-                      }
-                    else
-                      {
-                        // c == 1: (i, j) = (0, 2): factor L_{a1}(zeta), row a0;  c == 0: (i, j) = (1, 2): factor L_{a0}(zeta), row a1
-                        const int asel = c == 1 ? a1 : a0, arow = c == 1 ? a0 : a1;
-                        double lc_ = Lc[0];
-                        static_for<1, NA>([&](auto a_) {
-                          constexpr int a = a_;
-                          lc_ = asel == a ? Lc[a] : lc_;
-                        });
-                        for (int a = 0; a < NA; ++a)
-                          {
-                            const double mS = M2[0 * 64 + arow * 8 + a], mN = M2[1 * 64 + arow * 8 + a];
-                            accS[a] += lc_ * mS;
-                            if (c == 1)
-                              accN[1][a] += lc_ * mN;
-                            else
-                              accN[0][a] += lc_ * mN;
-                          }
-                      }
-                  }
+                  expand(fp, M2);
                 const int fl = t - n_bdry;
                 if (fp.nbr >= 0 && (pass == 1 || !fp.sep) && fl >= 0 && fl < MAXF)
                   M2c[fl * 64 + lane] = M2[2 * 64 + lane];

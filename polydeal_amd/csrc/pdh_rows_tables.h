@@ -9,10 +9,12 @@ struct PdhRows
   const int32_t *fr_nbr;   // neighbour polytope, -1 on the boundary
   const int32_t *fr_axis;  // normal axis c
   const int32_t *fr_blk;   // ascending rank of the neighbour's block in the row (-1 on the boundary)
-  const int32_t *fr_flags; // 1: the point range holds points of other planes too (boundary run of a corner polytope)
+  const int32_t *fr_flags; // bit 0: the point range holds points of other planes too (boundary run of a corner polytope);
+                           // bit 1: tensor sub-face rules run fastest along the SECOND tangential axis
   const double *fr_coord;  // x_c of the plane
   const double *fr_sigma;  // penalty as stored per point (sigma; sigma/2 on the boundary)
   const double *fr_nsign;  // +-1: own outward normal along c
+  int32_t fq_tensor_n;     // > 0: face points are verified tensor rules of this many points per direction on every sub-face
   int32_t vq_tensor_n;     // > 0: volume points are verified tensor rules of this many points per direction (else 0)
   long long *stamps;       // [n_owned][16] s_memtime at the phase boundaries; written by -DPDHR_STAMP builds only
 };

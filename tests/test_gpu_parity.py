@@ -1030,8 +1030,14 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world):
     assert used_t == "rows"
     assert np.max(np.abs(vt - ref)) <= TOL * sc, np.max(np.abs(vt - ref)) / sc
     assert np.max(np.abs(vt - vr)) > 0.0  # really another path
+    # ... and the same for the sub-face rules (4^2 points each), alone and together with the volume hint
+    for hint in (dict(fq_tensor_n=4), dict(fq_tensor_n=4, vq_tensor_n=4)):
+        vf, used_f = _values(dict(kw, **hint), "rows")
+        assert used_f == "rows"
+        assert np.max(np.abs(vf - ref)) <= TOL * sc, (hint, np.max(np.abs(vf - ref)) / sc)
+        assert np.max(np.abs(vf - vr)) > 0.0
     # a wrong hint must be harmless (the check on the points fails, the general path is taken)
-    vw, _ = _values(dict(kw, vq_tensor_n=2), "rows")
+    vw, _ = _values(dict(kw, vq_tensor_n=2, fq_tensor_n=2), "rows")
     assert np.array_equal(vw, vr)
     vm, used_m = _values(kw, "moment")
     assert used_m == "moment" and np.max(np.abs(vr - vm)) <= 1e-13 * sc
