@@ -999,6 +999,7 @@ struct RowsHost
   std::vector<int32_t> fr_ptr, fr_pcnt, fr_nbr, fr_axis, fr_blk, fr_flags;
   std::vector<int64_t> fr_pbeg;
   std::vector<double> fr_coord, fr_sigma, fr_nsign;
+  std::vector<double> meta; // per-slot records of the kernel (pdh_rows.h: ROWS_REC doubles each)
   bool fq_tensor_ok = false;
 };
 static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R, std::string *why = nullptr)
@@ -1111,7 +1112,54 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
         return no("too many faces on a polytope");
       R.fr_ptr.push_back((int32_t)R.fr_pbeg.size());
     }
-  return r == nruns ? true : no("run bookkeeping");
+  if (r != nruns)
+    return no("run bookkeeping");
+  // per-slot records: header (number of entries, own box as lo / 1/h, row base / length / position of the own block,
+  // volume point range) + one entry per face with the neighbour's box - everything the kernel needs about a polytope in
+  // one contiguous block
+  constexpr int HDR = 12, MAXE = 16, ENT = 12, REC = HDR + MAXE * ENT;
+  auto as_d = [](long long v) {
+    double d;
+    std::memcpy(&d, &v, sizeof(d));
+    return d;
+  };
+  R.meta.assign((size_t)K.n_owned * REC, 0.0);
+  for (int sl = 0; sl < K.n_owned; ++sl)
+    {
+      const int f0 = R.fr_ptr[sl], nf = R.fr_ptr[sl + 1] - f0;
+      if (nf > MAXE)
+        return no("too many face entries on a polytope");
+      double *rec = R.meta.data() + (size_t)sl * REC;
+      const int a = K.own_agg[sl];
+      rec[0] = as_d(nf);
+      for (int c = 0; c < 3; ++c)
+        {
+          rec[1 + c] = p->bbox[(size_t)a * 6 + c];
+          rec[4 + c] = 1.0 / (p->bbox[(size_t)a * 6 + 3 + c] - p->bbox[(size_t)a * 6 + c]);
+        }
+      rec[7] = as_d(K.row_base[sl]);
+      rec[8] = as_d(K.row_len[sl]);
+      rec[9] = as_d(K.diag_L[sl]);
+      rec[10] = as_d(K.vq_ptr[sl]);
+      rec[11] = as_d(K.vq_ptr[sl + 1]);
+      for (int e = 0; e < nf; ++e)
+        {
+          double *en = rec + HDR + e * ENT;
+          const int f = f0 + e, nb = R.fr_nbr[f];
+          en[0] = as_d(R.fr_pbeg[f]);
+          en[1] = as_d((long long)(uint32_t)R.fr_pcnt[f] | ((long long)nb << 32));
+          en[2] = as_d((long long)(R.fr_axis[f] & 0xff) | ((long long)(R.fr_flags[f] & 0xff) << 8) | ((long long)R.fr_blk[f] << 32));
+          en[3] = R.fr_coord[f];
+          en[4] = R.fr_sigma[f];
+          en[5] = R.fr_nsign[f];
+          for (int c = 0; c < 3; ++c)
+            {
+              en[6 + c] = nb >= 0 ? p->bbox[(size_t)nb * 6 + c] : 0.0;
+              en[9 + c] = nb >= 0 ? 1.0 / (p->bbox[(size_t)nb * 6 + 3 + c] - p->bbox[(size_t)nb * 6 + c]) : 1.0;
+            }
+        }
+    }
+  return true;
 }
 
 // Host-only: 1 if the row kernel (PDH_ALG_ROWS) applies to this description and row range, 0 if not (pdh_last_error(NULL)
@@ -1334,7 +1382,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
               (rc = upload(ctx, RH.fr_axis, &R.fr_axis)) != PDH_OK || (rc = upload(ctx, RH.fr_blk, &R.fr_blk)) != PDH_OK ||
               (rc = upload(ctx, RH.fr_flags, &R.fr_flags)) != PDH_OK ||
               (rc = upload(ctx, RH.fr_coord, &R.fr_coord)) != PDH_OK || (rc = upload(ctx, RH.fr_sigma, &R.fr_sigma)) != PDH_OK ||
-              (rc = upload(ctx, RH.fr_nsign, &R.fr_nsign)) != PDH_OK)
+              (rc = upload(ctx, RH.fr_nsign, &R.fr_nsign)) != PDH_OK || (rc = upload(ctx, RH.meta, &R.meta)) != PDH_OK)
             {
               free_problem(ctx);
               return rc;

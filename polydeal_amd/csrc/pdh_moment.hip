@@ -56,7 +56,18 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
     const char *e = getenv("PDH_ROWS_LDS_PAD");
     return e ? (size_t)atol(e) : (size_t)0;
   }();
-  hipLaunchKernelGGL((pdhr::k_rows<4>), dim3((unsigned)count), dim3(PDH_WAVE), pdhr::lds_doubles_rows<4>() * sizeof(double) + pad,
+  // persistent waves: as many single-wave workgroups as fit on the device at once (8 per CU by LDS and registers), each
+  // working through slots blockIdx.x, blockIdx.x + gridDim.x, ...; PDH_ROWS_WAVES_PER_CU overrides (diagnostics)
+  static const int resident = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const char *e = getenv("PDH_ROWS_WAVES_PER_CU");
+    const int per_cu = e ? atoi(e) : 8;
+    return cus * (per_cu > 0 ? per_cu : 8);
+  }();
+  const unsigned grid = (unsigned)(count < resident ? count : resident);
+  hipLaunchKernelGGL((pdhr::k_rows<4>), dim3(grid), dim3(PDH_WAVE), pdhr::lds_doubles_rows<4>() * sizeof(double) + pad,
                      stream, *P, *R, mtab, count);
   return hipGetLastError();
 }

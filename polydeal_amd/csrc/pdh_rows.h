@@ -62,6 +62,7 @@ namespace pdhr
 using pdh::static_for;
 using pdhm::d2_t;
 
+constexpr int ROWS_HDR = 12, ROWS_MAXE = 16, ROWS_ENT = 12, ROWS_REC = ROWS_HDR + ROWS_MAXE * ROWS_ENT; // per-slot record
 constexpr int MAXF = 6;  // INTERIOR faces per polytope the LDS layout provides for (6: 20.3 KB per wave = 8 waves per CU)
 constexpr int FREC = 33; // face record: L_i[8], (s_t L_j)[3][8], pad (odd stride)
 constexpr int FCH = 32;  // face points per chunk
@@ -95,15 +96,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   constexpr int NA = M::NA, NAP = M::NAP, NG = M::NG, DIM = 3;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x;
-  const int slot = blockIdx.x;
-  if (slot >= n_owned)
-    return;
-  PDHR_MARK(0);
-  const int agg = P.own_agg[slot];
-  // bounding box as scalars (indexed by a run-time axis through sel3: an array would be demoted to scratch memory)
-  const double lo0 = P.bbox[(int64_t)agg * 6 + 0], lo1 = P.bbox[(int64_t)agg * 6 + 1], lo2 = P.bbox[(int64_t)agg * 6 + 2];
-  const double ih0 = 1.0 / (P.bbox[(int64_t)agg * 6 + 3] - lo0), ih1 = 1.0 / (P.bbox[(int64_t)agg * 6 + 4] - lo1),
-               ih2 = 1.0 / (P.bbox[(int64_t)agg * 6 + 5] - lo2);
+  // LDS tables: once per wave (the kernel is persistent: a wave works through slots blockIdx.x, blockIdx.x + gridDim.x, ...)
   auto sel3 = [](int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); };
   double *tabE = lds, *tabD = lds + M::LTAB, *tabF = lds + 2 * M::LTAB;
   double *M2c = lds + 3 * M::LTAB;  // [MAXF][8][8] coupling moments of every interior face
@@ -115,57 +108,79 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     lds[(t / NAP) * M::RS + t % NAP] = mt[t];
   if (lane < 16)
     coefL[lane] = P.tab.coef[lane >> 2][lane & 3];
-
-  const bool act = lane < NA * NA;
-  const int a0 = act ? lane / NA : 0, a1 = act ? lane % NA : 0;
-  const int64_t rbase = P.row_base[slot];
-  const int rlen = P.row_len[slot];
-  const int L = P.diag_L[slot];
-  const int m0 = L >> 6;
-  const int f_begin = Rw.fr_ptr[slot];
-  const int nfaces = Rw.fr_ptr[slot + 1] - f_begin; // <= 64 (host)
-  // The face table of the polytope lives in the lanes (lane t = face t): ONE round of loads (+ one for the neighbours'
-  // boxes) instead of a chain of dependent loads per face; a face's entries are read with v_readlane.
-  int t_pcnt = 0, t_nbr = -1, t_axis = 0, t_blk = -1, t_pblo = 0, t_pbhi = 0, t_flags = 0;
-  double t_coord = 0.0, t_sigma = 0.0, t_nsign = 1.0, t_qlo0 = 0.0, t_qlo1 = 0.0, t_qlo2 = 0.0, t_qih0 = 1.0, t_qih1 = 1.0, t_qih2 = 1.0;
-  if (lane < nfaces)
-    {
-      const int f = f_begin + lane;
-      const int64_t pbeg = Rw.fr_pbeg[f];
-      t_pblo = (int)(uint32_t)pbeg;
-      t_pbhi = (int)(pbeg >> 32);
-      t_pcnt = Rw.fr_pcnt[f];
-      t_nbr = Rw.fr_nbr[f];
-      t_axis = Rw.fr_axis[f];
-      t_blk = Rw.fr_blk[f];
-      t_flags = Rw.fr_flags[f];
-      t_coord = Rw.fr_coord[f];
-      t_sigma = Rw.fr_sigma[f];
-      t_nsign = Rw.fr_nsign[f];
-      if (t_nbr >= 0)
-        {
-          const double *bq = P.bbox + (int64_t)t_nbr * 6;
-          t_qlo0 = bq[0];
-          t_qlo1 = bq[1];
-          t_qlo2 = bq[2];
-          t_qih0 = 1.0 / (bq[3] - bq[0]);
-          t_qih1 = 1.0 / (bq[4] - bq[1]);
-          t_qih2 = 1.0 / (bq[5] - bq[2]);
-        }
-    }
   auto rl_i = [](int v, int t) { return __builtin_amdgcn_readlane(v, t); };
   auto rl_d = [](double v, int t) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), t), __builtin_amdgcn_readlane(__double2loint(v), t));
   };
+  // Per-slot record (pdh_capi.cpp:build_rows_tables): ROWS_HDR header doubles, then ROWS_MAXE face entries of ROWS_ENT
+  // doubles (neighbour boxes included) - ONE round of loads per polytope, requested a whole polytope ahead: under the store
+  // traffic of this kernel a dependent global load takes ~7k cycles, and the chain slot -> face table -> neighbour boxes
+  // used to cost three of them at the head of every polytope.
+  struct Meta
+  {
+    double e[ROWS_ENT]; // lanes 0 .. ROWS_MAXE-1: the face entry; lanes 16 .. 16+ROWS_HDR-1: e[0] = header value
+  };
+  auto load_meta = [&](int s_) {
+    Meta m;
+    const double *r = Rw.meta + (int64_t)s_ * ROWS_REC;
+    for (int k = 0; k < ROWS_ENT; ++k)
+      m.e[k] = 0.0;
+    if (lane < ROWS_MAXE)
+      for (int k = 0; k < ROWS_ENT; ++k)
+        m.e[k] = r[ROWS_HDR + lane * ROWS_ENT + k];
+    else if (lane < 16 + ROWS_HDR)
+      m.e[0] = r[lane - 16];
+    return m;
+  };
+  int slot = blockIdx.x;
+  if (slot >= n_owned)
+    return;
+  Meta cur = load_meta(slot);
+  const int lane_outer = lane;
+#pragma unroll 1
+  for (; slot < n_owned; slot += (int)gridDim.x)
+  {
+  // Everything derived from the lane number below is loop-invariant; hoisted out of this loop it would sit in ~60 VGPRs for
+  // the whole kernel (the compiler did exactly that: 256 VGPRs + spills).  An opaque copy ties it to the iteration.
+  int lane = lane_outer;
+  asm volatile("" : "+v"(lane));
+  const bool act = lane < NA * NA;
+  const int a0 = act ? lane / NA : 0, a1 = act ? lane % NA : 0;
+  PDHR_MARK(0);
+  PDH_WAVE_SYNC();
+  // ---- decode this polytope's record; request the next one's
+  const double lo0 = rl_d(cur.e[0], 16 + 1), lo1 = rl_d(cur.e[0], 16 + 2), lo2 = rl_d(cur.e[0], 16 + 3);
+  const double ih0 = rl_d(cur.e[0], 16 + 4), ih1 = rl_d(cur.e[0], 16 + 5), ih2 = rl_d(cur.e[0], 16 + 6);
+  const int nfaces = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 0));
+  const int64_t rbase = __double_as_longlong(rl_d(cur.e[0], 16 + 7));
+  const int rlen = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 8));
+  const int L = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 9));
+  const int64_t vq_b = __double_as_longlong(rl_d(cur.e[0], 16 + 10)), vq_e = __double_as_longlong(rl_d(cur.e[0], 16 + 11));
+  const int m0 = L >> 6;
+  // the face table of the polytope lives in the lanes (lane t = face t); a face's entries are read with v_readlane
+  const long long pb_ = __double_as_longlong(cur.e[0]);
+  const int t_pblo = (int)(uint32_t)pb_, t_pbhi = (int)(pb_ >> 32);
+  const long long i1_ = __double_as_longlong(cur.e[1]), i2_ = __double_as_longlong(cur.e[2]);
+  const int t_pcnt = lane < nfaces ? (int)(uint32_t)i1_ : 0, t_nbr = lane < nfaces ? (int)(i1_ >> 32) : -1;
+  const int t_axis = (int)(i2_ & 0xff), t_flags = (int)((i2_ >> 8) & 0xff), t_blk = lane < nfaces ? (int)(i2_ >> 32) : -1;
+  const double t_coord = cur.e[3], t_sigma = cur.e[4], t_nsign = cur.e[5];
+  const double t_qlo0 = cur.e[6], t_qlo1 = cur.e[7], t_qlo2 = cur.e[8], t_qih0 = cur.e[9], t_qih1 = cur.e[10], t_qih2 = cur.e[11];
+  Meta nxt = cur;
+  if (slot + (int)gridDim.x < n_owned)
+    nxt = load_meta(slot + (int)gridDim.x);
   int n_bdry = 0; // boundary entries come first; coupling moments are kept per interior face
   while (n_bdry < nfaces && rl_i(t_blk, n_bdry) < 0)
     ++n_bdry;
+  // (general volume path only: MFMA accumulators and operand addresses; dead registers in the tensor path)
+  pdhm::MomentAcc<N1D> ma;
+  if (Rw.vq_tensor_n == 0)
+    {
+      ma.init(lane);
+      ma.init_addr(W, lane);
+    }
 
   PDHR_MARK(1);
   // ================= P1: volume moments ========================================================================
-  Acc ma;
-  ma.init(lane);
-  ma.init_addr(W, lane);
   double accM[NAP];
   for (int a = 0; a < NAP; ++a)
     accM[a] = 0.0;
@@ -177,7 +192,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       //   m_d[a] = sum_i W_d[i] L_a(x^_d[i]),   W_0 = w_(i,0,0), W_1 = w_(0,j,0) / w_000, W_2 = w_(0,0,k) / w_000
       // - 3 n sums per cell instead of n^3 points through the MFMA.  Lanes (cell of the batch, direction) form the vectors,
       // then every lane adds its (a0, a1) row:  M[a0,a1,.] += m_0[a0] m_1[a1] m_2[.].
-      const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
+      const int64_t qb = vq_b, qe = vq_e;
       const int m3 = tn * tn * tn;
       const int ncell = (int)((qe - qb) / m3);
       double *mv = W; // [16 cells][3][8]
@@ -225,7 +240,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   else
   {
     // point data two chunks ahead, in two statically addressed register sets (see P2 on why no copies)
-    const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
+    const int64_t qb = vq_b, qe = vq_e;
     struct VRaw
     {
       double x0, x1, x2, w;
@@ -1063,5 +1078,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       }
   }
   PDHR_MARK(6);
+  cur = nxt;
+  } // persistent loop over the wave's slots
 }
 } // namespace pdhr

@@ -14,6 +14,7 @@ struct PdhRows
   const double *fr_coord;  // x_c of the plane
   const double *fr_sigma;  // penalty as stored per point (sigma; sigma/2 on the boundary)
   const double *fr_nsign;  // +-1: own outward normal along c
+  const double *meta;      // [n_owned][ROWS_REC] per-slot records (header + face entries incl. neighbour boxes), pdh_rows.h
   int32_t fq_tensor_n;     // > 0: face points are verified tensor rules of this many points per direction on every sub-face
   int32_t vq_tensor_n;     // > 0: volume points are verified tensor rules of this many points per direction (else 0)
   long long *stamps;       // [n_owned][16] s_memtime at the phase boundaries; written by -DPDHR_STAMP builds only
