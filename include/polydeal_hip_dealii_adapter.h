@@ -63,6 +63,12 @@ namespace PolyUtilsHIP
     // on the host (SURVEY trap T9: the reference's dominant CPU cost; the kernels recompute them on the device anyway).
     // nullptr: fall back to ah.reinit* (correct, slow).
     const Quadrature<dim - 1> *face_quadrature = nullptr;
+    // Hint (include/polydeal_hip.h: vq_tensor_n / fq_tensor_n): the cell rule is a tensor rule with this many points per
+    // direction (QGauss<dim>(n): n) and the background cells are axis-aligned boxes, ditto the face rule.  The library
+    // verifies the claim on the points and weights it is given and ignores it if it does not hold (distorted cells), so a
+    // caller may always pass the 1-D size of its QGauss rules.  0: no claim.
+    unsigned int cell_rule_points_1d = 0;
+    unsigned int face_rule_points_1d = 0;
   };
 
   namespace internal
@@ -152,6 +158,8 @@ namespace PolyUtilsHIP
       F.p.n_rows     = ah.n_dofs(); // global
       F.p.reaction_c = opt.reaction_c;
       F.p.local      = distributed ? 1 : 0;
+      F.p.vq_tensor_n = opt.cell_rule_points_1d;
+      F.p.fq_tensor_n = opt.face_rule_points_1d;
 
       std::vector<types::global_dof_index> dofs(fe.n_dofs_per_cell());
       auto add_polytope = [&](const auto &polytope) {
