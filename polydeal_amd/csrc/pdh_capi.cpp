@@ -1011,8 +1011,8 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
       *why = m;
     return false;
   };
-  if (p->dim != 3 || p->basis != PDH_BASIS_DGQ || p->degree != 3 || K.n != 64)
-    return no("not 3-D FE_DGQ(3)");
+  if (p->dim != 3 || p->degree != 3 || !((p->basis == PDH_BASIS_DGQ && K.n == 64) || (p->basis == PDH_BASIS_AGGLODGP && K.n == 20)))
+    return no("not 3-D FE_DGQ(3) / FE_AggloDGP(3)");
   if ((int)K.own_agg.size() != K.n_owned) // pseudo slots of the exchange variant
     return no("exchange variant");
   const int64_t nap = (int64_t)K.ap_wself.size();

@@ -45,7 +45,8 @@ extern "C" int pdh_moment_table_doubles(int n1d)
   return 0;
 }
 
-// Row kernel (pdh_rows.h): one wave per owned polytope writes all blocks of its rows; FE_DGQ(3), axis-aligned planar faces.
+// Row kernel (pdh_rows.h): one wave per owned polytope writes all blocks of its rows; FE_DGQ(3) or FE_AggloDGP(3) in 3-D,
+// axis-aligned planar faces.
 extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const double *mtab, int count, hipStream_t stream)
 {
   if (count <= 0)
@@ -58,17 +59,25 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
   }();
   // persistent waves: as many single-wave workgroups as fit on the device at once (8 per CU by LDS and registers), each
   // working through slots blockIdx.x, blockIdx.x + gridDim.x, ...; PDH_ROWS_WAVES_PER_CU overrides (diagnostics)
-  static const int resident = [] {
-    int dev = 0, cus = 256;
+  static const int cus = [] {
+    int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess)
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const char *e = getenv("PDH_ROWS_WAVES_PER_CU");
-    const int per_cu = e ? atoi(e) : 8;
-    return cus * (per_cu > 0 ? per_cu : 8);
+      (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
   }();
+  static const int per_cu_env = [] {
+    const char *e = getenv("PDH_ROWS_WAVES_PER_CU");
+    return e ? atoi(e) : 0;
+  }();
+  const bool dgp = P->n == pdhr::DGP_N; // FE_AggloDGP(3): 26 KB of LDS per wave = 6 per CU
+  const int per_cu = per_cu_env > 0 ? per_cu_env : (dgp ? 6 : 8);
+  const int resident = cus * per_cu;
   const unsigned grid = (unsigned)(count < resident ? count : resident);
-  hipLaunchKernelGGL((pdhr::k_rows<4>), dim3(grid), dim3(PDH_WAVE), pdhr::lds_doubles_rows<4>() * sizeof(double) + pad,
-                     stream, *P, *R, mtab, count);
+  constexpr size_t lds_q = pdhr::lds_doubles_rows<4, 0>() * sizeof(double), lds_p = pdhr::lds_doubles_rows<4, 1>() * sizeof(double);
+  if (dgp)
+    hipLaunchKernelGGL((pdhr::k_rows<4, 1>), dim3(grid), dim3(PDH_WAVE), lds_p + pad, stream, *P, *R, mtab, count);
+  else
+    hipLaunchKernelGGL((pdhr::k_rows<4, 0>), dim3(grid), dim3(PDH_WAVE), lds_q + pad, stream, *P, *R, mtab, count);
   return hipGetLastError();
 }
 extern "C" int pdh_rows_max_faces(void) { return pdhr::MAXF; }

@@ -68,15 +68,34 @@ constexpr int FREC = 33; // face record: L_i[8], (s_t L_j)[3][8], pad (odd strid
 constexpr int FCH = 32;  // face points per chunk
 constexpr int FSTEP = 4 * FREC * 8;
 
-template <int N1D>
-constexpr int lds_doubles_rows()
+// FE_AggloDGP(3) variant (BASIS = 1): n = 20 functions L_k0 L_k1 L_k2, k0 + k1 + k2 <= 3 (pdh_basis.h: multi_indices)
+constexpr int DGP_N = 20;
+constexpr int DGP_SS = 104; // per-face slot: first the 8x8 coupling moments, later the compact 10x10 matrix S
+__host__ __device__ constexpr int dgp_pair(int ka, int kb) { return kb * 4 - kb * (kb - 1) / 2 + ka; } // ka + kb <= 3 -> 0..9
+__device__ __forceinline__ int dgp_index(int k0, int k1, int k2)
 {
-  using M = pdhm::MT<N1D>;
+  const int zoff = k2 == 0 ? 0 : (k2 == 1 ? 10 : (k2 == 2 ? 16 : 19));
+  const int nn = 4 - k2;
+  return zoff + k1 * nn - k1 * (k1 - 1) / 2 + k0;
+}
+
+template <int N1D>
+constexpr int w_doubles_rows()
+{
   using A = pdhm::MomentAcc<N1D>;
   constexpr int w_rec = A::VCH * A::VREC > FCH * FREC ? A::VCH * A::VREC : FCH * FREC;
   constexpr int w_con = 4 * 2 * 2 * 64 + 2 * 4 * 64 + 64; // T1B + T2B + carry of the own piece
-  constexpr int w = w_rec > w_con ? w_rec : w_con;
-  return 3 * M::LTAB + MAXF * 64 + 64 /* diagv */ + 16 /* C */ + 16 /* coef */ + w;
+  return w_rec > w_con ? w_rec : w_con;
+}
+template <int N1D, int BASIS = 0>
+constexpr int lds_doubles_rows()
+{
+  using M = pdhm::MT<N1D>;
+  constexpr int w = w_doubles_rows<N1D>();
+  constexpr int slot = BASIS == 0 ? 64 : DGP_SS;
+  // BASIS = 1 adds: C of every interior face [MAXF][16], the diagonal block [20][20], digit table [3][20] ints
+  constexpr int extra = BASIS == 0 ? 0 : MAXF * 16 + DGP_N * DGP_N + 32;
+  return 3 * M::LTAB + MAXF * slot + 64 /* diagv */ + 16 /* C */ + 16 /* coef */ + w + extra;
 }
 
 // multi-index digits of a function index i = k0 + 4 k1 + 16 k2: digit of axis c, and u = k_i + 4 k_j of the other two (i < j)
@@ -87,10 +106,11 @@ __device__ __forceinline__ int digits_t(int i, int c)
   return c == 0 ? (k1 + 4 * k2) : (c == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
 }
 
-template <int N1D>
+template <int N1D, int BASIS = 0>
 __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhRows Rw, const double *__restrict__ mt, const int n_owned)
 {
-  static_assert(N1D == 4, "the row kernel is written for FE_DGQ(3)");
+  static_assert(N1D == 4, "the row kernel is written for degree 3");
+  constexpr int MS = BASIS == 0 ? 64 : DGP_SS; // doubles per interior-face slot
   using M = pdhm::MT<N1D>;
   using Acc = pdhm::MomentAcc<N1D>;
   constexpr int NA = M::NA, NAP = M::NAP, NG = M::NG, DIM = 3;
@@ -100,10 +120,30 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   auto sel3 = [](int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); };
   double *tabE = lds, *tabD = lds + M::LTAB, *tabF = lds + 2 * M::LTAB;
   double *M2c = lds + 3 * M::LTAB;  // [MAXF][8][8] coupling moments of every interior face
-  double *diagv = M2c + MAXF * 64;  // [64] diagonal entries A[R,R]
+  double *diagv = M2c + MAXF * MS;  // [64] diagonal entries A[R,R]
   double *Cbuf = diagv + 64;        // [4][4]
   double *coefL = Cbuf + 16;        // [4][4] monomial coefficients of the 1-D basis (centred variable)
   double *W = coefL + 16;           // phase-local
+  // FE_AggloDGP only: behind W
+  double *Call = W + w_doubles_rows<N1D>(); // [MAXF][4][4] C of every interior face
+  double *Dblk = Call + MAXF * 16;          // [20][20] diagonal block
+  int *dig = reinterpret_cast<int *>(Dblk + DGP_N * DGP_N); // [3 axes][20]: k_c | pair index of the other two digits << 4
+  if constexpr (BASIS == 1)
+    if (lane < DGP_N)
+      {
+        int k0 = 0, k1 = 0, k2 = 0, cnt = 0;
+        for (int iz = 0; iz < 4; ++iz)
+          for (int iy = 0; iy < 4 - iz; ++iy)
+            for (int ix = 0; ix < 4 - iy - iz; ++ix)
+              {
+                if (cnt == lane)
+                  k0 = ix, k1 = iy, k2 = iz;
+                ++cnt;
+              }
+        dig[0 * DGP_N + lane] = k0 | (dgp_pair(k1, k2) << 4);
+        dig[1 * DGP_N + lane] = k1 | (dgp_pair(k0, k2) << 4);
+        dig[2 * DGP_N + lane] = k2 | (dgp_pair(k0, k1) << 4);
+      }
   for (int t = lane; t < 3 * M::TAB; t += PDH_WAVE)
     lds[(t / NAP) * M::RS + t % NAP] = mt[t];
   if (lane < 16)
@@ -156,7 +196,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   const int rlen = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 8));
   const int L = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 9));
   const int64_t vq_b = __double_as_longlong(rl_d(cur.e[0], 16 + 10)), vq_e = __double_as_longlong(rl_d(cur.e[0], 16 + 11));
-  const int m0 = L >> 6;
+  const int m0 = BASIS == 0 ? (L >> 6) : L / DGP_N;
   // the face table of the polytope lives in the lanes (lane t = face t); a face's entries are read with v_readlane
   const long long pb_ = __double_as_longlong(cur.e[0]);
   const int t_pblo = (int)(uint32_t)pb_, t_pbhi = (int)(pb_ >> 32);
@@ -532,7 +572,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 expand(fp, M2);
                 const int fl = t - n_bdry;
                 if (fp.nbr >= 0 && fl >= 0 && fl < MAXF)
-                  M2c[fl * 64 + lane] = M2[2 * 64 + lane];
+                  M2c[fl * MS + lane] = M2[2 * 64 + lane];
                 PDH_WAVE_SYNC();
               }
             tb = te;
@@ -706,7 +746,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   expand(fp, M2);
                 const int fl = t - n_bdry;
                 if (fp.nbr >= 0 && (pass == 1 || !fp.sep) && fl >= 0 && fl < MAXF)
-                  M2c[fl * 64 + lane] = M2[2 * 64 + lane];
+                  M2c[fl * MS + lane] = M2[2 * 64 + lane];
                 PDH_WAVE_SYNC();
                 PDHR_ACC(tm_flush);
               }
@@ -795,7 +835,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     {
       // T[(k_j,l_j)][alpha] = sum_beta EQj[(k_j,l_j)][beta] M2c[alpha][beta]
       const int pair = lane & 15;
-      const double *m2 = M2c + fl * 64;
+      const double *m2 = M2c + fl * MS;
       double ej[NA];
       for (int b = 0; b < NA; ++b)
         ej[b] = EQj[pair * M::RS + b];
@@ -824,7 +864,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         double s = 0.0;
         for (int a = 0; a < NA; ++a)
           s += ei[a] * Tst[pairJ * 8 + a];
-        Sbuf[(ki + 4 * kj) * 16 + li + 4 * lj] = s;
+        if constexpr (BASIS == 0)
+          Sbuf[(ki + 4 * kj) * 16 + li + 4 * lj] = s;
+        else if (ki + kj <= 3 && li + lj <= 3) // compact S over the face's moment slot (read for the last time in the T stage)
+          M2c[fl * MS + dgp_pair(ki, kj) * 10 + dgp_pair(li, lj)] = s;
       });
     }
     if (lane < 16)
@@ -844,7 +887,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             vl = vl * zq + coefL[l * 4 + m];
           }
         const double sg = rl_d(t_nsign, t), sig = rl_d(t_sigma, t);
-        Cbuf[lane] = (0.5 * sg * dk * ih_c - sig * vk) * vl - 0.5 * sg * vk * dl * ihq_c;
+        const double cv = (0.5 * sg * dk * ih_c - sig * vk) * vl - 0.5 * sg * vk * dl * ihq_c;
+        if constexpr (BASIS == 0)
+          Cbuf[lane] = cv;
+        else
+          Call[fl * 16 + lane] = cv;
       }
     PDH_WAVE_SYNC();
   };
@@ -854,7 +901,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   // ================= P3: carry into the own block's piece ==========================================================
   const bool shifted = P.diag_first != 0;
   double carry_own = 0.0;
-  if (shifted && m0 > 0)
+  if constexpr (BASIS == 1)
+    { // FE_AggloDGP: S and C of every interior face now (P4 takes W over), kept until the rows are streamed out
+      for (int t = n_bdry; t < nfaces; ++t)
+        {
+          PDH_WAVE_SYNC();
+          build_S(t);
+        }
+    }
+  else if (shifted && m0 > 0)
     for (int t = n_bdry; t < nfaces; ++t)
       if (rl_i(t_blk, t) == m0 - 1)
         {
@@ -965,7 +1020,21 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           PDH_WAVE_SYNC();
           pdhm::mstage3(AF, T2B, lane, D3);
         }
-        if (!shifted)
+        if constexpr (BASIS == 1)
+          { // FE_AggloDGP: the entries with total degree <= 3 on both sides go to the LDS copy of the diagonal block
+            const bool colok = di + dj + dblk <= 3; // this lane's column (l0, l1, l2) = (di, dj, dblk)
+            const int jx = dgp_index(di, dj, dblk);
+            static_for<0, 4>([&](auto cf_) {
+              constexpr int cf = cf_;
+              static_for<0, 4>([&](auto s0_) {
+                constexpr int s0 = s0_;
+                if constexpr (s0 + cf <= 3)
+                  if (colok && s0 + cf + k2 <= 3)
+                    Dblk[dgp_index(s0, cf, k2) * DGP_N + jx] = D3[cf][s0];
+              });
+            });
+          }
+        else if (!shifted)
           { // ascending layout: the own block is aligned, a register is a complete row
             static_for<0, 4>([&](auto cf_) {
               constexpr int cf = cf_;
@@ -1014,6 +1083,46 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   }
 
   PDHR_MARK(5);
+  if constexpr (BASIS == 1)
+    {
+      // ================= P5 (FE_AggloDGP): the polytope's 20 rows are ONE contiguous range of 20 rlen values ==============
+      // Streamed out in 512-byte pieces that start on 128-byte lines.  Position e -> (row R, position p in the row) ->
+      // column c (diagonal-first rows: p = 0 is the diagonal entry, the rest ascending without it) -> block b, function j.
+      // Own block: the LDS copy of P4; neighbour block: C[k_c(R), l_c(j)] S[pair(R), pair(j)] of that face.
+      PDH_WAVE_SYNC();
+      const int total = DGP_N * rlen;
+      const int mis = (int)(rbase & 15);
+      int e = lane - mis, R = 0, pp = lane - mis;
+      double *out = P.values + rbase;
+      const int nit = (total + mis + 63) >> 6; // uniform trip count: the face table is read across lanes inside
+#if PDHR_EXP == 1
+      for (int it = 0; it < nit && P.n < 0; ++it, e += 64, pp += 64)
+#else
+      for (int it = 0; it < nit; ++it, e += 64, pp += 64)
+#endif
+        {
+          while (pp >= rlen)
+            pp -= rlen, ++R;
+          const bool on = e >= 0 && e < total;
+          const int Rr = on ? R : 0, pr = on ? pp : 0;
+          int c = pr;
+          if (shifted)
+            c = pr == 0 ? L + Rr : (pr - 1 + (pr - 1 >= L + Rr ? 1 : 0));
+          const int b = (c * 3277) >> 16; // c / 20 for c < 6553
+          const int j = c - b * DGP_N;
+          int fl = b < m0 ? b : b - 1;
+          fl = fl < 0 ? 0 : (fl >= MAXF ? MAXF - 1 : fl);
+          const int ax = __shfl(t_axis, n_bdry + fl) & 3;
+          const int axc = ax > 2 ? 2 : ax;
+          const int dR = dig[axc * DGP_N + Rr], dj_ = dig[axc * DGP_N + j];
+          const double cv = Call[fl * 16 + (dR & 15) * 4 + (dj_ & 15)];
+          const double sv = M2c[fl * MS + (dR >> 4) * 10 + (dj_ >> 4)];
+          const double dv = Dblk[Rr * DGP_N + j];
+          if (on)
+            out[e] = b == m0 ? dv : cv * sv;
+        }
+    }
+  else
   // ================= P5: coupling blocks in ascending column order ====================================================
   {
     double carry = 0.0; // lane R: the value that lane 0 stores in row R of the next piece

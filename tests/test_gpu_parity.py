@@ -1005,12 +1005,13 @@ ROWS_CASES = [
 ]
 
 
+@pytest.mark.parametrize("basis", ["dgq", "dgp"])
 @pytest.mark.parametrize("lg,b,vname,diag_first,world", ROWS_CASES)
-def test_row_kernel_parity(lg, b, vname, diag_first, world):
+def test_row_kernel_parity(lg, b, vname, diag_first, world, basis):
     import polydeal_amd as pa
     from polydeal_amd.partition import row_range
 
-    fe = po.FE_DGQ(3, 3)
+    fe = po.FE_DGQ(3, 3) if basis == "dgq" else po.FE_AggloDGP(3, 3)
     grid = po.hyper_cube_refined(3, 0.0, 1.0, lg)
     ah = po.AgglomerationHandler(grid)
     for g in (po.block_agglomerates(grid, b) if b else _box_groups(grid, 4)):
@@ -1039,10 +1040,10 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world):
     # a wrong hint must be harmless (the check on the points fails, the general path is taken)
     vw, _ = _values(dict(kw, vq_tensor_n=2, fq_tensor_n=2), "rows")
     assert np.array_equal(vw, vr)
-    vm, used_m = _values(kw, "moment")
-    assert used_m == "moment" and np.max(np.abs(vr - vm)) <= 1e-13 * sc
+    vm, used_m = _values(kw, "moment" if basis == "dgq" else "direct")
+    assert used_m == ("moment" if basis == "dgq" else "direct") and np.max(np.abs(vr - vm)) <= 1e-13 * sc
     # per block, not only against the global maximum
-    n = 64
+    n = fe.n_dofs_per_cell
     blk = np.abs(ref).reshape(-1, n).max(axis=1)
     err = np.abs(vr - ref).reshape(-1, n).max(axis=1)
     assert np.all(err <= 1e-11 * np.maximum(blk, 1e-3 * sc))
