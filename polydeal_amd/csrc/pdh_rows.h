@@ -79,23 +79,27 @@ __device__ __forceinline__ int dgp_index(int k0, int k1, int k2)
   return zoff + k1 * nn - k1 * (k1 - 1) / 2 + k0;
 }
 
-template <int N1D>
+constexpr int DGP_T1 = 4 * 4 * 49, DGP_T2 = 3 * 40 * 7; // stage buffers of the FE_AggloDGP diagonal block (P4)
+template <int N1D, int BASIS = 0>
 constexpr int w_doubles_rows()
 {
   using A = pdhm::MomentAcc<N1D>;
   constexpr int w_rec = A::VCH * A::VREC > FCH * FREC ? A::VCH * A::VREC : FCH * FREC;
-  constexpr int w_con = 4 * 2 * 2 * 64 + 2 * 4 * 64 + 64; // T1B + T2B + carry of the own piece
+  constexpr int w_con = BASIS == 0 ? 4 * 2 * 2 * 64 + 2 * 4 * 64 + 64 /* T1B + T2B + carry of the own piece */
+                                   : (DGP_T1 + DGP_T2 + 63) / 64 * 64;
   return w_rec > w_con ? w_rec : w_con;
 }
 template <int N1D, int BASIS = 0>
 constexpr int lds_doubles_rows()
 {
   using M = pdhm::MT<N1D>;
-  constexpr int w = w_doubles_rows<N1D>();
+  constexpr int w = w_doubles_rows<N1D, BASIS>();
   constexpr int slot = BASIS == 0 ? 64 : DGP_SS;
   // BASIS = 1 adds: C of every interior face [MAXF][16], the diagonal block [20][20], digit table [3][20] ints
   constexpr int extra = BASIS == 0 ? 0 : MAXF * 16 + DGP_N * DGP_N + 32;
-  return 3 * M::LTAB + MAXF * slot + 64 /* diagv */ + 16 /* C */ + 16 /* coef */ + w + extra;
+  // (160 KB of LDS per CU hold 6 waves of the FE_AggloDGP variant only up to 26 624 bytes each - measured: 512 bytes more
+  // and the sixth workgroup of a CU waits for a second round)
+  return 3 * M::LTAB + MAXF * slot + (BASIS == 0 ? 64 : 0) /* diagv */ + 16 /* C */ + 16 /* coef */ + w + extra;
 }
 
 // multi-index digits of a function index i = k0 + 4 k1 + 16 k2: digit of axis c, and u = k_i + 4 k_j of the other two (i < j)
@@ -121,11 +125,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double *tabE = lds, *tabD = lds + M::LTAB, *tabF = lds + 2 * M::LTAB;
   double *M2c = lds + 3 * M::LTAB;  // [MAXF][8][8] coupling moments of every interior face
   double *diagv = M2c + MAXF * MS;  // [64] diagonal entries A[R,R]
-  double *Cbuf = diagv + 64;        // [4][4]
+  double *Cbuf = diagv + (BASIS == 0 ? 64 : 0); // [4][4]  (FE_AggloDGP has no diagv)
   double *coefL = Cbuf + 16;        // [4][4] monomial coefficients of the 1-D basis (centred variable)
   double *W = coefL + 16;           // phase-local
   // FE_AggloDGP only: behind W
-  double *Call = W + w_doubles_rows<N1D>(); // [MAXF][4][4] C of every interior face
+  double *Call = W + w_doubles_rows<N1D, BASIS>(); // [MAXF][4][4] C of every interior face
   double *Dblk = Call + MAXF * 16;          // [20][20] diagonal block
   int *dig = reinterpret_cast<int *>(Dblk + DGP_N * DGP_N); // [3 axes][20]: k_c | pair index of the other two digits << 4
   if constexpr (BASIS == 1)
@@ -255,15 +259,26 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               double mo[NA];
               for (int a = 0; a < NA; ++a)
                 mo[a] = 0.0;
-              for (int i = 0; i < tn; ++i)
-                {
-                  const double x = (P.vq_x[(int64_t)d * P.vq_stride + base + i * step] - lo_d) * ih_d;
-                  const double w = P.vq_w[base + i * step] * sc;
-                  double Lx[NA];
-                  pdhm::legendre01<NA>(x, Lx);
-                  for (int a = 0; a < NA; ++a)
-                    mo[a] += w * Lx[a];
-                }
+              // all loads of the task first (tn <= 8, checked by the host): in a rolled loop each point would wait for
+              // its own global load - four serial round trips per task
+              double xr[8], wr[8];
+              static_for<0, 8>([&](auto i_) {
+                constexpr int i = i_;
+                xr[i] = i < tn ? P.vq_x[(int64_t)d * P.vq_stride + base + i * step] : 0.0;
+                wr[i] = i < tn ? P.vq_w[base + i * step] : 0.0;
+              });
+              static_for<0, 8>([&](auto i_) {
+                constexpr int i = i_;
+                if (i < tn)
+                  {
+                    const double x = (xr[i] - lo_d) * ih_d;
+                    const double w = wr[i] * sc;
+                    double Lx[NA];
+                    pdhm::legendre01<NA>(x, Lx);
+                    for (int a = 0; a < NA; ++a)
+                      mo[a] += w * Lx[a];
+                  }
+              });
               for (int a = 0; a < NA; ++a)
                 mv[(cl * 3 + d) * 8 + a] = mo[a];
             }
@@ -460,8 +475,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         // Lane tasks = (face entry, sub-face, direction), up to 64 at a time (all faces of a box polytope in one batch): the
         // global loads of a whole batch are in flight together.
         double *mv = W;         // [64 tasks][self 8 | cross 8]
-        double *M2 = W + 1024;  // [3][8][8]
         int tb = 0;
+#ifdef PDHR_STAMP
+        long long tt_task = 0, tt_face = 0;
+#endif
 #if PDHR_EXP == 3
         while (tb < nfaces && P.n < 0)
 #else
@@ -494,6 +511,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             }
             PDH_WAVE_SYNC();
             {
+              PDHR_T0();
               const int src = mt >= 0 ? mt : 0;
               // the entry's parameters live in lane `src` of the face table
               const int c = __shfl(t_axis, src), flags = __shfl(t_flags, src), nbr = __shfl(t_nbr, src);
@@ -527,57 +545,115 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   double ms[NA], mc[NA];
                   for (int a = 0; a < NA; ++a)
                     ms[a] = mc[a] = 0.0;
-                  for (int al = 0; al < fn; ++al)
-                    {
-                      const int64_t q = base + al * stp;
-                      const double x = P.ap_x[(int64_t)ax * P.ap_stride + q];
-                      const double wS = member ? P.ap_wself[q] * sS : 0.0;
-                      const double wC = (member && nbr >= 0) ? P.ap_wcross[q] * sC : 0.0;
-                      double Lx[NA];
-                      pdhm::legendre01<NA>((x - lo_d) * ih_d, Lx);
-                      for (int a = 0; a < NA; ++a)
-                        ms[a] += wS * Lx[a];
-                      if (ihF_d != ih_d || loF_d != lo_d)
-                        pdhm::legendre01<NA>((x - loF_d) * ihF_d, Lx);
-                      for (int a = 0; a < NA; ++a)
-                        mc[a] += wC * Lx[a];
-                    }
+                  // (all loads of the task first, like the volume tasks; fn <= 8)
+                  double xr[8], wsr[8], wcr[8];
+                  static_for<0, 8>([&](auto i_) {
+                    constexpr int al = i_;
+                    const int64_t q = base + al * stp;
+                    xr[al] = al < fn ? P.ap_x[(int64_t)ax * P.ap_stride + q] : 0.0;
+                    wsr[al] = al < fn ? P.ap_wself[q] : 0.0;
+                    wcr[al] = (al < fn && nbr >= 0) ? P.ap_wcross[q] : 0.0;
+                  });
+                  static_for<0, 8>([&](auto i_) {
+                    constexpr int al = i_;
+                    if (al < fn)
+                      {
+                        const double x = xr[al];
+                        const double wS = member ? wsr[al] * sS : 0.0;
+                        const double wC = (member && nbr >= 0) ? wcr[al] * sC : 0.0;
+                        double Lx[NA];
+                        pdhm::legendre01<NA>((x - lo_d) * ih_d, Lx);
+                        for (int a = 0; a < NA; ++a)
+                          ms[a] += wS * Lx[a];
+                        if (ihF_d != ih_d || loF_d != lo_d)
+                          pdhm::legendre01<NA>((x - loF_d) * ihF_d, Lx);
+                        for (int a = 0; a < NA; ++a)
+                          mc[a] += wC * Lx[a];
+                      }
+                  });
                   for (int a = 0; a < NA; ++a)
                     {
                       mv[lane * 16 + a] = ms[a];
                       mv[lane * 16 + 8 + a] = mc[a];
                     }
                 }
+              PDHR_ACC(tt_task);
             }
             PDH_WAVE_SYNC();
+            PDHR_T0();
+            // Per face, every lane forms what its (a0, a1) rows need straight from the task vectors (read-only now): no
+            // staging of the 2-D moments, no hand-off inside the loop.  M2[a_i][a_j] = sum_sub m_i[a_i] m_j[a_j]; the rows
+            // take L_{a_c}(zeta) M2 (expansion as in the general path below).
             int s0 = 0;
             for (int t = tb; t < te; ++t)
               {
-                const FP fp = face_params(t);
-                const int ns = rl_i(my_nsub, t);
-                double G = 0.0, Gc = 0.0;
-                for (int sb = 0; sb < ns; ++sb)
+                const int c = rl_i(t_axis, t), nbr = rl_i(t_nbr, t), ns = rl_i(my_nsub, t);
+                const double kS = rl_d(t_sigma, t), kN = -0.5 * rl_d(t_nsign, t);
+                const double zeta = (rl_d(t_coord, t) - sel3(c, lo0, lo1, lo2)) * sel3(c, ih0, ih1, ih2);
+                double Lc[NA];
+                pdhm::legendre01<NA>(zeta, Lc);
+                const double *mvt = mv + s0 * 16;
+                if (c == 2)
                   {
-                    G += mv[(s0 + 2 * sb) * 16 + a0] * mv[(s0 + 2 * sb + 1) * 16 + a1];
-                    Gc += mv[(s0 + 2 * sb) * 16 + 8 + a0] * mv[(s0 + 2 * sb + 1) * 16 + 8 + a1];
+                    double G = 0.0;
+                    for (int sb = 0; sb < ns; ++sb)
+                      G += mvt[(2 * sb) * 16 + a0] * mvt[(2 * sb + 1) * 16 + a1];
+                    const double gS = kS * G, gN = kN * G;
+                    for (int a = 0; a < NA; ++a)
+                      {
+                        accS[a] += Lc[a] * gS;
+                        accN[2][a] += Lc[a] * gN;
+                      }
+                  }
+                else
+                  {
+                    const int asel = c == 1 ? a1 : a0, arow = c == 1 ? a0 : a1;
+                    double lc_ = Lc[0];
+                    static_for<1, NA>([&](auto a_) {
+                      constexpr int a = a_;
+                      lc_ = asel == a ? Lc[a] : lc_;
+                    });
+                    double g[NA];
+                    for (int a = 0; a < NA; ++a)
+                      g[a] = 0.0;
+                    for (int sb = 0; sb < ns; ++sb)
+                      {
+                        const double mi = mvt[(2 * sb) * 16 + arow];
+                        for (int a = 0; a < NA; ++a)
+                          g[a] += mi * mvt[(2 * sb + 1) * 16 + a];
+                      }
+                    const double fS = lc_ * kS, fN = lc_ * kN;
+                    for (int a = 0; a < NA; ++a)
+                      {
+                        accS[a] += fS * g[a];
+                        if (c == 1)
+                          accN[1][a] += fN * g[a];
+                        else
+                          accN[0][a] += fN * g[a];
+                      }
+                  }
+                const int fl = t - n_bdry;
+                if (nbr >= 0 && fl >= 0 && fl < MAXF)
+                  {
+                    double Gc = 0.0;
+                    for (int sb = 0; sb < ns; ++sb)
+                      Gc += mvt[(2 * sb) * 16 + 8 + a0] * mvt[(2 * sb + 1) * 16 + 8 + a1];
+                    if (act)
+                      M2c[fl * MS + a0 * 8 + a1] = Gc;
                   }
                 s0 += 2 * ns;
-                if (act)
-                  {
-                    M2[0 * 64 + a0 * 8 + a1] = fp.sig * G;
-                    M2[1 * 64 + a0 * 8 + a1] = -0.5 * fp.nsg * G;
-                    M2[2 * 64 + a0 * 8 + a1] = Gc;
-                  }
-                PDH_WAVE_SYNC();
-                expand(fp, M2);
-                const int fl = t - n_bdry;
-                if (fp.nbr >= 0 && fl >= 0 && fl < MAXF)
-                  M2c[fl * MS + lane] = M2[2 * 64 + lane];
-                PDH_WAVE_SYNC();
               }
+            PDHR_ACC(tt_face);
             tb = te;
           }
         PDH_WAVE_SYNC();
+#ifdef PDHR_STAMP
+        if (lane == 0 && Rw.stamps)
+          {
+            Rw.stamps[(int64_t)slot * 16 + 12] = tt_task;
+            Rw.stamps[(int64_t)slot * 16 + 13] = tt_face;
+          }
+#endif
       }
     else
 #if PDHR_EXP == 3
@@ -948,6 +1024,108 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   if (P.reaction_c != 0.0)
     for (int a = 0; a < NA; ++a)
       accS[a] += P.reaction_c * accM[a];
+  if constexpr (BASIS == 1)
+    {
+      // FE_AggloDGP: 20 x 20 entries - the same three-stage sum factorisation on the VALU, restricted to total degree <= 3
+      // on both sides, slab by slab over k2.  Stage 1 (a2, in registers) -> T1[g1 | ee | n0 | n1][l2][a0,a1]; stage 2 (a1):
+      // work items (k1, (l1,l2), a0) -> T2[X = D | E | Fs][k1][(l1,l2)][a0] with the h factors folded in; stage 3 (a0):
+      // work items (row (k0,k1), column j) -> the LDS copy of the block.
+      double *T1 = W, *T2 = W + DGP_T1;
+      const double s00 = ih0 * ih0, s11 = ih1 * ih1, s22 = ih2 * ih2;
+#ifdef PDHR_STAMP
+      long long tp1 = 0, tp2 = 0, tp3 = 0;
+#endif
+#pragma unroll 1
+#if PDHR_EXP == 2
+      for (int k2 = 0; k2 < 4 && P.n < 0; ++k2)
+#else
+      for (int k2 = 0; k2 < 4; ++k2)
+#endif
+        {
+          PDH_WAVE_SYNC();
+          PDHR_T0();
+          if (act)
+            static_for<0, 4>([&](auto ll_) {
+              constexpr int ll = ll_;
+              const int pr = (k2 * 4 + ll) * M::RS;
+              double g1 = 0.0, eD = 0.0, eE = 0.0, eF = 0.0, n0 = 0.0, n1 = 0.0;
+              static_for<0, NA>([&](auto a_) {
+                constexpr int a = a_;
+                const double e = tabE[pr + a], d = tabD[pr + a], f = tabF[pr + a];
+                g1 += e * accM[a];
+                eD += d * accM[a];
+                eE += e * accS[a];
+                eF += f * accN[2][a];
+                n0 += e * accN[0][a];
+                n1 += e * accN[1][a];
+              });
+              T1[(0 * 4 + ll) * 49 + lane] = g1;
+              T1[(1 * 4 + ll) * 49 + lane] = s22 * eD + eE + ih2 * eF;
+              T1[(2 * 4 + ll) * 49 + lane] = n0;
+              T1[(3 * 4 + ll) * 49 + lane] = n1;
+            });
+          PDH_WAVE_SYNC();
+          PDHR_ACC(tp1);
+          const int nk1 = 4 - k2;
+          const long long t1_ = (long long)__builtin_readcyclecounter();
+          for (int q = lane; q < nk1 * 70; q += 64)
+            {
+              const int cc = q / 7, a0_ = q - 7 * cc;
+              const int k1 = cc / 10, lp = cc - 10 * k1;
+              const int l2 = lp < 4 ? 0 : (lp < 7 ? 1 : (lp < 9 ? 2 : 3));
+              const int l1 = lp - (l2 == 0 ? 0 : (l2 == 1 ? 4 : (l2 == 2 ? 7 : 9)));
+              const int tp = (k1 * 4 + l1) * M::RS;
+              const double *r0 = T1 + (0 * 4 + l2) * 49 + a0_ * 7, *r1 = r0 + 4 * 49, *r2 = r0 + 8 * 49, *r3 = r0 + 12 * 49;
+              double sD = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, sF = 0.0;
+              static_for<0, NA>([&](auto a_) {
+                constexpr int a = a_;
+                const double e = tabE[tp + a], d = tabD[tp + a], f = tabF[tp + a], g = r0[a];
+                sD += e * g;
+                s1 += d * g;
+                s2 += e * r1[a];
+                s3 += f * r3[a];
+                sF += e * r2[a];
+              });
+              T2[(0 * 40 + cc) * 7 + a0_] = s00 * sD;
+              T2[(1 * 40 + cc) * 7 + a0_] = s11 * s1 + s2 + ih1 * s3;
+              T2[(2 * 40 + cc) * 7 + a0_] = ih0 * sF;
+            }
+          PDH_WAVE_SYNC();
+          const long long t2_ = (long long)__builtin_readcyclecounter();
+#ifdef PDHR_STAMP
+          tp2 += t2_ - t1_;
+#endif
+          const int nrow = nk1 * (nk1 + 1) / 2;
+          for (int q = lane; q < nrow * DGP_N; q += 64)
+            {
+              const int rr = q / DGP_N, j = q - DGP_N * rr;
+              int k1 = 0, k0 = rr, w_ = nk1;
+              while (k0 >= w_)
+                k0 -= w_, --w_, ++k1;
+              const int dj_ = dig[j]; // axis 0: l0 | pair(l1, l2) << 4
+              const int tp = (k0 * 4 + (dj_ & 15)) * M::RS;
+              const double *t2 = T2 + (k1 * 10 + (dj_ >> 4)) * 7;
+              double sv = 0.0;
+              static_for<0, NA>([&](auto a_) {
+                constexpr int a = a_;
+                sv += tabD[tp + a] * t2[a] + tabE[tp + a] * t2[40 * 7 + a] + tabF[tp + a] * t2[80 * 7 + a];
+              });
+              Dblk[dgp_index(k0, k1, k2) * DGP_N + j] = sv;
+            }
+#ifdef PDHR_STAMP
+          tp3 += (long long)__builtin_readcyclecounter() - t2_;
+#endif
+        }
+#ifdef PDHR_STAMP
+      if (lane == 0 && Rw.stamps)
+        {
+          Rw.stamps[(int64_t)slot * 16 + 8] = tp1;
+          Rw.stamps[(int64_t)slot * 16 + 9] = tp2;
+          Rw.stamps[(int64_t)slot * 16 + 10] = tp3;
+        }
+#endif
+    }
+  else
   {
     double *T1B = W;                  // [4 arrays][2 bf][2 ks][64]
     double *T2B = W + 4 * 2 * 2 * 64; // [2 ks][4 cf][64]
@@ -1020,21 +1198,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           PDH_WAVE_SYNC();
           pdhm::mstage3(AF, T2B, lane, D3);
         }
-        if constexpr (BASIS == 1)
-          { // FE_AggloDGP: the entries with total degree <= 3 on both sides go to the LDS copy of the diagonal block
-            const bool colok = di + dj + dblk <= 3; // this lane's column (l0, l1, l2) = (di, dj, dblk)
-            const int jx = dgp_index(di, dj, dblk);
-            static_for<0, 4>([&](auto cf_) {
-              constexpr int cf = cf_;
-              static_for<0, 4>([&](auto s0_) {
-                constexpr int s0 = s0_;
-                if constexpr (s0 + cf <= 3)
-                  if (colok && s0 + cf + k2 <= 3)
-                    Dblk[dgp_index(s0, cf, k2) * DGP_N + jx] = D3[cf][s0];
-              });
-            });
-          }
-        else if (!shifted)
+        if (!shifted)
           { // ascending layout: the own block is aligned, a register is a complete row
             static_for<0, 4>([&](auto cf_) {
               constexpr int cf = cf_;
@@ -1092,34 +1256,76 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       PDH_WAVE_SYNC();
       const int total = DGP_N * rlen;
       const int mis = (int)(rbase & 15);
-      int e = lane - mis, R = 0, pp = lane - mis;
+      int e = lane - mis;
       double *out = P.values + rbase;
-      const int nit = (total + mis + 63) >> 6; // uniform trip count: the face table is read across lanes inside
+      const int nit = (total + mis + 63) >> 6;
+      // digits of every function along each interior face's axis, face by face (6 x 20 ints in the dead T2B area of W)
+      int *digf = reinterpret_cast<int *>(W + 4 * 2 * 2 * 64);
+      for (int r = 0; r < 2; ++r) // (uniform: the face table is read across lanes)
+        {
+          const int q0 = lane + 64 * r, q = q0 < MAXF * DGP_N ? q0 : MAXF * DGP_N - 1;
+          const int f = q / DGP_N, i = q - f * DGP_N;
+          int ax = __shfl(t_axis, n_bdry + f) & 3;
+          ax = ax > 2 ? 2 : ax;
+          if (q0 < MAXF * DGP_N)
+            digf[q] = dig[ax * DGP_N + i];
+        }
+      PDH_WAVE_SYNC();
+      // four pieces per trip, level by level (positions -> digit reads -> value reads -> stores): in a rolled loop every
+      // piece waited for its own two LDS round trips (620 cycles per piece in the stamps)
+      const float rinv = 1.0f / (float)rlen;
+      const int nit4 = (nit + 3) >> 2;
 #if PDHR_EXP == 1
-      for (int it = 0; it < nit && P.n < 0; ++it, e += 64, pp += 64)
+      for (int it = 0; it < nit4 && P.n < 0; ++it, e += 256)
 #else
-      for (int it = 0; it < nit; ++it, e += 64, pp += 64)
+      for (int it = 0; it < nit4; ++it, e += 256)
 #endif
         {
-          while (pp >= rlen)
-            pp -= rlen, ++R;
-          const bool on = e >= 0 && e < total;
-          const int Rr = on ? R : 0, pr = on ? pp : 0;
-          int c = pr;
-          if (shifted)
-            c = pr == 0 ? L + Rr : (pr - 1 + (pr - 1 >= L + Rr ? 1 : 0));
-          const int b = (c * 3277) >> 16; // c / 20 for c < 6553
-          const int j = c - b * DGP_N;
-          int fl = b < m0 ? b : b - 1;
-          fl = fl < 0 ? 0 : (fl >= MAXF ? MAXF - 1 : fl);
-          const int ax = __shfl(t_axis, n_bdry + fl) & 3;
-          const int axc = ax > 2 ? 2 : ax;
-          const int dR = dig[axc * DGP_N + Rr], dj_ = dig[axc * DGP_N + j];
-          const double cv = Call[fl * 16 + (dR & 15) * 4 + (dj_ & 15)];
-          const double sv = M2c[fl * MS + (dR >> 4) * 10 + (dj_ >> 4)];
-          const double dv = Dblk[Rr * DGP_N + j];
-          if (on)
-            out[e] = b == m0 ? dv : cv * sv;
+          int Rk[4], jk[4], fk[4], dRk[4] = {0, 0, 0, 0}, dJk[4] = {0, 0, 0, 0};
+          bool on[4], own[4];
+          double val[4] = {0.0, 0.0, 0.0, 0.0};
+          static_for<0, 4>([&](auto k_) {
+            constexpr int k = k_;
+            const int ek = e + 64 * k;
+            on[k] = ek >= 0 && ek < total;
+            const int ec = on[k] ? ek : 0;
+            const int R_ = (int)(((float)ec + 0.5f) * rinv); // ec / rlen (ec < 2800, rlen >= 20: exact)
+            const int p_ = ec - R_ * rlen;
+            int c = p_;
+            if (shifted)
+              c = p_ == 0 ? L + R_ : (p_ - 1 + (p_ - 1 >= L + R_ ? 1 : 0));
+            const int b = (c * 3277) >> 16; // c / 20 for c < 6553
+            int fl = b < m0 ? b : b - 1;
+            fl = fl < 0 ? 0 : (fl >= MAXF ? MAXF - 1 : fl);
+            Rk[k] = R_, jk[k] = c - b * DGP_N, fk[k] = fl, own[k] = b == m0;
+          });
+#if PDHR_EXP == 6
+          if (P.n < 0)
+#endif
+          static_for<0, 4>([&](auto k_) {
+            constexpr int k = k_;
+            dRk[k] = digf[fk[k] * DGP_N + Rk[k]];
+            dJk[k] = digf[fk[k] * DGP_N + jk[k]];
+          });
+#if PDHR_EXP == 6
+          if (P.n < 0)
+#endif
+          static_for<0, 4>([&](auto k_) {
+            constexpr int k = k_;
+            const double cv = Call[fk[k] * 16 + (dRk[k] & 15) * 4 + (dJk[k] & 15)];
+            const double sv = M2c[fk[k] * MS + (dRk[k] >> 4) * 10 + (dJk[k] >> 4)];
+            const double dv = Dblk[Rk[k] * DGP_N + jk[k]];
+            val[k] = own[k] ? dv : cv * sv;
+          });
+          static_for<0, 4>([&](auto k_) {
+            constexpr int k = k_;
+#if PDHR_EXP == 5
+            if (on[k] && P.n < 0)
+#else
+            if (on[k])
+#endif
+              out[e + 64 * k] = val[k];
+          });
         }
     }
   else
