@@ -1047,11 +1047,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           if (act)
             static_for<0, 4>([&](auto ll_) {
               constexpr int ll = ll_;
-              const int pr = (k2 * 4 + ll) * M::RS;
+              // (uniform table rows: scalar loads from the global table, not LDS broadcasts)
+              const double *tE = mt + M::OFF_E + (k2 * 4 + ll) * NAP, *tD = mt + M::OFF_D + (k2 * 4 + ll) * NAP,
+                           *tF = mt + M::OFF_FS + (k2 * 4 + ll) * NAP;
               double g1 = 0.0, eD = 0.0, eE = 0.0, eF = 0.0, n0 = 0.0, n1 = 0.0;
               static_for<0, NA>([&](auto a_) {
                 constexpr int a = a_;
-                const double e = tabE[pr + a], d = tabD[pr + a], f = tabF[pr + a];
+                const double e = tE[a], d = tD[a], f = tF[a];
                 g1 += e * accM[a];
                 eD += d * accM[a];
                 eE += e * accS[a];
@@ -1147,13 +1149,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         if (act)
           static_for<0, 4>([&](auto ll_) {
             constexpr int ll = ll_;
-            const int pr = (k2 * 4 + ll) * M::RS;
+            // (uniform table rows: scalar loads from the global table, not LDS broadcasts)
+            const double *tE = mt + M::OFF_E + (k2 * 4 + ll) * NAP, *tD = mt + M::OFF_D + (k2 * 4 + ll) * NAP,
+                         *tF = mt + M::OFF_FS + (k2 * 4 + ll) * NAP;
             double g1 = 0.0, ee = 0.0, n0 = 0.0, n1 = 0.0;
             static_for<0, NA>([&](auto a_) {
               constexpr int a = a_;
-              const double e = tabE[pr + a];
+              const double e = tE[a];
               g1 += e * accM[a];
-              ee += (tabD[pr + a] * (ih2 * ih2)) * accM[a] + e * accS[a] + (tabF[pr + a] * ih2) * accN[2][a];
+              ee += (tD[a] * (ih2 * ih2)) * accM[a] + e * accS[a] + (tF[a] * ih2) * accN[2][a];
               n0 += e * accN[0][a];
               n1 += e * accN[1][a];
             });
