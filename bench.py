@@ -7,8 +7,10 @@ examples/poisson.cc:1099-1103).  Workload = BASELINE.json configs[2]: unit cube,
 mesh, 32^3 = 32 768 polytopes of 2x2x2 cells, p = 3, QGauss(4) cell and face rules (examples/poisson.cc:
 702-709), SIP variant of examples/poisson.cc.  Headline FE is FE_DGQ(3) ((p+1)^3 = 64 dofs/polytope,
 2 097 152 dofs); the FE_AggloDGP(3) number (20 dofs/polytope, what poisson.cc instantiates) is reported
-under "extra".  N > 1: strong scaling, polytopes (matrix rows) split into N contiguous ranges, one rank
-per GPU, every rank owns its rows outright (owner-computes-rows) so the data path has no collective.
+under "extra".  N > 1 (one rank per GPU): weak scaling by default - the mesh is N such cubes stacked along z
+(subdivided_hyper_rectangle, 64 x 64 x 64N cells, ONE connected problem), rank r owns the polytopes (matrix rows) of
+slab r and describes only them and their ghost neighbours; `--scaling strong` splits the N = 1 problem into N row
+ranges instead.  Either way every rank owns its rows outright (owner-computes-rows): the data path has no collective.
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,27 +27,38 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix (= vector) peak, datasheet; see D
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_work(flat, n):
+def algorithmic_work(flat, n, owned=None):
     """flops and compulsory HBM bytes, split per kernel.
     volume 2 d Nq n^2 per polytope; interior face 24 Nqf n^2 (12 of them in the two diagonal blocks,
     12 in the two coupling blocks); boundary face 6 Nqf n^2.  Bytes: every CSR value written once
-    + quadrature data read once (8 (d+1) per volume point, 8 (2d+1) per face point per side)."""
+    + quadrature data read once (8 (d+1) per volume point, 8 (2d+1) per face point per side).
+    `owned` (rank-local descriptions): mask of the polytopes whose rows this rank writes - a face cut by the partition
+    then counts with its owned side only (one diagonal-block contribution, one coupling block)."""
     import numpy as np
     c = flat.c
     d = c.dim
     arr = flat.arrays()
     nq = flat.nq_tot
     fq_ptr = arr["fq_ptr"]
-    cnt = np.diff(fq_ptr) if fq_ptr is not None else np.zeros(0)
-    interior = arr["face_out"] >= 0 if c.n_faces else np.zeros(0, bool)
-    nqf_int = float(cnt[interior].sum()) if c.n_faces else 0.0
-    nqf_bdr = float(cnt[~interior].sum()) if c.n_faces else 0.0
+    cnt = np.diff(fq_ptr).astype(np.float64) if fq_ptr is not None else np.zeros(0)
     n2 = float(n) * n
-    fl_diag = 2.0 * d * nq * n2 + 12.0 * nqf_int * n2 + 6.0 * nqf_bdr * n2
-    fl_off = 12.0 * nqf_int * n2
-    n_int = int(interior.sum()) if c.n_faces else 0
-    by_diag = 8.0 * n2 * c.n_agg + 8.0 * (d + 1) * nq + 8.0 * (2 * d + 1) * (2 * nqf_int + nqf_bdr)
-    by_off = 8.0 * n2 * 2 * n_int + 8.0 * (2 * d + 1) * 2 * nqf_int
+    if not c.n_faces:
+        sides_pts = bdr_pts = 0.0
+        n_blocks = 0
+    else:
+        interior = arr["face_out"] >= 0
+        if owned is None:
+            sides = np.where(interior, 2.0, 0.0)  # owned sides of every interior face
+        else:
+            sides = np.where(interior, owned[arr["face_in"]].astype(np.float64) + owned[np.maximum(arr["face_out"], 0)], 0.0)
+        sides_pts = float((cnt * sides).sum())     # face points x owned sides
+        bdr_pts = float(cnt[~interior].sum())
+        n_blocks = float(sides.sum())              # coupling blocks written
+    n_own = c.n_agg if owned is None else int(owned.sum())
+    fl_diag = 2.0 * d * nq * n2 + 6.0 * sides_pts * n2 + 6.0 * bdr_pts * n2
+    fl_off = 6.0 * sides_pts * n2
+    by_diag = 8.0 * n2 * n_own + 8.0 * (d + 1) * nq + 8.0 * (2 * d + 1) * (sides_pts + bdr_pts)
+    by_off = 8.0 * n2 * n_blocks + 8.0 * (2 * d + 1) * sides_pts
     return dict(flops=[fl_diag, fl_off], bytes=[by_diag, by_off])
 
 
@@ -57,9 +70,12 @@ def make_variant(pa, name, fe):
     return pa.SipVariant.poisson_example(fe)
 
 
-def build_handler(pa, dim, cells, block, basis, degree, nq):
+def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1):
     lg = cells.bit_length() - 1
-    if (1 << lg) == cells:
+    if stack > 1:  # `stack` unit cubes on top of each other (last direction), lexicographic cells: slab r = rank r's rows
+        grid = pa.BackgroundGrid.subdivided_hyper_rectangle(dim, (cells,) * (dim - 1) + (cells * stack,), (0.0,) * dim,
+                                                            (1.0,) * (dim - 1) + (float(stack),))
+    elif (1 << lg) == cells:
         grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, lg)
     else:
         grid = pa.BackgroundGrid.subdivided_hyper_cube(dim, cells, 0.0, 1.0)
@@ -73,12 +89,13 @@ def build_handler(pa, dim, cells, block, basis, degree, nq):
 
 def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto"):
     t0 = time.time()
-    grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1)
+    stack = world if args.scaling == "weak" else 1
+    grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1, stack)
     t_handler = time.time() - t0
     var = make_variant(pa, args.variant, fe)
     n = fe.n_dofs_per_cell
     n_agg = ah.n_agglomerates
-    # contiguous dof-row ranges of whole polytopes per rank (strong scaling)
+    # contiguous dof-row ranges of whole polytopes per rank (weak: slab r of the stacked mesh; strong: 1/N of the cube)
     from polydeal_amd.partition import row_range
     r0, r1 = row_range(n_agg, n, rank, world)
     splits = [row_range(n_agg, n, r, world)[0] for r in range(world)] + [n_agg * n]
@@ -136,7 +153,11 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
         dt = float(t.item())
     stats = ctx.stats()
     mfma = ctx.kernel_work()
-    work = algorithmic_work(flat, n) if rank == 0 else None
+    own_mask = None
+    if world > 1:
+        dofs = flat.arrays()["dof_offset"]
+        own_mask = (dofs >= r0) & (dofs < r1)
+    work = algorithmic_work(flat, n, own_mask) if rank == 0 else None
     # Validity of what the timed launches left in HBM, checked on the device (nothing is copied back): no non-finite entry,
     # and - FE_DGQ is a partition of unity - the sum of all entries of the owned rows is 1^T A 1 restricted to them, which
     # the SIP form fixes in closed form: sum over the owned Nitsche boundary faces of sigma |F|  +  c |owned polytopes|
@@ -341,6 +362,9 @@ def main():
     ap.add_argument("--fe", choices=["dgq", "dgp"], default="dgq")
     ap.add_argument("--variant", choices=["poisson", "diffusion_reaction", "assemble_dg_matrix"], default="poisson",
                     help="caller variant (penalty / face ownership / reaction term), SURVEY.md 8(a)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = N cubes stacked along the last direction, one slab per rank (default); "
+                         "strong = the N = 1 problem split into N row ranges")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary FE measurement")
     ap.add_argument("--overlap-extra", action="store_true",
                     help="also time the step with the library's default overlapped launch of its two kernels "
@@ -534,17 +558,23 @@ def main():
         out = {
             "metric": "assembled DoF/s (SIP Poisson, p=%d, %dD)" % (args.degree, args.dim),
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dD SIP Poisson, unit cube, %d^%d hex cells, %d polytopes of %d^%d cells, %s(%d) n=%d, "
+            "config": {"workload": "%dD SIP Poisson, %s, %d polytopes of %d^%d cells, %s(%d) n=%d, "
                                    "QGauss(%d), variant %s; %d dofs, %d nnz"
-                                   % (args.dim, args.cells, args.dim, r["n_agg"], args.block, args.dim,
+                                   % (args.dim,
+                                      ("unit cube, %d^%d hex cells" % (args.cells, args.dim)) if (world == 1 or args.scaling == "strong")
+                                      else ("%d unit cubes stacked along the last direction (one connected mesh), %s x %d hex cells"
+                                            % (world, " x ".join([str(args.cells)] * (args.dim - 1)), args.cells * world)),
+                                      r["n_agg"], args.block, args.dim,
                                       "FE_DGQ" if args.fe == "dgq" else "FE_AggloDGP", args.degree, r["n"],
                                       args.degree + 1, {"poisson": "examples/poisson.cc", "diffusion_reaction": "examples/diffusion_reaction.cc",
                                                         "assemble_dg_matrix": "PolyUtils::assemble_dg_matrix"}[args.variant],
                                       r["n_dofs"], r["nnz"] if r["nnz"] is not None else -1),
                        "algorithm": r["alg"],
-                       "parallelism": "rows(polytopes) split in %d contiguous ranges, owner-computes-rows, no collective" % world,
+                       "parallelism": ("rows(polytopes) split in %d contiguous ranges" % world if args.scaling == "strong" or world == 1
+                                       else "rank r owns the rows of slab r (%d polytopes per rank)" % (r["n_agg"] // world))
+                                      + ", rank-local descriptions, owner-computes-rows, no data-path collective",
                        "exchange_variant": r["ghost"]},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -211,6 +211,11 @@ class Grid:
     cell_ijk: np.ndarray  # [n_cells, dim] integer position of each active cell
     ijk_to_cell: np.ndarray  # dense lookup
     vertices: np.ndarray  # [n_cells, 2^dim, dim]
+    n_dir: tuple = None  # cells per direction (subdivided_hyper_rectangle); None: n_per_dir in every direction
+
+    @property
+    def dirs(self):
+        return self.n_dir if self.n_dir is not None else (self.n_per_dir,) * self.dim
 
     @property
     def n_cells(self):
@@ -220,7 +225,7 @@ class Grid:
         ax, side = f // 2, f % 2
         ijk = self.cell_ijk[cell].copy()
         ijk[ax] += 1 if side else -1
-        if ijk[ax] < 0 or ijk[ax] >= self.n_per_dir:
+        if ijk[ax] < 0 or ijk[ax] >= self.dirs[ax]:
             return INVALID
         return int(self.ijk_to_cell[tuple(ijk)])
 
@@ -232,8 +237,8 @@ class Grid:
         """Random interior-vertex jitter, in the spirit of GridTools::distort_random as used by
         test/polydeal/exact_solutions_dgp.cc:306 (the RNG stream itself is not reproduced)."""
         rng = np.random.default_rng(seed)
-        n = self.n_per_dir
-        shape = (n + 1,) * self.dim + (self.dim,)
+        nd = self.dirs
+        shape = tuple(m + 1 for m in nd) + (self.dim,)
         h = (self.vertices[0, -1, 0] - self.vertices[0, 0, 0])
         jitter = (rng.random(shape) * 2 - 1) * factor * h
         # keep boundary vertices fixed
@@ -241,7 +246,7 @@ class Grid:
             sl = [slice(None)] * (self.dim + 1)
             sl[c] = 0
             jitter[tuple(sl)] = 0
-            sl[c] = n
+            sl[c] = nd[c]
             jitter[tuple(sl)] = 0
         for cell in range(self.n_cells):
             for v in range(2 ** self.dim):
@@ -251,27 +256,31 @@ class Grid:
 
 
 def _build_grid(dim, n, lo, hi, order):
-    ijk = np.array(list(itertools.product(range(n), repeat=dim)), dtype=np.int64)[:, ::-1]  # x fastest
+    """n: cells per direction (int, or a tuple of dim ints for a rectangle - lexicographic order only)."""
+    nd = tuple(int(m) for m in n) if isinstance(n, (tuple, list)) else (int(n),) * dim
+    ijk = np.array(list(itertools.product(*[range(m) for m in nd[::-1]])), dtype=np.int64)[:, ::-1]  # x fastest
     if order == "morton":
-        levels = int(round(math.log2(n)))
-        assert 2 ** levels == n
+        levels = int(round(math.log2(nd[0])))
+        assert all(2 ** levels == m for m in nd)
         key = _morton_encode(ijk, dim, levels)
     else:
         key = np.zeros(len(ijk), dtype=np.int64)
+        mul = 1
         for c in range(dim):
-            key += ijk[:, c] * n ** c
+            key += ijk[:, c] * mul
+            mul *= nd[c]
     perm = np.argsort(key, kind="stable")
     cell_ijk = ijk[perm]
-    lut = np.zeros((n,) * dim, dtype=np.int64)
+    lut = np.zeros(nd, dtype=np.int64)
     lut[tuple(cell_ijk.T)] = np.arange(len(cell_ijk))
     lo = np.broadcast_to(np.asarray(lo, dtype=np.float64), (dim,))
     hi = np.broadcast_to(np.asarray(hi, dtype=np.float64), (dim,))
-    h = (hi - lo) / n
+    h = (hi - lo) / np.asarray(nd, dtype=np.float64)
     verts = np.zeros((len(cell_ijk), 2 ** dim, dim))
     for v in range(2 ** dim):
         off = np.array([(v >> c) & 1 for c in range(dim)])
         verts[:, v, :] = lo + (cell_ijk + off) * h
-    return Grid(dim, n, cell_ijk, lut, verts)
+    return Grid(dim, nd[0], cell_ijk, lut, verts, None if len(set(nd)) == 1 else nd)
 
 
 def hyper_cube_refined(dim, lo, hi, n_refine) -> Grid:
@@ -282,6 +291,11 @@ def hyper_cube_refined(dim, lo, hi, n_refine) -> Grid:
 def subdivided_hyper_cube(dim, n, lo=0.0, hi=1.0) -> Grid:
     """GridGenerator::subdivided_hyper_cube(tria, n, lo, hi): lexicographic cells [deal.II]."""
     return _build_grid(dim, n, lo, hi, "lex")
+
+
+def subdivided_hyper_rectangle(dim, repetitions, lo, hi) -> Grid:
+    """GridGenerator::subdivided_hyper_rectangle(tria, repetitions, p1, p2): lexicographic cells [deal.II]."""
+    return _build_grid(dim, tuple(repetitions), lo, hi, "lex")
 
 
 # ---------------------------------------------------------------------------
@@ -791,11 +805,11 @@ def block_agglomerates(grid: Grid, b: int):
     """Lists of cells forming b^dim blocks, in mesh order inside a block (so the master is the
     lowest index, as collect_cells_for_agglomeration yields: include/poly_utils.h:532-538);
     blocks enumerated lexicographically (x fastest)."""
-    n, dim = grid.n_per_dir, grid.dim
-    assert n % b == 0
-    nb = n // b
+    dim = grid.dim
+    assert all(m % b == 0 for m in grid.dirs)
+    nbd = [m // b for m in grid.dirs]
     out = []
-    for bijk in itertools.product(range(nb), repeat=dim):
+    for bijk in itertools.product(*[range(m) for m in nbd[::-1]]):
         bijk = bijk[::-1]
         cells = []
         for off in itertools.product(range(b), repeat=dim):

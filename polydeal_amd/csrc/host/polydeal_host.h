@@ -147,7 +147,8 @@ struct FE_AggloDGP : FiniteElement // reference include/fe_agglodgp.h:317
 class BackgroundGrid
 {
 public:
-  int dim = 2, n_per_dir = 1;
+  int dim = 2, n_per_dir = 1; // n_per_dir: cells along x (= every direction unless built as a rectangle)
+  std::array<int, 3> n_dir = {1, 1, 1};
   std::vector<std::array<int, 3>> cell_ijk;
   std::vector<int> lut;             // ijk -> cell
   std::vector<double> vertices;     // [cell][2^dim][dim]
@@ -160,6 +161,18 @@ public:
   {
     return build(dim, n, lo, hi, false);
   }
+  // GridGenerator::subdivided_hyper_rectangle(tria, repetitions, p1, p2) [deal.II]: lexicographic cells
+  static BackgroundGrid subdivided_hyper_rectangle(int dim, const int *repetitions, const double *lo, const double *hi)
+  {
+    if (dim != 2 && dim != 3)
+      throw std::invalid_argument("BackgroundGrid: dim must be 2 or 3");
+    std::array<int, 3> nd = {repetitions[0], repetitions[1], dim == 3 ? repetitions[2] : 1};
+    for (int c = 0; c < dim; ++c)
+      if (nd[c] < 1 || !(hi[c] > lo[c]))
+        throw std::invalid_argument("BackgroundGrid: repetitions must be >= 1 and p2 > p1");
+    const double l3[3] = {lo[0], lo[1], dim == 3 ? lo[2] : 0.0}, h3[3] = {hi[0], hi[1], dim == 3 ? hi[2] : 1.0};
+    return build(dim, nd, l3, h3, false);
+  }
   int n_active_cells() const { return (int)cell_ijk.size(); }
   int n_faces_per_cell() const { return 2 * dim; }
   int nv() const { return 1 << dim; }
@@ -169,7 +182,7 @@ public:
     std::array<int, 3> ijk = cell_ijk[cell];
     const int ax = f / 2;
     ijk[ax] += (f & 1) ? 1 : -1;
-    if (ijk[ax] < 0 || ijk[ax] >= n_per_dir)
+    if (ijk[ax] < 0 || ijk[ax] >= n_dir[ax])
       return invalid_index;
     return lut[lin(ijk)];
   }
@@ -181,11 +194,10 @@ public:
   {
     std::mt19937_64 rng(seed);
     std::uniform_real_distribution<double> U(-1.0, 1.0);
-    const int n = n_per_dir;
     const double h = vertex(0, nv() - 1)[0] - vertex(0, 0)[0];
     size_t nvert = 1;
     for (int c = 0; c < dim; ++c)
-      nvert *= (size_t)(n + 1);
+      nvert *= (size_t)(n_dir[c] + 1);
     std::vector<double> jit(nvert * dim, 0.0);
     for (size_t v = 0; v < nvert; ++v)
       {
@@ -193,9 +205,9 @@ public:
         bool interior = true;
         for (int c = 0; c < dim; ++c)
           {
-            const int i = (int)(r % (n + 1));
-            r /= (n + 1);
-            if (i == 0 || i == n)
+            const int i = (int)(r % (n_dir[c] + 1));
+            r /= (n_dir[c] + 1);
+            if (i == 0 || i == n_dir[c])
               interior = false;
           }
         for (int c = 0; c < dim; ++c)
@@ -212,7 +224,7 @@ public:
           for (int c = 0; c < dim; ++c)
             {
               vid += mul * (size_t)(cell_ijk[cell][c] + ((v >> c) & 1));
-              mul *= (size_t)(n + 1);
+              mul *= (size_t)(n_dir[c] + 1);
             }
           for (int c = 0; c < dim; ++c)
             vertices[((size_t)cell * nv() + v) * dim + c] += jit[vid * dim + c];
@@ -222,26 +234,33 @@ public:
 private:
   int lin(const std::array<int, 3> &ijk) const
   {
-    return ijk[0] + n_per_dir * (ijk[1] + (dim == 3 ? n_per_dir * ijk[2] : 0));
+    return ijk[0] + n_dir[0] * (ijk[1] + (dim == 3 ? n_dir[1] * ijk[2] : 0));
   }
   static BackgroundGrid build(int dim, int n, double lo, double hi, bool morton)
   {
     if (dim != 2 && dim != 3)
       throw std::invalid_argument("BackgroundGrid: dim must be 2 or 3");
+    const double l3[3] = {lo, lo, lo}, h3[3] = {hi, hi, hi};
+    return build(dim, std::array<int, 3>{n, n, dim == 3 ? n : 1}, l3, h3, morton);
+  }
+  static BackgroundGrid build(int dim, const std::array<int, 3> &nd, const double *lo, const double *hi, bool morton)
+  {
     BackgroundGrid g;
     g.dim = dim;
-    g.n_per_dir = n;
-    const size_t nc = (dim == 2) ? (size_t)n * n : (size_t)n * n * n;
+    g.n_per_dir = nd[0];
+    g.n_dir = nd;
+    const int n = nd[0];
+    const size_t nc = (size_t)nd[0] * nd[1] * (dim == 3 ? nd[2] : 1);
     g.cell_ijk.resize(nc);
     g.lut.assign(nc, 0);
     int levels = 0;
     while ((1 << levels) < n)
       ++levels;
-    if (morton && (1 << levels) != n)
-      throw std::invalid_argument("BackgroundGrid: Morton order needs a power-of-two size");
+    if (morton && ((1 << levels) != n || nd[1] != n || (dim == 3 && nd[2] != n)))
+      throw std::invalid_argument("BackgroundGrid: Morton order needs a power-of-two cube");
     for (size_t l = 0; l < nc; ++l)
       {
-        std::array<int, 3> ijk = {(int)(l % n), (int)((l / n) % n), (int)(dim == 3 ? l / ((size_t)n * n) : 0)};
+        std::array<int, 3> ijk = {(int)(l % nd[0]), (int)((l / nd[0]) % nd[1]), (int)(dim == 3 ? l / ((size_t)nd[0] * nd[1]) : 0)};
         size_t idx = l;
         if (morton)
           {
@@ -253,12 +272,11 @@ private:
         g.cell_ijk[idx] = ijk;
         g.lut[l] = (int)idx;
       }
-    const double h = (hi - lo) / n;
     g.vertices.resize(nc * (size_t)(1 << dim) * dim);
     for (size_t cell = 0; cell < nc; ++cell)
       for (int v = 0; v < (1 << dim); ++v)
         for (int c = 0; c < dim; ++c)
-          g.vertices[(cell * (1 << dim) + v) * dim + c] = lo + (g.cell_ijk[cell][c] + ((v >> c) & 1)) * h;
+          g.vertices[(cell * (1 << dim) + v) * dim + c] = lo[c] + (g.cell_ijk[cell][c] + ((v >> c) & 1)) * ((hi[c] - lo[c]) / nd[c]);
     return g;
   }
 };
@@ -1125,16 +1143,16 @@ private:
 inline void define_block_agglomerates(AgglomerationHandler &ah, int b)
 {
   const BackgroundGrid &g = ah.get_triangulation();
-  const int n = g.n_per_dir, dim = g.dim;
-  if (b <= 0 || n % b)
+  const int dim = g.dim;
+  if (b <= 0 || g.n_dir[0] % b || g.n_dir[1] % b || (dim == 3 && g.n_dir[2] % b))
     throw std::invalid_argument("block size must divide the number of cells per direction");
-  const int nb = n / b;
-  const int nblocks = (dim == 2) ? nb * nb : nb * nb * nb;
+  const int nbx = g.n_dir[0] / b, nby = g.n_dir[1] / b, nbz = dim == 3 ? g.n_dir[2] / b : 1;
+  const int nblocks = nbx * nby * nbz;
   const int ncb = (dim == 2) ? b * b : b * b * b;
   std::vector<int> cells(ncb);
   for (int B = 0; B < nblocks; ++B)
     {
-      const int bi[3] = {B % nb, (B / nb) % nb, B / (nb * nb)};
+      const int bi[3] = {B % nbx, (B / nbx) % nby, B / (nbx * nby)};
       for (int l = 0; l < ncb; ++l)
         {
           const int o[3] = {l % b, (l / b) % b, l / (b * b)};

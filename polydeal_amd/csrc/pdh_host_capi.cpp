@@ -49,6 +49,22 @@ int guarded(F &&f)
 extern "C" {
 const char *pdhh_last_error(void) { return g_host_err.c_str(); }
 
+// GridGenerator::subdivided_hyper_rectangle: repetitions[dim], p1[dim], p2[dim]
+void *pdhh_grid_create_rectangle(int dim, const int *repetitions, const double *lo, const double *hi)
+{
+  try
+    {
+      auto *h = new GridH;
+      h->g = BackgroundGrid::subdivided_hyper_rectangle(dim, repetitions, lo, hi);
+      return h;
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return nullptr;
+    }
+}
+
 void *pdhh_grid_create(int dim, int n_per_dir, int morton, double lo, double hi)
 {
   try

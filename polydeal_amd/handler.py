@@ -22,6 +22,8 @@ def _lib():
         lib.pdhh_last_error.restype = C.c_char_p
         lib.pdhh_grid_create.restype = C.c_void_p
         lib.pdhh_grid_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+        lib.pdhh_grid_create_rectangle.restype = C.c_void_p
+        lib.pdhh_grid_create_rectangle.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pdhh_grid_destroy.argtypes = [C.c_void_p]
         lib.pdhh_grid_destroy.restype = None
         lib.pdhh_grid_n_cells.argtypes = [C.c_void_p]
@@ -134,11 +136,26 @@ class SipVariant:
 class BackgroundGrid:
     """hyper_cube + refine_global (Morton order) or subdivided_hyper_cube (lexicographic)."""
 
-    def __init__(self, dim, n_per_dir, lo=0.0, hi=1.0, morton=True):
+    def __init__(self, dim, n_per_dir, lo=0.0, hi=1.0, morton=True, _handle=None):
         self.dim, self.n_per_dir = dim, n_per_dir
-        self.h = _lib().pdhh_grid_create(dim, n_per_dir, int(morton), lo, hi)
+        self.h = _handle if _handle is not None else _lib().pdhh_grid_create(dim, n_per_dir, int(morton), lo, hi)
         if not self.h:
             _raise()
+
+    @staticmethod
+    def subdivided_hyper_rectangle(dim, repetitions, lo, hi):
+        """GridGenerator::subdivided_hyper_rectangle(tria, repetitions, p1, p2): lexicographic cells."""
+        rep = np.ascontiguousarray(repetitions, dtype=np.int32)
+        p1 = np.ascontiguousarray(np.broadcast_to(np.asarray(lo, dtype=np.float64), (dim,)))
+        p2 = np.ascontiguousarray(np.broadcast_to(np.asarray(hi, dtype=np.float64), (dim,)))
+        if rep.shape != (dim,):
+            raise ValueError("repetitions must have dim entries")
+        h = _lib().pdhh_grid_create_rectangle(dim, rep.ctypes.data, p1.ctypes.data, p2.ctypes.data)
+        if not h:
+            _raise()
+        g = BackgroundGrid(dim, int(rep[0]), _handle=h)
+        g.repetitions = tuple(int(r) for r in rep)
+        return g
 
     @staticmethod
     def hyper_cube_refined(dim, lo, hi, n_refine):

@@ -146,6 +146,44 @@ def test_flatten_matches_oracle(dim, refine, b, basis, p, nq, vname, distort):
         assert np.max(np.abs(a - bb)) <= 2e-15 * max(1.0, np.max(np.abs(a))), k
 
 
+@pytest.mark.parametrize("dim,rep,lo,hi,b,basis,p,distort", [
+    (3, (4, 2, 6), (0.0, 0.0, -1.0), (2.0, 1.0, 2.0), 2, "dgq", 2, 0.0),
+    (2, (6, 3), (0.0, -1.0), (3.0, 1.0), 3, "dgp", 2, 0.1),
+    (3, (2, 2, 4), (0.0, 0.0, 0.0), (1.0, 1.0, 2.0), 1, "dgp", 3, 0.0),
+])
+def test_flatten_on_subdivided_hyper_rectangle_matches_oracle(dim, rep, lo, hi, b, basis, p, distort):
+    """GridGenerator::subdivided_hyper_rectangle grids (different cell counts and sizes per direction; the multi-GPU bench
+    stacks the per-rank slabs along z): same tables from the product mirror and from the oracle."""
+    grid = pa.BackgroundGrid.subdivided_hyper_rectangle(dim, rep, lo, hi)
+    if distort:
+        grid.distort(distort, seed=3)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_block_agglomerates(b)
+    fe = (pa.FE_DGQ if basis == "dgq" else pa.FE_AggloDGP)(dim, p)
+    ah.initialize_fe_values(p + 1, p + 1)
+    ah.distribute_agglomerated_dofs(fe)
+    flat = ah.flatten(pa.SipVariant.poisson_example(fe), diag_first=True, with_colind=True).arrays()
+    og = po.subdivided_hyper_rectangle(dim, rep, lo, hi)
+    assert og.n_cells == grid.n_cells
+    for c in range(og.n_cells):
+        if not distort:
+            assert np.max(np.abs(og.vertices[c] - grid.cell_vertices(c))) <= 1e-15
+        og.vertices[c] = grid.cell_vertices(c)
+    oah = po.AgglomerationHandler(og)
+    for g in po.block_agglomerates(og, b):
+        oah.define_agglomerate(g)
+    ofe = (po.FE_DGQ if basis == "dgq" else po.FE_AggloDGP)(dim, p)
+    oah.initialize_fe_values(p + 1, p + 1)
+    oah.distribute_agglomerated_dofs(ofe)
+    ref = oracle_flatten(oah, po.variant_poisson_example(ofe), diag_first=True)
+    for k in ("dof_offset", "vq_ptr", "face_in", "face_out", "fq_ptr", "rowptr", "colind"):
+        assert np.array_equal(np.asarray(ref[k]).ravel(), flat[k]), k
+    for k in ("bbox", "vq_x", "vq_w", "fq_x", "fq_n", "fq_w", "fq_w_out", "face_sigma"):
+        a, bb = np.asarray(ref[k], dtype=float).ravel(), flat[k]
+        assert a.shape == bb.shape, k
+        assert np.max(np.abs(a - bb)) <= 4e-15 * max(1.0, np.max(np.abs(a))), k
+
+
 def test_errors_are_reported():
     grid = pa.BackgroundGrid.hyper_cube_refined(2, 0.0, 1.0, 2)
     ah = pa.AgglomerationHandler(grid)
