@@ -12,9 +12,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -243,19 +245,25 @@ static void free_problem(pdh_ctx *ctx)
     (void)hipFree(p);
   ctx->allocs.clear();
   ctx->has_problem = false;
+  ctx->d_ap_src = nullptr;
 }
 
 template <class T>
-static int upload(pdh_ctx *ctx, const std::vector<T> &h, const T **dptr)
+static int upload_n(pdh_ctx *ctx, const T *h, size_t count, const T **dptr)
 {
   void *d = nullptr;
-  const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
   PDH_HIP(ctx, hipMalloc(&d, bytes));
   ctx->allocs.push_back(d);
-  if (!h.empty())
-    PDH_HIP(ctx, hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (count)
+    PDH_HIP(ctx, hipMemcpy(d, h, count * sizeof(T), hipMemcpyHostToDevice));
   *dptr = static_cast<const T *>(d);
   return PDH_OK;
+}
+template <class V>
+static int upload(pdh_ctx *ctx, const V &h, const typename V::value_type **dptr)
+{
+  return upload_n(ctx, h.data(), h.size(), dptr);
 }
 
 extern "C" const char *pdh_version(void) { return "polydeal_hip 0.2 gfx950"; }
@@ -324,6 +332,27 @@ extern "C" void pdh_destroy(pdh_ctx *ctx)
 // Host-only part of set_problem: validation + repacking.  Kept separate so that it can be exercised on
 // a machine without a GPU (tests call pdh_check_problem).
 // ---------------------------------------------------------------------------------------------------
+// std::vector whose resize() leaves the new elements uninitialised: the big point arrays are filled by all host threads
+// right after they are sized, a serial zero-fill of 1.3 GB in between costs more than the fill itself
+template <class T>
+struct UninitAlloc : std::allocator<T>
+{
+  template <class U>
+  struct rebind
+  {
+    using other = UninitAlloc<U>;
+  };
+  template <class U, class... A>
+  void construct(U *ptr, A &&...a)
+  {
+    if constexpr (sizeof...(A) == 0)
+      ::new ((void *)ptr) U;
+    else
+      ::new ((void *)ptr) U(std::forward<A>(a)...);
+  }
+};
+using dvec = std::vector<double, UninitAlloc<double>>;
+
 struct Packed
 {
   int n = 0, n1d = 0, NT = 0, LB = 0;
@@ -331,13 +360,42 @@ struct Packed
   PdhBasisTab tab;
   std::vector<int32_t> own_agg, own_row, row_len, diag_L, it_own, it_nbr, it_pcnt, it_pos, it_nbr_slot, it_pos_t;
   std::vector<int64_t> row_base, vq_ptr, ap_ptr, it_pbeg;
-  std::vector<double> vq_x, vq_w, ap_x, ap_n, ap_wself, ap_wcross, ap_sig;
+  dvec vq_x, vq_w;
+  // Own-side face points are NOT built on the host: set_problem uploads the caller's face arrays as they are and a kernel
+  // (pdh_exchange.hip: k_pack_faces) writes the per-polytope runs in HBM from these tables - one entry per run, owned slots
+  // first, then the pseudo slots of the exchange variant: first packed point, first caller point, count, flags
+  // (bit 0: the polytope is side 0 of the face, bit 1: boundary face), sigma of the face
+  std::vector<int64_t> pk_at, pk_fq;
+  std::vector<int32_t> pk_cnt, pk_flags;
+  std::vector<double> pk_sig;
+  int64_t n_ap = 0;
+  // volume points of the owned slots: the caller's own arrays when the slots are its polytopes in its order (no copy),
+  // else vq_x / vq_w above; [dim][vq_stride] and [n_vq]
+  const double *vqx_h = nullptr, *vqw_h = nullptr;
+  int64_t vq_stride_h = 0, n_vq = 0;
   std::vector<int64_t> vq_src, run_ap, run_fq;
   std::vector<int32_t> run_cnt, run_bdry;
   // per run (owned slots only, same order): owning slot, neighbour polytope (-1 boundary) and the ascending rank of the
   // neighbour's block in the slot's rows, penalty as stored per point - input of the row kernel's face table (pdh_rows.h)
   std::vector<int32_t> run_slot, run_nbr, run_blk;
   std::vector<double> run_sig;
+  // host view of a packed face point (what the kernel writes): run r of the owned slots, point q of the run
+  const pdh_problem *src = nullptr;
+  int64_t nqf_src = 0;
+  double ap_x(int d, size_t r, int64_t q) const { return src->fq_x[d * nqf_src + pk_fq[r] + q]; }
+  double ap_n(int d, size_t r, int64_t q) const { return ((pk_flags[r] & 1) ? 1.0 : -1.0) * src->fq_n[d * nqf_src + pk_fq[r] + q]; }
+  double ap_wself(size_t r, int64_t q) const
+  {
+    const int64_t i = pk_fq[r] + q;
+    if (pk_flags[r] & 2)
+      return 2.0 * src->fq_w[i];
+    return ((pk_flags[r] & 1) || !src->fq_w_out) ? src->fq_w[i] : src->fq_w_out[i];
+  }
+  double ap_wcross(size_t r, int64_t q) const
+  {
+    const int64_t i = pk_fq[r] + q;
+    return (pk_flags[r] & 2) ? 0.0 : (src->fq_w_out ? src->fq_w_out[i] : src->fq_w[i]);
+  }
   int64_t n_values = 0;
   int n_owned = 0; // own_agg / ap_ptr / ... may carry pseudo slots behind the owned ones (ghost-block exchange)
   // ghost-block exchange (PDH_EXCHANGE_GHOST): doubles per peer rank, and where the received blocks go
@@ -800,13 +858,22 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
 
   // second pass: weights, coordinates and normals in SoA with the final strides - disjoint ranges, all host threads
   const int64_t nvq = nvq_run, nap = nap_run;
-  K.vq_w.resize((size_t)nvq);
-  K.vq_x.resize((size_t)dim * nvq);
-  K.ap_wself.resize((size_t)nap);
-  K.ap_wcross.resize((size_t)nap);
-  K.ap_sig.resize((size_t)nap);
-  K.ap_x.resize((size_t)dim * nap);
-  K.ap_n.resize((size_t)dim * nap);
+  bool vq_identity = nvq == nq_tot;
+  for (int sl = 0; sl < K.n_owned && vq_identity; ++sl)
+    vq_identity = K.vq_ptr[sl] == p->vq_ptr[K.own_agg[sl]];
+  K.n_vq = nvq;
+  if (vq_identity)
+    K.vqx_h = p->vq_x, K.vqw_h = p->vq_w, K.vq_stride_h = nq_tot;
+  else
+    {
+      K.vq_w.resize((size_t)nvq);
+      K.vq_x.resize((size_t)dim * nvq);
+      K.vqx_h = K.vq_x.data(), K.vqw_h = K.vq_w.data(), K.vq_stride_h = nvq;
+    }
+  K.n_ap = nap;
+  K.src = p;
+  K.nqf_src = nqf_tot;
+  if (!vq_identity)
   host_parallel_for((size_t)K.n_owned, [&](size_t sl) {
     const int a = K.own_agg[sl];
     int64_t vq = K.vq_ptr[sl];
@@ -817,36 +884,26 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           K.vq_x[c * nvq + vq] = p->vq_x[c * nq_tot + q];
       }
   });
-  host_parallel_for(runs.size(), [&](size_t ri) {
-    const Run &r = runs[ri];
-    const bool side0 = (p->face_in[r.f] == r.a);
-    const int other = side0 ? p->face_out[r.f] : p->face_in[r.f];
-    const double sig = p->face_sigma[r.f];
-    const double sgn = side0 ? 1.0 : -1.0;
-    int64_t ap = run_at[ri];
-    for (int64_t q = p->fq_ptr[r.f]; q < p->fq_ptr[r.f + 1]; ++q, ++ap)
-      {
-        const double w_in = p->fq_w[q];
-        const double w_out = p->fq_w_out ? p->fq_w_out[q] : w_in;
-        if (other < 0)
-          { // Nitsche boundary: same form with 2 JxW and sigma / 2 (exact scalings)
-            K.ap_wself[ap] = 2.0 * w_in;
-            K.ap_wcross[ap] = 0.0;
-            K.ap_sig[ap] = 0.5 * sig;
-          }
-        else
-          {
-            K.ap_wself[ap] = side0 ? w_in : w_out; // M11 uses JxW_0, M22 JxW_1 (poly_utils.h:1898, 1922)
-            K.ap_wcross[ap] = w_out;               // M12, M21 use JxW_1 (poly_utils.h:1906, 1914)
-            K.ap_sig[ap] = sig;
-          }
-        for (int c = 0; c < dim; ++c)
-          {
-            K.ap_x[c * nap + ap] = p->fq_x[c * nqf_tot + q];
-            K.ap_n[c * nap + ap] = sgn * p->fq_n[c * nqf_tot + q];
-          }
-      }
-  });
+  // tables of the device-side face repack (k_pack_faces): weights and signs as the kernels want them -
+  //   boundary: w_self = 2 JxW, sigma / 2 (Nitsche boundary = interior self-block with these exact scalings), w_cross = 0;
+  //   interior: w_self = JxW of the own side (M11 uses JxW_0, M22 JxW_1: poly_utils.h:1898, 1922), w_cross = JxW_1
+  //   (M12, M21: poly_utils.h:1906, 1914), normal = outward normal of the owning polytope
+  K.pk_at.resize(runs.size());
+  K.pk_fq.resize(runs.size());
+  K.pk_cnt.resize(runs.size());
+  K.pk_flags.resize(runs.size());
+  K.pk_sig.resize(runs.size());
+  for (size_t ri = 0; ri < runs.size(); ++ri)
+    {
+      const Run &r = runs[ri];
+      const bool side0 = (p->face_in[r.f] == r.a);
+      const int other = side0 ? p->face_out[r.f] : p->face_in[r.f];
+      K.pk_at[ri] = run_at[ri];
+      K.pk_fq[ri] = p->fq_ptr[r.f];
+      K.pk_cnt[ri] = (int32_t)(p->fq_ptr[r.f + 1] - p->fq_ptr[r.f]);
+      K.pk_flags[ri] = (side0 ? 1 : 0) | (other < 0 ? 2 : 0);
+      K.pk_sig[ri] = other < 0 ? 0.5 * p->face_sigma[r.f] : p->face_sigma[r.f];
+    }
   return PDH_OK;
 }
 
@@ -863,7 +920,8 @@ static bool volume_rules_are_tensor(const pdh_problem *p, const Packed &K, int n
 {
   if (n <= 0 || n > 8 || p->dim != 3)
     return false;
-  const int64_t m = (int64_t)n * n * n, nvq = (int64_t)K.vq_w.size();
+  const int64_t m = (int64_t)n * n * n, nvq = K.vq_stride_h;
+  const double *vq_x = K.vqx_h, *vq_w = K.vqw_h;
   std::vector<char> bad((size_t)K.n_owned, 0);
   host_parallel_for((size_t)K.n_owned, [&](size_t sl) {
     const int64_t b0 = K.vq_ptr[sl], e0 = K.vq_ptr[sl + 1];
@@ -875,7 +933,7 @@ static bool volume_rules_are_tensor(const pdh_problem *p, const Packed &K, int n
     const int a = K.own_agg[sl];
     for (int64_t b = b0; b < e0; b += m)
       {
-        const double w000 = K.vq_w[b];
+        const double w000 = vq_w[b];
         if (!(w000 > 0.0))
           {
             bad[sl] = 1;
@@ -891,16 +949,16 @@ static bool volume_rules_are_tensor(const pdh_problem *p, const Packed &K, int n
                 double wf = w000;
                 for (int d = 0; d < 3; ++d)
                   {
-                    const double X = K.vq_x[d * nvq + b + idx[d] * step[d]];
+                    const double X = vq_x[d * nvq + b + idx[d] * step[d]];
                     const double h = p->bbox[(size_t)a * 6 + 3 + d] - p->bbox[(size_t)a * 6 + d];
-                    if (std::fabs(K.vq_x[d * nvq + q] - X) > 8e-16 * (std::fabs(X) + h))
+                    if (std::fabs(vq_x[d * nvq + q] - X) > 8e-16 * (std::fabs(X) + h))
                       {
                         bad[sl] = 1;
                         return;
                       }
-                    wf *= K.vq_w[b + idx[d] * step[d]] / w000;
+                    wf *= vq_w[b + idx[d] * step[d]] / w000;
                   }
-                if (std::fabs(K.vq_w[q] - wf) > 1e-13 * wf)
+                if (std::fabs(vq_w[q] - wf) > 1e-13 * wf)
                   {
                     bad[sl] = 1;
                     return;
@@ -921,13 +979,11 @@ static bool face_rules_are_tensor(const pdh_problem *p, const Packed &K, int n, 
 {
   if (n <= 0 || n > 8 || p->dim != 3)
     return false;
-  const int64_t nap = (int64_t)K.ap_wself.size();
   const int m = n * n;
   const size_t nruns = K.run_ap.size();
   fast_j.assign(3 * nruns, -1); // per run and normal axis: does t_j run fastest? (-1: no group with that axis)
   std::vector<char> bad(nruns, 0);
   host_parallel_for(nruns, [&](size_t r) {
-    const int64_t b0 = K.run_ap[r];
     const int cnt = K.run_cnt[r];
     if (cnt % m)
       {
@@ -935,16 +991,16 @@ static bool face_rules_are_tensor(const pdh_problem *p, const Packed &K, int n, 
         return;
       }
     const int a = K.own_agg[K.run_slot[r]];
-    for (int64_t b = b0; b < b0 + cnt; b += m)
+    for (int64_t b = 0; b < cnt; b += m) // b: first point of the group inside run r
       {
         int c = 0;
         for (int d = 0; d < 3; ++d)
-          if (std::fabs(K.ap_n[d * nap + b]) > 0.5)
+          if (std::fabs(K.ap_n(d, r, b)) > 0.5)
             c = d;
         const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
         // which tangential coordinate changes between the first two points?
         const double h_i = p->bbox[(size_t)a * 6 + 3 + ti] - p->bbox[(size_t)a * 6 + ti];
-        const bool i_moves = n > 1 && std::fabs(K.ap_x[ti * nap + b + 1] - K.ap_x[ti * nap + b]) > 1e-9 * h_i;
+        const bool i_moves = n > 1 && std::fabs(K.ap_x(ti, r, b + 1) - K.ap_x(ti, r, b)) > 1e-9 * h_i;
         const int f = (n == 1 || i_moves) ? 0 : 1;
         signed char &fast = fast_j[3 * r + c];
         if (fast < 0)
@@ -957,8 +1013,8 @@ static bool face_rules_are_tensor(const pdh_problem *p, const Packed &K, int n, 
         const int64_t st_i = f == 0 ? 1 : n, st_j = f == 0 ? n : 1;
         for (int which = 0; which < 2; ++which)
           {
-            const std::vector<double> &w = which ? K.ap_wcross : K.ap_wself;
-            const double w00 = w[b];
+            auto w = [&](int64_t q) { return which ? K.ap_wcross(r, q) : K.ap_wself(r, q); };
+            const double w00 = w(b);
             if (which && K.run_nbr[r] < 0)
               continue;
             if (!(w00 > 0.0))
@@ -970,16 +1026,16 @@ static bool face_rules_are_tensor(const pdh_problem *p, const Packed &K, int n, 
               for (int al = 0; al < n; ++al)
                 {
                   const int64_t q = b + al * st_i + be * st_j;
-                  const double Xi = K.ap_x[ti * nap + b + al * st_i], Xj = K.ap_x[tj * nap + b + be * st_j];
+                  const double Xi = K.ap_x(ti, r, b + al * st_i), Xj = K.ap_x(tj, r, b + be * st_j);
                   const double h_j = p->bbox[(size_t)a * 6 + 3 + tj] - p->bbox[(size_t)a * 6 + tj];
-                  if (std::fabs(K.ap_x[ti * nap + q] - Xi) > 8e-16 * (std::fabs(Xi) + h_i) ||
-                      std::fabs(K.ap_x[tj * nap + q] - Xj) > 8e-16 * (std::fabs(Xj) + h_j))
+                  if (std::fabs(K.ap_x(ti, r, q) - Xi) > 8e-16 * (std::fabs(Xi) + h_i) ||
+                      std::fabs(K.ap_x(tj, r, q) - Xj) > 8e-16 * (std::fabs(Xj) + h_j))
                     {
                       bad[r] = 1;
                       return;
                     }
-                  const double wf = w[b + al * st_i] * (w[b + be * st_j] / w00);
-                  if (std::fabs(w[q] - wf) > 1e-13 * wf)
+                  const double wf = w(b + al * st_i) * (w(b + be * st_j) / w00);
+                  if (std::fabs(w(q) - wf) > 1e-13 * wf)
                     {
                       bad[r] = 1;
                       return;
@@ -1015,7 +1071,6 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
     return no("not 3-D FE_DGQ(3) / FE_AggloDGP(3)");
   if ((int)K.own_agg.size() != K.n_owned) // pseudo slots of the exchange variant
     return no("exchange variant");
-  const int64_t nap = (int64_t)K.ap_wself.size();
   const size_t nruns = K.run_ap.size();
   const int maxf = pdh_rows_max_faces();
   // Planes of every run.  An interior face must lie in one plane.  The boundary "face" of a polytope collects ALL its
@@ -1027,7 +1082,6 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
   host_parallel_for(nruns, [&](size_t r) {
     auto no = [&](const char *m) { why_run[r] = m; };
     {
-      const int64_t b = K.run_ap[r];
       const int cnt = K.run_cnt[r];
       if (cnt <= 0)
         return no("empty face");
@@ -1038,18 +1092,18 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
         {
           int c = -1;
           for (int d = 0; d < 3; ++d)
-            if (std::fabs(K.ap_n[d * nap + b + q]) > 0.5)
+            if (std::fabs(K.ap_n(d, r, q)) > 0.5)
               c = d;
           if (c < 0)
             return no("normal not axis-aligned");
-          const double sg = K.ap_n[c * nap + b + q] > 0 ? 1.0 : -1.0;
+          const double sg = K.ap_n(c, r, q) > 0 ? 1.0 : -1.0;
           for (int d = 0; d < 3; ++d)
             {
-              const double nd = K.ap_n[d * nap + b + q];
+              const double nd = K.ap_n(d, r, q);
               if (d == c ? std::fabs(nd - sg) > 1e-14 : std::fabs(nd) > 1e-14)
                 return no("normal not axis-aligned");
             }
-          const double x = K.ap_x[c * nap + b + q];
+          const double x = K.ap_x(c, r, q);
           const double h = p->bbox[(size_t)a * 6 + 3 + c] - p->bbox[(size_t)a * 6 + c];
           size_t k = 0;
           for (; k < planes[r].size(); ++k)
@@ -1072,9 +1126,9 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
       for (int q = 0; q < cnt; ++q)
         for (const Plane &pl : planes[r])
           {
-            const double x = K.ap_x[pl.axis * nap + b + q];
+            const double x = K.ap_x(pl.axis, r, q);
             const double h = p->bbox[(size_t)a * 6 + 3 + pl.axis] - p->bbox[(size_t)a * 6 + pl.axis];
-            const bool mine = K.ap_n[pl.axis * nap + b + q] * pl.sign > 0.5 && std::fabs(x - pl.coord) <= 1e-9 * h;
+            const bool mine = K.ap_n(pl.axis, r, q) * pl.sign > 0.5 && std::fabs(x - pl.coord) <= 1e-9 * h;
             if (mine && std::fabs(x - pl.coord) > 2e-15 * (std::fabs(pl.coord) + h))
               return no("face not planar");
           }
@@ -1190,8 +1244,8 @@ extern "C" int pdh_check_problem(const pdh_problem *p, int32_t row_begin, int32_
     {
       stats[0] = (int64_t)K.n_owned;
       stats[1] = (int64_t)K.it_own.size();
-      stats[2] = (int64_t)K.vq_w.size();
-      stats[3] = (int64_t)K.ap_wself.size();
+      stats[2] = K.n_vq;
+      stats[3] = K.n_ap;
       stats[4] = K.n_values;
       stats[5] = K.n;
       stats[6] = (int64_t)pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
@@ -1220,6 +1274,72 @@ extern "C" int pdh_check_exchange(const pdh_problem *p, int32_t row_begin, int32
   return PDH_OK;
 }
 
+// Own-side face points of every slot (PdhDev::ap_*), built in HBM: the caller's face arrays go up as they are (each face
+// once), k_pack_faces writes one SoA run per (polytope, face) with the sign of the normal, the weights and sigma resolved
+// (tables Packed::pk_*).  The staging copies are released before this returns.
+extern "C" hipError_t pdh_launch_pack_faces(int dim, int64_t nqf, const double *fq_x, const double *fq_n, const double *fq_w,
+                                            const double *fq_w_out, int64_t n_runs, const int64_t *pk_at, const int64_t *pk_fq,
+                                            const int32_t *pk_cnt, const int32_t *pk_flags, const double *pk_sig, int64_t nap,
+                                            double *ap_x, double *ap_n, double *ap_wself, double *ap_wcross, double *ap_sig,
+                                            hipStream_t stream);
+static int pack_faces_on_device(pdh_ctx *ctx, const pdh_problem *p, const Packed &K, PdhDev &D)
+{
+  const int dim = p->dim;
+  const int64_t nap = K.n_ap, nqf = K.nqf_src, nruns = (int64_t)K.pk_at.size();
+  double *out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const size_t out_n[5] = {(size_t)dim * nap, (size_t)dim * nap, (size_t)nap, (size_t)nap, (size_t)nap};
+  for (int k = 0; k < 5; ++k)
+    {
+      void *d = nullptr;
+      PDH_HIP(ctx, hipMalloc(&d, std::max<size_t>(out_n[k], 1) * sizeof(double)));
+      ctx->allocs.push_back(d);
+      out[k] = static_cast<double *>(d);
+    }
+  D.ap_x = out[0], D.ap_n = out[1], D.ap_wself = out[2], D.ap_wcross = out[3], D.ap_sig = out[4];
+  if (nruns == 0 || nap == 0)
+    return PDH_OK;
+  std::vector<void *> tmp;
+  auto stage = [&](const void *h, size_t bytes, const void **dptr) -> hipError_t {
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, std::max<size_t>(bytes, 8));
+    if (e != hipSuccess)
+      return e;
+    tmp.push_back(d);
+    *dptr = d;
+    return bytes ? hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  const void *d_x = nullptr, *d_n = nullptr, *d_w = nullptr, *d_wo = nullptr, *d_at = nullptr, *d_fq = nullptr, *d_cnt = nullptr,
+             *d_fl = nullptr, *d_sg = nullptr;
+  hipError_t e = stage(p->fq_x, (size_t)dim * nqf * sizeof(double), &d_x);
+  if (e == hipSuccess)
+    e = stage(p->fq_n, (size_t)dim * nqf * sizeof(double), &d_n);
+  if (e == hipSuccess)
+    e = stage(p->fq_w, (size_t)nqf * sizeof(double), &d_w);
+  if (e == hipSuccess && p->fq_w_out)
+    e = stage(p->fq_w_out, (size_t)nqf * sizeof(double), &d_wo);
+  if (e == hipSuccess)
+    e = stage(K.pk_at.data(), K.pk_at.size() * sizeof(int64_t), &d_at);
+  if (e == hipSuccess)
+    e = stage(K.pk_fq.data(), K.pk_fq.size() * sizeof(int64_t), &d_fq);
+  if (e == hipSuccess)
+    e = stage(K.pk_cnt.data(), K.pk_cnt.size() * sizeof(int32_t), &d_cnt);
+  if (e == hipSuccess)
+    e = stage(K.pk_flags.data(), K.pk_flags.size() * sizeof(int32_t), &d_fl);
+  if (e == hipSuccess)
+    e = stage(K.pk_sig.data(), K.pk_sig.size() * sizeof(double), &d_sg);
+  if (e == hipSuccess)
+    e = pdh_launch_pack_faces(dim, nqf, (const double *)d_x, (const double *)d_n, (const double *)d_w, (const double *)d_wo, nruns,
+                              (const int64_t *)d_at, (const int64_t *)d_fq, (const int32_t *)d_cnt, (const int32_t *)d_fl,
+                              (const double *)d_sg, nap, out[0], out[1], out[2], out[3], out[4], ctx->stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(ctx->stream);
+  for (void *d : tmp)
+    (void)hipFree(d);
+  if (e != hipSuccess)
+    return fail(ctx, PDH_EDEVICE, std::string("face repack: ") + hipGetErrorString(e));
+  return PDH_OK;
+}
+
 extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end)
 {
   if (!ctx)
@@ -1227,10 +1347,23 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   PDH_HIP(ctx, hipSetDevice(ctx->device));
   PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_problem(ctx);
-  Packed K;
+  // PDH_TRACE_SETUP=1 (diagnostics): wall time of the phases of this call on stderr
+  static const bool trace = getenv("PDH_TRACE_SETUP") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!trace)
+      return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pdh_set_problem] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  lap("wait for the stream, free the old problem");
+  std::unique_ptr<Packed> K_owner(new Packed);
+  Packed &K = *K_owner;
   int rc = pack_problem(ctx, p, row_begin, row_end, K, ctx->exchange_mode);
   if (rc != PDH_OK)
     return rc;
+  lap("validate + repack (host)");
 
   PdhDev &D = ctx->dev;
   std::memset(&D, 0, sizeof(D));
@@ -1250,14 +1383,18 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   PDH_UP(bbox, bbox)
   PDH_UP(K.midx, midx)
   PDH_UP(K.vq_ptr, vq_ptr)
-  PDH_UP(K.vq_x, vq_x)
-  PDH_UP(K.vq_w, vq_w)
+  if ((rc = upload_n(ctx, K.vqx_h, (size_t)p->dim * K.vq_stride_h, &D.vq_x)) != PDH_OK ||
+      (rc = upload_n(ctx, K.vqw_h, (size_t)K.n_vq, &D.vq_w)) != PDH_OK)
+    {
+      free_problem(ctx);
+      return rc;
+    }
   PDH_UP(K.ap_ptr, ap_ptr)
-  PDH_UP(K.ap_x, ap_x)
-  PDH_UP(K.ap_n, ap_n)
-  PDH_UP(K.ap_wself, ap_wself)
-  PDH_UP(K.ap_wcross, ap_wcross)
-  PDH_UP(K.ap_sig, ap_sig)
+  if ((rc = pack_faces_on_device(ctx, p, K, D)) != PDH_OK)
+    {
+      free_problem(ctx);
+      return rc;
+    }
   PDH_UP(K.own_agg, own_agg)
   PDH_UP(K.own_row, own_row)
   PDH_UP(K.row_base, row_base)
@@ -1271,6 +1408,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   PDH_UP(K.it_nbr_slot, it_nbr_slot)
   PDH_UP(K.it_pos_t, it_pos_t)
 #undef PDH_UP
+  lap("upload");
   ctx->problem_ghost = ctx->exchange_mode == PDH_EXCHANGE_GHOST;
   ctx->n_send = K.n_send;
   ctx->n_recv = K.n_recv;
@@ -1288,8 +1426,8 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
           return rc;
         }
     }
-  D.vq_stride = (int64_t)K.vq_w.size();
-  D.ap_stride = (int64_t)K.ap_wself.size();
+  D.vq_stride = K.vq_stride_h;
+  D.ap_stride = K.n_ap;
   void *dv = nullptr;
   // the send region of the ghost-block exchange sits behind the values: the kernels address it like more rows
   hipError_t e = hipMalloc(&dv, std::max<int64_t>(K.n_values + K.n_send, 1) * sizeof(double));
@@ -1304,21 +1442,20 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   ctx->n_owned = K.n_owned;
   ctx->n_diag_slots = (int)K.own_agg.size();
   ctx->n_items = (int)K.it_own.size();
-  ctx->n_vq = (int64_t)K.vq_w.size();
-  ctx->n_ap = (int64_t)K.ap_wself.size();
+  ctx->n_vq = K.n_vq;
+  ctx->n_ap = K.n_ap;
   ctx->NT = K.NT;
   ctx->LB = K.LB;
   ctx->group = combo_group(p->dim, K.n1d, K.NT, K.LB);
   ctx->lds_diag = pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
   ctx->lds_off = pdh::lds_bytes_offdiag(p->dim, K.n1d, K.NT);
+  lap("values allocation");
   ctx->vq_src = K.vq_src;
   {
-    std::vector<int64_t> ap_src(K.ap_wself.size(), -1);
-    for (size_t r = 0; r < K.run_ap.size(); ++r)
-      if (K.run_bdry[r])
-        for (int32_t t = 0; t < K.run_cnt[r]; ++t)
-          ap_src[K.run_ap[r] + t] = K.run_fq[r] + t;
-    if ((rc = upload(ctx, K.vq_src, &ctx->d_vq_src)) != PDH_OK || (rc = upload(ctx, ap_src, &ctx->d_ap_src)) != PDH_OK)
+    // (the per-point map of the packed boundary points to the caller's face points - 8 bytes per packed face point - is
+    // needed by the right-hand side only: built and uploaded at its first call, ensure_ap_src)
+    ctx->d_ap_src = nullptr;
+    if ((rc = upload(ctx, K.vq_src, &ctx->d_vq_src)) != PDH_OK)
       {
         free_problem(ctx);
         return rc;
@@ -1327,8 +1464,10 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
     ctx->n_fq_caller = p->n_faces ? p->fq_ptr[p->n_faces] : 0;
   }
   ctx->face_runs.clear();
+  ctx->face_runs.reserve(K.run_ap.size());
   for (size_t r = 0; r < K.run_ap.size(); ++r)
     ctx->face_runs.push_back({K.run_ap[r], K.run_fq[r], K.run_cnt[r], K.run_bdry[r]});
+  lap("caller-order maps");
   ctx->n_rows_owned = (int64_t)K.n_owned * K.n;
   ctx->n_agg_total = p->n_agg;
   {
@@ -1370,12 +1509,14 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
         }
       ctx->d_mtab = static_cast<double *>(dm);
     }
+  lap("values + tables");
   ctx->rows_ok = false;
   if (ctx->d_mtab && !ctx->problem_ghost)
     {
       RowsHost RH;
       if (build_rows_tables(p, K, RH))
         {
+          lap("row kernel: planes + records");
           PdhRows &R = ctx->rows;
           if ((rc = upload(ctx, RH.fr_ptr, &R.fr_ptr)) != PDH_OK || (rc = upload(ctx, RH.fr_pbeg, &R.fr_pbeg)) != PDH_OK ||
               (rc = upload(ctx, RH.fr_pcnt, &R.fr_pcnt)) != PDH_OK || (rc = upload(ctx, RH.fr_nbr, &R.fr_nbr)) != PDH_OK ||
@@ -1399,13 +1540,17 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
             else
               R.stamps = nullptr;
           }
+          lap("row kernel: upload");
           R.vq_tensor_n = volume_rules_are_tensor(p, K, p->vq_tensor_n) ? p->vq_tensor_n : 0;
           R.fq_tensor_n = RH.fq_tensor_ok ? p->fq_tensor_n : 0;
           ctx->rows_ok = true;
+          lap("row kernel: volume rule check");
         }
     }
   ctx->has_problem = true;
   ctx->ev_used = 0;
+  K_owner.reset();
+  lap("release host staging");
   return PDH_OK;
 }
 
@@ -1678,6 +1823,21 @@ extern "C" int pdh_assemble_sip(pdh_ctx *ctx, const pdh_problem *p, double *valu
 }
 
 // ---- right-hand side -------------------------------------------------------------------------------------------------
+// packed boundary point -> the caller's face point (-1: interior), for the Nitsche datum; once per problem
+static int ensure_ap_src(pdh_ctx *ctx)
+{
+  if (ctx->d_ap_src)
+    return PDH_OK;
+  std::vector<int64_t> ap_src((size_t)std::max<int64_t>(ctx->n_ap, 1), -1);
+  host_parallel_for(ctx->face_runs.size(), [&](size_t r) {
+    const auto &fr = ctx->face_runs[r];
+    if (fr.boundary)
+      for (int32_t t = 0; t < fr.count; ++t)
+        ap_src[fr.ap_begin + t] = fr.fq_begin + t;
+  });
+  return upload(ctx, ap_src, &ctx->d_ap_src);
+}
+
 extern "C" int pdh_assemble_rhs_device(pdh_ctx *ctx, const double *d_f_vol, const double *d_g_bdry, double *d_rhs)
 {
   if (!ctx)
@@ -1687,6 +1847,9 @@ extern "C" int pdh_assemble_rhs_device(pdh_ctx *ctx, const double *d_f_vol, cons
   if (!d_rhs)
     return fail(ctx, PDH_EINVAL, "rhs is NULL");
   PDH_HIP(ctx, hipSetDevice(ctx->device));
+  const int rc_map = ensure_ap_src(ctx);
+  if (rc_map != PDH_OK)
+    return rc_map;
   PDH_HIP(ctx, pdh_launch_rhs(ctx->dev.dim, ctx->dev.n1d, &ctx->dev, ctx->n_owned, d_f_vol, d_g_bdry, d_rhs, ctx->d_vq_src,
                               ctx->d_ap_src, ctx->stream));
   return PDH_OK;

@@ -100,3 +100,56 @@ extern "C" hipError_t pdh_launch_checksum(const double *values, int64_t n, doubl
   hipLaunchKernelGGL(k_checksum, dim3(2048), dim3(256), 0, stream, values, n, d_out4);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Set-up: own-side face points of every (polytope, face) run, written in HBM from the caller's face arrays (each face
+// stored once).  One wave per run.  Weights / signs as the assembly kernels expect them (pdh_capi.cpp: Packed::pk_*):
+//   boundary run: w_self = 2 JxW, sigma / 2, w_cross = 0; interior: w_self = JxW of the own side, w_cross = JxW of side 1,
+//   normal = outward normal of the owning polytope (sign flipped when it is side 1 of the face).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_faces(const int dim, const int64_t nqf, const double *__restrict__ fq_x,
+                                                    const double *__restrict__ fq_n, const double *__restrict__ fq_w,
+                                                    const double *__restrict__ fq_w_out, const int64_t n_runs,
+                                                    const int64_t *__restrict__ pk_at, const int64_t *__restrict__ pk_fq,
+                                                    const int32_t *__restrict__ pk_cnt, const int32_t *__restrict__ pk_flags,
+                                                    const double *__restrict__ pk_sig, const int64_t nap, double *__restrict__ ap_x,
+                                                    double *__restrict__ ap_n, double *__restrict__ ap_wself,
+                                                    double *__restrict__ ap_wcross, double *__restrict__ ap_sig)
+{
+  const int lane = threadIdx.x & (PDH_WAVE - 1);
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x / PDH_WAVE) + (threadIdx.x / PDH_WAVE);
+  if (r >= n_runs)
+    return;
+  const int64_t at = pk_at[r], fq = pk_fq[r];
+  const int cnt = pk_cnt[r], fl = pk_flags[r];
+  const bool side0 = (fl & 1) != 0, bdry = (fl & 2) != 0;
+  const double sig = pk_sig[r], sgn = side0 ? 1.0 : -1.0;
+  for (int t = lane; t < cnt; t += PDH_WAVE)
+    {
+      const int64_t q = fq + t, a = at + t;
+      const double w_in = fq_w[q], w_out = fq_w_out ? fq_w_out[q] : w_in;
+      ap_wself[a] = bdry ? 2.0 * w_in : (side0 ? w_in : w_out);
+      ap_wcross[a] = bdry ? 0.0 : w_out;
+      ap_sig[a] = sig;
+      for (int c = 0; c < dim; ++c)
+        {
+          ap_x[c * nap + a] = fq_x[c * nqf + q];
+          ap_n[c * nap + a] = sgn * fq_n[c * nqf + q];
+        }
+    }
+}
+
+extern "C" hipError_t pdh_launch_pack_faces(int dim, int64_t nqf, const double *fq_x, const double *fq_n, const double *fq_w,
+                                            const double *fq_w_out, int64_t n_runs, const int64_t *pk_at, const int64_t *pk_fq,
+                                            const int32_t *pk_cnt, const int32_t *pk_flags, const double *pk_sig, int64_t nap,
+                                            double *ap_x, double *ap_n, double *ap_wself, double *ap_wcross, double *ap_sig,
+                                            hipStream_t stream)
+{
+  if (n_runs <= 0)
+    return hipSuccess;
+  const int per_block = 256 / PDH_WAVE;
+  const int64_t blocks = (n_runs + per_block - 1) / per_block;
+  hipLaunchKernelGGL(k_pack_faces, dim3((unsigned)blocks), dim3(256), 0, stream, dim, nqf, fq_x, fq_n, fq_w, fq_w_out, n_runs, pk_at,
+                     pk_fq, pk_cnt, pk_flags, pk_sig, nap, ap_x, ap_n, ap_wself, ap_wcross, ap_sig);
+  return hipGetLastError();
+}
