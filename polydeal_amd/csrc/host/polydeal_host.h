@@ -608,10 +608,32 @@ struct SipVariant
 };
 
 // Flattened problem: owns the arrays a pdh_problem points to.
+// std::vector whose resize() leaves new elements uninitialised: the point arrays (about 1 GB on the bench workload) are
+// filled by all host threads right after they are sized; a serial zero-fill in between costs more than the fill.
+template <class T>
+struct UninitAllocator : std::allocator<T>
+{
+  template <class U>
+  struct rebind
+  {
+    using other = UninitAllocator<U>;
+  };
+  template <class U, class... A>
+  void construct(U *ptr, A &&...a)
+  {
+    if constexpr (sizeof...(A) == 0)
+      ::new ((void *)ptr) U;
+    else
+      ::new ((void *)ptr) U(std::forward<A>(a)...);
+  }
+};
+using PointArray = std::vector<double, UninitAllocator<double>>;
+
 struct FlatProblem
 {
   pdh_problem c{};
-  std::vector<double> bbox, vq_x, vq_w, fq_x, fq_n, fq_w, fq_w_out, face_sigma;
+  std::vector<double> bbox, face_sigma;
+  PointArray vq_x, vq_w, fq_x, fq_n, fq_w, fq_w_out;
   std::vector<int32_t> dof_offset, face_in, face_out, colind, col_offset, agg_rank;
   std::vector<int64_t> vq_ptr, fq_ptr, rowptr;
   void bind()
