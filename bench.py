@@ -87,7 +87,7 @@ def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1):
     return grid, ah, fe
 
 
-def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto"):
+def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto", look_for_tensor_rules=True):
     t0 = time.time()
     stack = world if args.scaling == "weak" else 1
     grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1, stack)
@@ -105,6 +105,8 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
         flat = ah.flatten_local(var, r0, r1, diag_first=True, with_colind=False, row_splits=splits)
     else:
         flat = ah.flatten(var, diag_first=True, with_colind=False)
+    if not look_for_tensor_rules:  # general-point paths only (pdh_problem::vq_tensor_n / fq_tensor_n < 0)
+        flat.c.vq_tensor_n = flat.c.fq_tensor_n = -1
     t_flatten = time.time() - t0 - t_handler
     ctx = pa.Context(local_rank)  # first one in the process: HIP runtime + device context creation (not problem set-up)
     t_context = time.time() - t0 - t_handler - t_flatten
@@ -184,7 +186,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     vals = ctx.assemble() if stats["n_values"] <= 64_000_000 else None
     chk = validity
     aux = None
-    if world == 1 and args.aux_kernels and alg == "auto":
+    if world == 1 and args.aux_kernels and alg == "auto" and look_for_tensor_rules:
         try:
             aux = time_aux_kernels(torch, ctx, flat, n, stats)
         except Exception as exc:
@@ -437,6 +439,11 @@ def main():
         # the same workload through the direct (MFMA contraction) form, for the record
         direct = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, max(3, args.steps // 3), 1, alg="direct")
 
+    general = None
+    if main_res["alg"] == "rows" and not args.no_extra and world == 1:
+        # the same workload with the row kernel's general-point paths (no use of the tensor structure of the rules)
+        general = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, max(3, args.steps // 3), 1,
+                          look_for_tensor_rules=False)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
       try:  # a failure of the CPU leg must not discard the GPU measurement already taken
@@ -509,7 +516,15 @@ def main():
                                  "lines; planar axis-aligned faces -> rank-one face moments, Kronecker form C (x) S of the coupling "
                                  "blocks; volume moments + three-stage contraction of the diagonal block on the f64 MFMA",
                     "whole_step_GBs": ke[0]["algorithmic_bytes_per_launch"] / (r["dt"] / args.steps) * 1e-9,
-                    "whole_step_algorithmic_TFLOPs": ke[0]["algorithmic_flops_per_launch"] / (r["dt"] / args.steps) * 1e-12}
+                    "whole_step_algorithmic_TFLOPs": ke[0]["algorithmic_flops_per_launch"] / (r["dt"] / args.steps) * 1e-12,
+                    "quadrature_structure": "tensor rules per sub-cell / sub-face found on the points by pdh_set_problem "
+                                            "(QGauss on a Cartesian background grid): moments in factorised form"}
+            if general is not None:
+                roof["general_points"] = {
+                    "note": "same workload, pdh_problem::vq_tensor_n = fq_tensor_n = -1: quadrature points treated as unstructured "
+                            "(moment GEMMs over the points on the f64 MFMA); algorithm " + general["alg"],
+                    "ms_per_step": 1e3 * general["dt"] / max(3, args.steps // 3), "kernel_ms": general["kms"][0],
+                    "frac": ke[0]["algorithmic_bytes_per_launch"] / max(general["kms"][0] * 1e-3, 1e-9) * 1e-9 / HBM_PEAK_GBS}
         elif moment:
             # The moment form removes ~85 % of the arithmetic of SURVEY 8(d)'s count, so the f64-MFMA roof no longer binds:
             # the roof that remains is the HBM traffic of the values (written once) + quadrature data (read once).

@@ -96,13 +96,14 @@ typedef struct pdh_problem
    * ghost-block exchange variant (pdh_set_exchange_mode), which ships the M21/M22 blocks of the faces cut by the
    * partition to the rank that owns their rows (reference include/poly_utils.h:1930-1992, 2134-2194).             */
   const int32_t *agg_rank;
-  /* Optional hint (0 = nothing assumed): the volume points of every polytope come in consecutive groups of
+  /* Structure of the volume rules.  The volume points of every polytope may come in consecutive groups of
    * vq_tensor_n^dim points, each group a tensor-product rule on an axis-aligned box, first index fastest:
    *   x_(i,j,k) = (X_i, Y_j, Z_k),  JxW_(i,j,k) = a_i b_j c_k        (QGauss<dim>(n) on Cartesian sub-cells,
    *   source/agglomeration_handler.cc:639-653 with MappingCartesian-like cells).
-   * pdh_set_problem VERIFIES this on the points (a few ulp); where it holds for all owned polytopes the row kernel
-   * integrates the volume moments cell by cell in factorised form (3 n sums instead of n^3 points).  A wrong hint is
-   * harmless: the check fails and the general path is taken.                                                      */
+   * > 0: a claim, which pdh_set_problem VERIFIES on the points (a few ulp); 0: pdh_set_problem finds out by itself
+   * (n = 8 .. 2 are tried; a candidate that does not hold fails on the first group); < 0: do not look.  Where the
+   * structure holds for all owned polytopes the row kernel integrates the volume moments cell by cell in factorised form
+   * (3 n sums instead of n^3 points).  A wrong claim is harmless: the check fails and the general path is taken.   */
   int32_t vq_tensor_n;
   /* The same for the face points: groups of fq_tensor_n^(dim-1) points, each a tensor rule on an axis-aligned rectangle
    * (either tangential direction may run fastest).  Verified on the points like vq_tensor_n.                        */

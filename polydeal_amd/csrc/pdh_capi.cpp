@@ -1050,18 +1050,35 @@ static bool face_rules_are_tensor(const pdh_problem *p, const Packed &K, int n, 
   return true;
 }
 
+// pdh_problem::vq_tensor_n / fq_tensor_n: > 0 a claim to verify, 0 find out (2 .. 8 points per direction are tried, largest
+// first: a wrong candidate fails on the first group of points), < 0 do not look
+template <class Check>
+static int resolve_tensor_hint(int hint, Check &&holds)
+{
+  if (hint > 0)
+    return holds(hint) ? hint : 0;
+  if (hint < 0)
+    return 0;
+  for (int n = 8; n >= 2; --n)
+    if (holds(n))
+      return n;
+  return 0;
+}
+
 struct RowsHost
 {
   std::vector<int32_t> fr_ptr, fr_pcnt, fr_nbr, fr_axis, fr_blk, fr_flags;
   std::vector<int64_t> fr_pbeg;
   std::vector<double> fr_coord, fr_sigma, fr_nsign;
   std::vector<double> meta; // per-slot records of the kernel (pdh_rows.h: ROWS_REC doubles each)
-  bool fq_tensor_ok = false;
+  int fq_tensor_n = 0; // verified (or detected) points per direction of the sub-face rules, 0: none
 };
 static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R, std::string *why = nullptr)
 {
   std::vector<signed char> fast_j;
-  R.fq_tensor_ok = face_rules_are_tensor(p, K, p->fq_tensor_n, fast_j);
+  R.fq_tensor_n = resolve_tensor_hint(p->fq_tensor_n, [&](int n) { return face_rules_are_tensor(p, K, n, fast_j); });
+  if (R.fq_tensor_n == 0)
+    fast_j.clear();
   auto no = [&](const char *m) {
     if (why)
       *why = m;
@@ -1155,7 +1172,7 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
             R.fr_nbr.push_back(K.run_nbr[t]);
             R.fr_axis.push_back(pl.axis);
             R.fr_blk.push_back(K.run_blk[t]);
-            R.fr_flags.push_back((planes[t].size() > 1 ? 1 : 0) | ((R.fq_tensor_ok && fast_j[3 * t + pl.axis] == 1) ? 2 : 0));
+            R.fr_flags.push_back((planes[t].size() > 1 ? 1 : 0) | ((R.fq_tensor_n > 0 && fast_j[3 * t + pl.axis] == 1) ? 2 : 0));
             R.fr_coord.push_back(pl.coord);
             R.fr_sigma.push_back(K.run_sig[t]);
             R.fr_nsign.push_back(pl.sign);
@@ -1541,8 +1558,8 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
               R.stamps = nullptr;
           }
           lap("row kernel: upload");
-          R.vq_tensor_n = volume_rules_are_tensor(p, K, p->vq_tensor_n) ? p->vq_tensor_n : 0;
-          R.fq_tensor_n = RH.fq_tensor_ok ? p->fq_tensor_n : 0;
+          R.vq_tensor_n = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
+          R.fq_tensor_n = RH.fq_tensor_n;
           ctx->rows_ok = true;
           lap("row kernel: volume rule check");
         }

@@ -1022,24 +1022,28 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world, basis):
     kw = flatten(ah, var, diag_first=diag_first)
     ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
     sc = np.max(np.abs(ref))
-    vr, used = _values(kw, "rows")
+    # general-point paths (tensor structure of the rules neither claimed nor looked for)
+    vr, used = _values(dict(kw, vq_tensor_n=-1, fq_tensor_n=-1), "rows")
     assert used == "rows"
     assert np.max(np.abs(vr - ref)) <= TOL * sc, np.max(np.abs(vr - ref)) / sc
-    # with the hint that the volume points are tensor rules of 4^3 points per sub-cell (verified by the library): the
+    # with the claim that the volume points are tensor rules of 4^3 points per sub-cell (verified by the library): the
     # volume moments are then integrated cell by cell in factorised form
-    vt, used_t = _values(dict(kw, vq_tensor_n=4), "rows")
+    vt, used_t = _values(dict(kw, vq_tensor_n=4, fq_tensor_n=-1), "rows")
     assert used_t == "rows"
     assert np.max(np.abs(vt - ref)) <= TOL * sc, np.max(np.abs(vt - ref)) / sc
     assert np.max(np.abs(vt - vr)) > 0.0  # really another path
     # ... and the same for the sub-face rules (4^2 points each), alone and together with the volume hint
-    for hint in (dict(fq_tensor_n=4), dict(fq_tensor_n=4, vq_tensor_n=4)):
+    for hint in (dict(fq_tensor_n=4, vq_tensor_n=-1), dict(fq_tensor_n=4, vq_tensor_n=4)):
         vf, used_f = _values(dict(kw, **hint), "rows")
         assert used_f == "rows"
         assert np.max(np.abs(vf - ref)) <= TOL * sc, (hint, np.max(np.abs(vf - ref)) / sc)
         assert np.max(np.abs(vf - vr)) > 0.0
-    # a wrong hint must be harmless (the check on the points fails, the general path is taken)
+    # a wrong claim must be harmless (the check on the points fails, the general path is taken)
     vw, _ = _values(dict(kw, vq_tensor_n=2, fq_tensor_n=2), "rows")
     assert np.array_equal(vw, vr)
+    # no claim at all (0): the library finds the structure itself - bit-identical to the verified claim
+    v0, used_0 = _values(kw, "rows")
+    assert used_0 == "rows" and np.array_equal(v0, vf)
     vm, used_m = _values(kw, "moment" if basis == "dgq" else "direct")
     assert used_m == ("moment" if basis == "dgq" else "direct") and np.max(np.abs(vr - vm)) <= 1e-13 * sc
     # per block, not only against the global maximum
