@@ -77,6 +77,7 @@ extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_
 extern "C" hipError_t pdh_launch_moment(int n1d, int which, const PdhDev *P, const double *mtab, int count, hipStream_t stream);
 #include "pdh_rows_tables.h"
 extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const double *mtab, int count, hipStream_t stream);
+extern "C" int pdh_rows_n_dofs(int n1d, int basis);
 extern "C" int pdh_rows_max_faces(void);
 extern "C" int pdh_moment_table_doubles(int n1d);
 
@@ -1084,8 +1085,8 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
       *why = m;
     return false;
   };
-  if (p->dim != 3 || p->degree != 3 || !((p->basis == PDH_BASIS_DGQ && K.n == 64) || (p->basis == PDH_BASIS_AGGLODGP && K.n == 20)))
-    return no("not 3-D FE_DGQ(3) / FE_AggloDGP(3)");
+  if (p->dim != 3 || p->degree < 1 || p->degree > 3 || K.n != pdh_rows_n_dofs(p->degree + 1, p->basis == PDH_BASIS_AGGLODGP ? 1 : 0))
+    return no("not 3-D FE_DGQ / FE_AggloDGP of degree 1 .. 3");
   if ((int)K.own_agg.size() != K.n_owned) // pseudo slots of the exchange variant
     return no("exchange variant");
   const size_t nruns = K.run_ap.size();
@@ -1233,6 +1234,23 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
   return true;
 }
 
+// Second half of the eligibility test: structure of the volume rules (vq_n), and - every kind but FE_DGQ(3) has no
+// general-point paths - tensor rules everywhere and no face entry with more sub-faces than the 64 lane tasks of a batch
+// hold (pdh_rows.h, P2).
+static bool rows_kind_applies(const pdh_problem *p, const Packed &K, const RowsHost &RH, int &vq_n, std::string *why = nullptr)
+{
+  vq_n = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
+  if (K.n1d == 4 && p->basis == PDH_BASIS_DGQ)
+    return true;
+  bool ok = vq_n > 0 && RH.fq_tensor_n > 0;
+  const int64_t m = (int64_t)RH.fq_tensor_n * RH.fq_tensor_n;
+  for (size_t f = 0; ok && f < RH.fr_pcnt.size(); ++f)
+    ok = RH.fr_pcnt[f] / m <= 32;
+  if (!ok && why)
+    *why = "this element takes the row kernel only with tensor-product rules on every sub-cell and sub-face";
+  return ok;
+}
+
 // Host-only: 1 if the row kernel (PDH_ALG_ROWS) applies to this description and row range, 0 if not (pdh_last_error(NULL)
 // says why), < 0 on an invalid description.
 extern "C" int pdh_check_rows(const pdh_problem *p, int32_t row_begin, int32_t row_end)
@@ -1244,7 +1262,8 @@ extern "C" int pdh_check_rows(const pdh_problem *p, int32_t row_begin, int32_t r
     return rc;
   RowsHost R;
   std::string why;
-  if (build_rows_tables(p, K, R, &why))
+  int vq_n = 0;
+  if (build_rows_tables(p, K, R, &why) && rows_kind_applies(p, K, R, vq_n, &why))
     return 1;
   g_err_noctx = why;
   return 0;
@@ -1558,9 +1577,11 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
               R.stamps = nullptr;
           }
           lap("row kernel: upload");
-          R.vq_tensor_n = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
+          int vq_n = 0;
+          const bool ok = rows_kind_applies(p, K, RH, vq_n);
+          R.vq_tensor_n = vq_n;
           R.fq_tensor_n = RH.fq_tensor_n;
-          ctx->rows_ok = true;
+          ctx->rows_ok = ok;
           lap("row kernel: volume rule check");
         }
     }

@@ -69,15 +69,51 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
     const char *e = getenv("PDH_ROWS_WAVES_PER_CU");
     return e ? atoi(e) : 0;
   }();
-  const bool dgp = P->n == pdhr::DGP_N; // FE_AggloDGP(3): 26 KB of LDS per wave = 6 per CU
-  const int per_cu = per_cu_env > 0 ? per_cu_env : (dgp ? 6 : 8);
-  const int resident = cus * per_cu;
-  const unsigned grid = (unsigned)(count < resident ? count : resident);
-  constexpr size_t lds_q = pdhr::lds_doubles_rows<4, 0>() * sizeof(double), lds_p = pdhr::lds_doubles_rows<4, 1>() * sizeof(double);
-  if (dgp)
-    hipLaunchKernelGGL((pdhr::k_rows<4, 1>), dim3(grid), dim3(PDH_WAVE), lds_p + pad, stream, *P, *R, mtab, count);
-  else
-    hipLaunchKernelGGL((pdhr::k_rows<4, 0>), dim3(grid), dim3(PDH_WAVE), lds_q + pad, stream, *P, *R, mtab, count);
-  return hipGetLastError();
+  // kinds of the kernel (pdh_rows.h: RowsKind): FE_DGQ(3) is the row-piece kernel, the others stream their rows
+  const int full = P->n1d * P->n1d * P->n1d;
+  const int basis = P->n == full ? 0 : 1;
+  hipError_t rc = hipErrorInvalidValue;
+  auto launch = [&](auto n1d_, auto basis_) {
+    constexpr int N = decltype(n1d_)::value, B = decltype(basis_)::value;
+    if (P->n != pdhr::RowsKind<N, B>::NF)
+      return;
+    constexpr size_t lds = pdhr::lds_doubles_rows<N, B>() * sizeof(double);
+    // resident single-wave workgroups per CU: by LDS (160 KB, handed out in granules of 1280 bytes - measured: 26 624 bytes
+    // fit six times, 27 136 do not), at most 8 (two waves per SIMD at 256 VGPRs)
+    constexpr size_t granules = (lds + 1279) / 1280 * 1280;
+    constexpr int fit = (int)(160 * 1024 / granules) < 8 ? (int)(160 * 1024 / granules) : 8;
+    const int per_cu = per_cu_env > 0 ? per_cu_env : fit;
+    const int resident = cus * per_cu;
+    const unsigned grid = (unsigned)(count < resident ? count : resident);
+    hipLaunchKernelGGL((pdhr::k_rows<N, B>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
+    rc = hipGetLastError();
+  };
+  using std::integral_constant;
+  if (P->n1d == 4 && basis == 0)
+    launch(integral_constant<int, 4>{}, integral_constant<int, 0>{});
+  else if (P->n1d == 4)
+    launch(integral_constant<int, 4>{}, integral_constant<int, 1>{});
+  else if (P->n1d == 3 && basis == 0)
+    launch(integral_constant<int, 3>{}, integral_constant<int, 0>{});
+  else if (P->n1d == 3)
+    launch(integral_constant<int, 3>{}, integral_constant<int, 1>{});
+  else if (P->n1d == 2 && basis == 0)
+    launch(integral_constant<int, 2>{}, integral_constant<int, 0>{});
+  else if (P->n1d == 2)
+    launch(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+  return rc;
+}
+extern "C" int pdh_rows_n_dofs(int n1d, int basis)
+{
+  switch (n1d * 2 + (basis ? 1 : 0))
+    {
+    case 8: return pdhr::RowsKind<4, 0>::NF;
+    case 9: return pdhr::RowsKind<4, 1>::NF;
+    case 6: return pdhr::RowsKind<3, 0>::NF;
+    case 7: return pdhr::RowsKind<3, 1>::NF;
+    case 4: return pdhr::RowsKind<2, 0>::NF;
+    case 5: return pdhr::RowsKind<2, 1>::NF;
+    }
+  return 0;
 }
 extern "C" int pdh_rows_max_faces(void) { return pdhr::MAXF; }

@@ -68,38 +68,69 @@ constexpr int FREC = 33; // face record: L_i[8], (s_t L_j)[3][8], pad (odd strid
 constexpr int FCH = 32;  // face points per chunk
 constexpr int FSTEP = 4 * FREC * 8;
 
-// FE_AggloDGP(3) variant (BASIS = 1): n = 20 functions L_k0 L_k1 L_k2, k0 + k1 + k2 <= 3 (pdh_basis.h: multi_indices)
-constexpr int DGP_N = 20;
-constexpr int DGP_SS = 104; // per-face slot: first the 8x8 coupling moments, later the compact 10x10 matrix S
-__host__ __device__ constexpr int dgp_pair(int ka, int kb) { return kb * 4 - kb * (kb - 1) / 2 + ka; } // ka + kb <= 3 -> 0..9
-__device__ __forceinline__ int dgp_index(int k0, int k1, int k2)
+// Kinds of the kernel.  (N1D, BASIS) = (4, 0) - FE_DGQ(3), n = 64 - is the row-piece kernel described above.  Every other
+// kind (FE_DGQ(1,2), FE_AggloDGP(1..3)) is the "streamed" variant: its n rows are one contiguous range of n * rlen values
+// that is written front to back (P4 / P5 below), and it exists for verified tensor rules only (no general-point paths).
+// BASIS = 0: all (k0,k1,k2) < N1D; BASIS = 1: k0 + k1 + k2 <= p (pdh_basis.h: multi_indices; x index fastest in both).
+template <int N1D, int BASIS>
+struct RowsKind
 {
-  const int zoff = k2 == 0 ? 0 : (k2 == 1 ? 10 : (k2 == 2 ? 16 : 19));
-  const int nn = 4 - k2;
-  return zoff + k1 * nn - k1 * (k1 - 1) / 2 + k0;
-}
+  static constexpr bool SMALL = !(N1D == 4 && BASIS == 0);
+  static constexpr int NA = 2 * N1D - 1;
+  static constexpr int NF = BASIS == 0 ? N1D * N1D * N1D : N1D * (N1D + 1) * (N1D + 2) / 6; // functions
+  static constexpr int NS = BASIS == 0 ? N1D * N1D : N1D * (N1D + 1) / 2;                   // pairs of tangential digits
+  static constexpr int SS = SMALL ? ((NS * NS > 64 ? NS * NS : 64) + 7) / 8 * 8 : 64; // per-face slot: 8x8 moments, later S
+  static constexpr int NC = N1D * NS;                                                  // stage-2 work items per a0 (upper bound)
+  static constexpr int T1 = 4 * N1D * NA * NA, T2 = 3 * NC * NA;                       // stage buffers of the diagonal block
+  // index of the digit pair (ka, kb) among the pairs that occur
+  __host__ __device__ static constexpr int pair(int ka, int kb) { return BASIS == 0 ? ka + N1D * kb : kb * N1D - kb * (kb - 1) / 2 + ka; }
+  // number of the function with digits (k0, k1, k2)
+  __device__ __forceinline__ static int findex(int k0, int k1, int k2)
+  {
+    if constexpr (BASIS == 0)
+      return k0 + N1D * (k1 + N1D * k2);
+    else
+      {
+        int zoff = 0;
+        for (int z = 0; z < k2; ++z)
+          zoff += (N1D - z) * (N1D - z + 1) / 2;
+        const int nn = N1D - k2;
+        return zoff + k1 * nn - k1 * (k1 - 1) / 2 + k0;
+      }
+  }
+};
 
-constexpr int DGP_T1 = 4 * 4 * 49, DGP_T2 = 3 * 40 * 7; // stage buffers of the FE_AggloDGP diagonal block (P4)
 template <int N1D, int BASIS = 0>
 constexpr int w_doubles_rows()
 {
   using A = pdhm::MomentAcc<N1D>;
-  constexpr int w_rec = A::VCH * A::VREC > FCH * FREC ? A::VCH * A::VREC : FCH * FREC;
-  constexpr int w_con = BASIS == 0 ? 4 * 2 * 2 * 64 + 2 * 4 * 64 + 64 /* T1B + T2B + carry of the own piece */
-                                   : (DGP_T1 + DGP_T2 + 63) / 64 * 64;
-  return w_rec > w_con ? w_rec : w_con;
+  using K = RowsKind<N1D, BASIS>;
+  using M = pdhm::MT<N1D>;
+  if constexpr (!K::SMALL)
+    {
+      constexpr int w_rec = A::VCH * A::VREC > FCH * FREC ? A::VCH * A::VREC : FCH * FREC;
+      constexpr int w_con = 4 * 2 * 2 * 64 + 2 * 4 * 64 + 64; // T1B + T2B + carry of the own piece
+      return w_rec > w_con ? w_rec : w_con;
+    }
+  else
+    {
+      // task vectors of P2 [64][16]; S / C scratch (two tables + T); stage buffers of the diagonal block
+      constexpr int w_s = 2 * M::LTAB + 128, w_d = (K::T1 + K::T2 + 63) / 64 * 64;
+      constexpr int w0 = w_s > 1024 ? w_s : 1024;
+      return w0 > w_d ? w0 : w_d;
+    }
 }
 template <int N1D, int BASIS = 0>
 constexpr int lds_doubles_rows()
 {
   using M = pdhm::MT<N1D>;
+  using K = RowsKind<N1D, BASIS>;
   constexpr int w = w_doubles_rows<N1D, BASIS>();
-  constexpr int slot = BASIS == 0 ? 64 : DGP_SS;
-  // BASIS = 1 adds: C of every interior face [MAXF][16], the diagonal block [20][20], digit table [3][20] ints
-  constexpr int extra = BASIS == 0 ? 0 : MAXF * 16 + DGP_N * DGP_N + 32;
-  // (160 KB of LDS per CU hold 6 waves of the FE_AggloDGP variant only up to 26 624 bytes each - measured: 512 bytes more
+  // streamed kinds add: C of every interior face [MAXF][16], the diagonal block [n][n], digit table [3][n] ints
+  constexpr int extra = !K::SMALL ? 0 : MAXF * 16 + K::NF * K::NF + (3 * K::NF + 1) / 2 + 1;
+  // (160 KB of LDS per CU hold 6 waves of the FE_AggloDGP(3) kind only up to 26 624 bytes each - measured: 512 bytes more
   // and the sixth workgroup of a CU waits for a second round)
-  return 3 * M::LTAB + MAXF * slot + (BASIS == 0 ? 64 : 0) /* diagv */ + 16 /* C */ + 16 /* coef */ + w + extra;
+  return 3 * M::LTAB + MAXF * K::SS + (!K::SMALL ? 64 : 0) /* diagv */ + 16 /* C */ + 16 /* coef */ + w + extra;
 }
 
 // multi-index digits of a function index i = k0 + 4 k1 + 16 k2: digit of axis c, and u = k_i + 4 k_j of the other two (i < j)
@@ -113,8 +144,11 @@ __device__ __forceinline__ int digits_t(int i, int c)
 template <int N1D, int BASIS = 0>
 __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhRows Rw, const double *__restrict__ mt, const int n_owned)
 {
-  static_assert(N1D == 4, "the row kernel is written for degree 3");
-  constexpr int MS = BASIS == 0 ? 64 : DGP_SS; // doubles per interior-face slot
+  static_assert(N1D >= 2 && N1D <= 4, "the row kernel is written for degree 1 .. 3");
+  using RK = RowsKind<N1D, BASIS>;
+  constexpr bool SMALL = RK::SMALL;
+  constexpr int MS = RK::SS; // doubles per interior-face slot
+  constexpr int NF = RK::NF, NS = RK::NS;
   using M = pdhm::MT<N1D>;
   using Acc = pdhm::MomentAcc<N1D>;
   constexpr int NA = M::NA, NAP = M::NAP, NG = M::NG, DIM = 3;
@@ -125,28 +159,28 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double *tabE = lds, *tabD = lds + M::LTAB, *tabF = lds + 2 * M::LTAB;
   double *M2c = lds + 3 * M::LTAB;  // [MAXF][8][8] coupling moments of every interior face
   double *diagv = M2c + MAXF * MS;  // [64] diagonal entries A[R,R]
-  double *Cbuf = diagv + (BASIS == 0 ? 64 : 0); // [4][4]  (FE_AggloDGP has no diagv)
+  double *Cbuf = diagv + (!SMALL ? 64 : 0); // [4][4]  (the streamed kinds have no diagv)
   double *coefL = Cbuf + 16;        // [4][4] monomial coefficients of the 1-D basis (centred variable)
   double *W = coefL + 16;           // phase-local
-  // FE_AggloDGP only: behind W
+  // streamed kinds only: behind W
   double *Call = W + w_doubles_rows<N1D, BASIS>(); // [MAXF][4][4] C of every interior face
-  double *Dblk = Call + MAXF * 16;          // [20][20] diagonal block
-  int *dig = reinterpret_cast<int *>(Dblk + DGP_N * DGP_N); // [3 axes][20]: k_c | pair index of the other two digits << 4
-  if constexpr (BASIS == 1)
-    if (lane < DGP_N)
+  double *Dblk = Call + MAXF * 16;          // [n][n] diagonal block
+  int *dig = reinterpret_cast<int *>(Dblk + NF * NF); // [3 axes][n]: k_c | index of the pair of the other two digits << 4
+  if constexpr (SMALL)
+    if (lane < NF)
       {
         int k0 = 0, k1 = 0, k2 = 0, cnt = 0;
-        for (int iz = 0; iz < 4; ++iz)
-          for (int iy = 0; iy < 4 - iz; ++iy)
-            for (int ix = 0; ix < 4 - iy - iz; ++ix)
+        for (int iz = 0; iz < N1D; ++iz)
+          for (int iy = 0; iy < (BASIS == 0 ? N1D : N1D - iz); ++iy)
+            for (int ix = 0; ix < (BASIS == 0 ? N1D : N1D - iy - iz); ++ix)
               {
                 if (cnt == lane)
                   k0 = ix, k1 = iy, k2 = iz;
                 ++cnt;
               }
-        dig[0 * DGP_N + lane] = k0 | (dgp_pair(k1, k2) << 4);
-        dig[1 * DGP_N + lane] = k1 | (dgp_pair(k0, k2) << 4);
-        dig[2 * DGP_N + lane] = k2 | (dgp_pair(k0, k1) << 4);
+        dig[0 * NF + lane] = k0 | (RK::pair(k1, k2) << 4);
+        dig[1 * NF + lane] = k1 | (RK::pair(k0, k2) << 4);
+        dig[2 * NF + lane] = k2 | (RK::pair(k0, k1) << 4);
       }
   for (int t = lane; t < 3 * M::TAB; t += PDH_WAVE)
     lds[(t / NAP) * M::RS + t % NAP] = mt[t];
@@ -200,7 +234,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   const int rlen = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 8));
   const int L = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 9));
   const int64_t vq_b = __double_as_longlong(rl_d(cur.e[0], 16 + 10)), vq_e = __double_as_longlong(rl_d(cur.e[0], 16 + 11));
-  const int m0 = BASIS == 0 ? (L >> 6) : L / DGP_N;
+  const int m0 = !SMALL ? (L >> 6) : L / NF;
   // the face table of the polytope lives in the lanes (lane t = face t); a face's entries are read with v_readlane
   const long long pb_ = __double_as_longlong(cur.e[0]);
   const int t_pblo = (int)(uint32_t)pb_, t_pbhi = (int)(pb_ >> 32);
@@ -217,11 +251,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     ++n_bdry;
   // (general volume path only: MFMA accumulators and operand addresses; dead registers in the tensor path)
   pdhm::MomentAcc<N1D> ma;
-  if (Rw.vq_tensor_n == 0)
-    {
-      ma.init(lane);
-      ma.init_addr(W, lane);
-    }
+  if constexpr (N1D == 4) // (the other kinds exist for verified tensor rules only)
+    if (Rw.vq_tensor_n == 0)
+      {
+        ma.init(lane);
+        ma.init_addr(W, lane);
+      }
 
   PDHR_MARK(1);
   // ================= P1: volume moments ========================================================================
@@ -292,7 +327,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         }
       PDH_WAVE_SYNC();
     }
-  else
+  else if constexpr (N1D == 4)
   {
     // point data two chunks ahead, in two statically addressed register sets (see P2 on why no copies)
     const int64_t qb = vq_b, qe = vq_e;
@@ -655,7 +690,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           }
 #endif
       }
-    else
+    else if constexpr (N1D == 4)
 #if PDHR_EXP == 3
     if (nfaces > 0 && P.n < 0)
 #else
@@ -900,21 +935,27 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               for (int a = 0; a < NA; ++a)
                 e[a] += vv * mt[M::OFF_GL + a * NG + gq];
             }
-          double *te = tabQ + dd * M::LTAB + (k * 4 + l) * M::RS;
-          for (int a = 0; a < NA; ++a)
-            te[a] = e[a];
-          te[NA] = 0.0;
+          if (k < N1D && l < N1D)
+            {
+              double *te = tabQ + dd * M::LTAB + (k * N1D + l) * M::RS;
+              for (int a = 0; a < NA; ++a)
+                te[a] = e[a];
+              te[NA] = 0.0;
+            }
         }
       PDH_WAVE_SYNC();
     }
     const double *EQi = same[0] ? tabE : tabQ, *EQj = same[1] ? tabE : (tabQ + M::LTAB);
     {
       // T[(k_j,l_j)][alpha] = sum_beta EQj[(k_j,l_j)][beta] M2c[alpha][beta]
+      // (lanes are grouped by 16 = 4 x 4 digit pairs whatever N1D is; pairs with a digit >= N1D are idle)
       const int pair = lane & 15;
+      const int kj_ = pair >> 2, lj_ = pair & 3;
+      const int pairT = (kj_ < N1D && lj_ < N1D) ? kj_ * N1D + lj_ : 0;
       const double *m2 = M2c + fl * MS;
       double ej[NA];
       for (int b = 0; b < NA; ++b)
-        ej[b] = EQj[pair * M::RS + b];
+        ej[b] = EQj[pairT * M::RS + b];
       static_for<0, 2>([&](auto h_) {
         constexpr int h = h_;
         const int al = (lane >> 4) + 4 * h;
@@ -931,19 +972,25 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     {
       // S[k_i + 4 k_j][l_i + 4 l_j] = sum_alpha EQi[(k_i,l_i)][alpha] T[(k_j,l_j)][alpha]
       const int pairI = lane & 15, ki = pairI >> 2, li = pairI & 3;
+      const int pairIT = (ki < N1D && li < N1D) ? ki * N1D + li : 0;
       double ei[NA];
       for (int a = 0; a < NA; ++a)
-        ei[a] = EQi[pairI * M::RS + a];
+        ei[a] = EQi[pairIT * M::RS + a];
       static_for<0, 4>([&](auto r_) {
         constexpr int r = r_;
         const int pairJ = (lane >> 4) + 4 * r, kj = pairJ >> 2, lj = pairJ & 3;
         double s = 0.0;
         for (int a = 0; a < NA; ++a)
           s += ei[a] * Tst[pairJ * 8 + a];
-        if constexpr (BASIS == 0)
+        if constexpr (!SMALL)
           Sbuf[(ki + 4 * kj) * 16 + li + 4 * lj] = s;
-        else if (ki + kj <= 3 && li + lj <= 3) // compact S over the face's moment slot (read for the last time in the T stage)
-          M2c[fl * MS + dgp_pair(ki, kj) * 10 + dgp_pair(li, lj)] = s;
+        else
+          { // compact S over the face's moment slot (read for the last time in the T stage)
+            const bool okk = ki < N1D && kj < N1D && (BASIS == 0 || ki + kj < N1D);
+            const bool okl = li < N1D && lj < N1D && (BASIS == 0 || li + lj < N1D);
+            if (okk && okl)
+              M2c[fl * MS + RK::pair(ki, kj) * NS + RK::pair(li, lj)] = s;
+          }
       });
     }
     if (lane < 16)
@@ -964,7 +1011,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           }
         const double sg = rl_d(t_nsign, t), sig = rl_d(t_sigma, t);
         const double cv = (0.5 * sg * dk * ih_c - sig * vk) * vl - 0.5 * sg * vk * dl * ihq_c;
-        if constexpr (BASIS == 0)
+        if constexpr (!SMALL)
           Cbuf[lane] = cv;
         else
           Call[fl * 16 + lane] = cv;
@@ -977,8 +1024,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   // ================= P3: carry into the own block's piece ==========================================================
   const bool shifted = P.diag_first != 0;
   double carry_own = 0.0;
-  if constexpr (BASIS == 1)
-    { // FE_AggloDGP: S and C of every interior face now (P4 takes W over), kept until the rows are streamed out
+  if constexpr (SMALL)
+    { // streamed kinds: S and C of every interior face now (P4 takes W over), kept until the rows are streamed out
       for (int t = n_bdry; t < nfaces; ++t)
         {
           PDH_WAVE_SYNC();
@@ -997,6 +1044,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   PDHR_MARK(4);
   // ================= P4: diagonal block ============================================================================
   PDH_WAVE_SYNC();
+  if constexpr (N1D == 4)
   if (tn == 0)
   {
   {
@@ -1024,32 +1072,33 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   if (P.reaction_c != 0.0)
     for (int a = 0; a < NA; ++a)
       accS[a] += P.reaction_c * accM[a];
-  if constexpr (BASIS == 1)
+  if constexpr (SMALL)
     {
-      // FE_AggloDGP: 20 x 20 entries - the same three-stage sum factorisation on the VALU, restricted to total degree <= 3
-      // on both sides, slab by slab over k2.  Stage 1 (a2, in registers) -> T1[g1 | ee | n0 | n1][l2][a0,a1]; stage 2 (a1):
+      // streamed kinds: n x n entries - the same three-stage sum factorisation on the VALU, restricted to the index set of the
+      // basis on both sides, slab by slab over k2.  Stage 1 (a2, in registers) -> T1[g1 | ee | n0 | n1][l2][a0,a1]; stage 2 (a1):
       // work items (k1, (l1,l2), a0) -> T2[X = D | E | Fs][k1][(l1,l2)][a0] with the h factors folded in; stage 3 (a0):
       // work items (row (k0,k1), column j) -> the LDS copy of the block.
-      double *T1 = W, *T2 = W + DGP_T1;
+      double *T1 = W, *T2 = W + RK::T1;
+      constexpr int NA2 = NA * NA, NC = RK::NC;
       const double s00 = ih0 * ih0, s11 = ih1 * ih1, s22 = ih2 * ih2;
 #ifdef PDHR_STAMP
       long long tp1 = 0, tp2 = 0, tp3 = 0;
 #endif
 #pragma unroll 1
 #if PDHR_EXP == 2
-      for (int k2 = 0; k2 < 4 && P.n < 0; ++k2)
+      for (int k2 = 0; k2 < N1D && P.n < 0; ++k2)
 #else
-      for (int k2 = 0; k2 < 4; ++k2)
+      for (int k2 = 0; k2 < N1D; ++k2)
 #endif
         {
           PDH_WAVE_SYNC();
           PDHR_T0();
           if (act)
-            static_for<0, 4>([&](auto ll_) {
+            static_for<0, N1D>([&](auto ll_) {
               constexpr int ll = ll_;
               // (uniform table rows: scalar loads from the global table, not LDS broadcasts)
-              const double *tE = mt + M::OFF_E + (k2 * 4 + ll) * NAP, *tD = mt + M::OFF_D + (k2 * 4 + ll) * NAP,
-                           *tF = mt + M::OFF_FS + (k2 * 4 + ll) * NAP;
+              const double *tE = mt + M::OFF_E + (k2 * N1D + ll) * NAP, *tD = mt + M::OFF_D + (k2 * N1D + ll) * NAP,
+                           *tF = mt + M::OFF_FS + (k2 * N1D + ll) * NAP;
               double g1 = 0.0, eD = 0.0, eE = 0.0, eF = 0.0, n0 = 0.0, n1 = 0.0;
               static_for<0, NA>([&](auto a_) {
                 constexpr int a = a_;
@@ -1061,23 +1110,31 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 n0 += e * accN[0][a];
                 n1 += e * accN[1][a];
               });
-              T1[(0 * 4 + ll) * 49 + lane] = g1;
-              T1[(1 * 4 + ll) * 49 + lane] = s22 * eD + eE + ih2 * eF;
-              T1[(2 * 4 + ll) * 49 + lane] = n0;
-              T1[(3 * 4 + ll) * 49 + lane] = n1;
+              T1[(0 * N1D + ll) * NA2 + lane] = g1;
+              T1[(1 * N1D + ll) * NA2 + lane] = s22 * eD + eE + ih2 * eF;
+              T1[(2 * N1D + ll) * NA2 + lane] = n0;
+              T1[(3 * N1D + ll) * NA2 + lane] = n1;
             });
           PDH_WAVE_SYNC();
           PDHR_ACC(tp1);
-          const int nk1 = 4 - k2;
+          const int nk1 = BASIS == 0 ? N1D : N1D - k2; // values of k1 (and, below, rows (k0, k1)) of this slab
           const long long t1_ = (long long)__builtin_readcyclecounter();
-          for (int q = lane; q < nk1 * 70; q += 64)
+          for (int q = lane; q < nk1 * NS * NA; q += 64)
             {
-              const int cc = q / 7, a0_ = q - 7 * cc;
-              const int k1 = cc / 10, lp = cc - 10 * k1;
-              const int l2 = lp < 4 ? 0 : (lp < 7 ? 1 : (lp < 9 ? 2 : 3));
-              const int l1 = lp - (l2 == 0 ? 0 : (l2 == 1 ? 4 : (l2 == 2 ? 7 : 9)));
-              const int tp = (k1 * 4 + l1) * M::RS;
-              const double *r0 = T1 + (0 * 4 + l2) * 49 + a0_ * 7, *r1 = r0 + 4 * 49, *r2 = r0 + 8 * 49, *r3 = r0 + 12 * 49;
+              const int cc = q / NA, a0_ = q - NA * cc;
+              const int k1 = cc / NS, lp = cc - NS * k1; // lp = RK::pair(l1, l2)
+              int l1, l2;
+              if constexpr (BASIS == 0)
+                l2 = lp / N1D, l1 = lp - N1D * l2;
+              else
+                {
+                  l2 = 0, l1 = lp;
+                  for (int w_ = N1D; l1 >= w_; --w_)
+                    l1 -= w_, ++l2;
+                }
+              const int tp = (k1 * N1D + l1) * M::RS;
+              const double *r0 = T1 + (0 * N1D + l2) * NA2 + a0_ * NA, *r1 = r0 + N1D * NA2, *r2 = r0 + 2 * N1D * NA2,
+                           *r3 = r0 + 3 * N1D * NA2;
               double sD = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, sF = 0.0;
               static_for<0, NA>([&](auto a_) {
                 constexpr int a = a_;
@@ -1088,31 +1145,37 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 s3 += f * r3[a];
                 sF += e * r2[a];
               });
-              T2[(0 * 40 + cc) * 7 + a0_] = s00 * sD;
-              T2[(1 * 40 + cc) * 7 + a0_] = s11 * s1 + s2 + ih1 * s3;
-              T2[(2 * 40 + cc) * 7 + a0_] = ih0 * sF;
+              T2[(0 * NC + cc) * NA + a0_] = s00 * sD;
+              T2[(1 * NC + cc) * NA + a0_] = s11 * s1 + s2 + ih1 * s3;
+              T2[(2 * NC + cc) * NA + a0_] = ih0 * sF;
             }
           PDH_WAVE_SYNC();
           const long long t2_ = (long long)__builtin_readcyclecounter();
 #ifdef PDHR_STAMP
           tp2 += t2_ - t1_;
 #endif
-          const int nrow = nk1 * (nk1 + 1) / 2;
-          for (int q = lane; q < nrow * DGP_N; q += 64)
+          const int nrow = BASIS == 0 ? N1D * N1D : nk1 * (nk1 + 1) / 2;
+          for (int q = lane; q < nrow * NF; q += 64)
             {
-              const int rr = q / DGP_N, j = q - DGP_N * rr;
-              int k1 = 0, k0 = rr, w_ = nk1;
-              while (k0 >= w_)
-                k0 -= w_, --w_, ++k1;
+              const int rr = q / NF, j = q - NF * rr;
+              int k1, k0;
+              if constexpr (BASIS == 0)
+                k1 = rr / N1D, k0 = rr - N1D * k1;
+              else
+                {
+                  k1 = 0, k0 = rr;
+                  for (int w_ = nk1; k0 >= w_; --w_)
+                    k0 -= w_, ++k1;
+                }
               const int dj_ = dig[j]; // axis 0: l0 | pair(l1, l2) << 4
-              const int tp = (k0 * 4 + (dj_ & 15)) * M::RS;
-              const double *t2 = T2 + (k1 * 10 + (dj_ >> 4)) * 7;
+              const int tp = (k0 * N1D + (dj_ & 15)) * M::RS;
+              const double *t2 = T2 + (k1 * NS + (dj_ >> 4)) * NA;
               double sv = 0.0;
               static_for<0, NA>([&](auto a_) {
                 constexpr int a = a_;
-                sv += tabD[tp + a] * t2[a] + tabE[tp + a] * t2[40 * 7 + a] + tabF[tp + a] * t2[80 * 7 + a];
+                sv += tabD[tp + a] * t2[a] + tabE[tp + a] * t2[NC * NA + a] + tabF[tp + a] * t2[2 * NC * NA + a];
               });
-              Dblk[dgp_index(k0, k1, k2) * DGP_N + j] = sv;
+              Dblk[RK::findex(k0, k1, k2) * NF + j] = sv;
             }
 #ifdef PDHR_STAMP
           tp3 += (long long)__builtin_readcyclecounter() - t2_;
@@ -1251,33 +1314,33 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   }
 
   PDHR_MARK(5);
-  if constexpr (BASIS == 1)
+  if constexpr (SMALL)
     {
-      // ================= P5 (FE_AggloDGP): the polytope's 20 rows are ONE contiguous range of 20 rlen values ==============
+      // ================= P5 (streamed kinds): the polytope's n rows are ONE contiguous range of n rlen values ==============
       // Streamed out in 512-byte pieces that start on 128-byte lines.  Position e -> (row R, position p in the row) ->
       // column c (diagonal-first rows: p = 0 is the diagonal entry, the rest ascending without it) -> block b, function j.
       // Own block: the LDS copy of P4; neighbour block: C[k_c(R), l_c(j)] S[pair(R), pair(j)] of that face.
       PDH_WAVE_SYNC();
-      const int total = DGP_N * rlen;
+      const int total = NF * rlen;
       const int mis = (int)(rbase & 15);
       int e = lane - mis;
       double *out = P.values + rbase;
       const int nit = (total + mis + 63) >> 6;
-      // digits of every function along each interior face's axis, face by face (6 x 20 ints in the dead T2B area of W)
-      int *digf = reinterpret_cast<int *>(W + 4 * 2 * 2 * 64);
-      for (int r = 0; r < 2; ++r) // (uniform: the face table is read across lanes)
+      // digits of every function along each interior face's axis, face by face (MAXF x n ints at the start of W, dead now)
+      int *digf = reinterpret_cast<int *>(W);
+      for (int r = 0; r < (MAXF * NF + 63) / 64; ++r) // (uniform: the face table is read across lanes)
         {
-          const int q0 = lane + 64 * r, q = q0 < MAXF * DGP_N ? q0 : MAXF * DGP_N - 1;
-          const int f = q / DGP_N, i = q - f * DGP_N;
+          const int q0 = lane + 64 * r, q = q0 < MAXF * NF ? q0 : MAXF * NF - 1;
+          const int f = q / NF, i = q - f * NF;
           int ax = __shfl(t_axis, n_bdry + f) & 3;
           ax = ax > 2 ? 2 : ax;
-          if (q0 < MAXF * DGP_N)
-            digf[q] = dig[ax * DGP_N + i];
+          if (q0 < MAXF * NF)
+            digf[q] = dig[ax * NF + i];
         }
       PDH_WAVE_SYNC();
       // four pieces per trip, level by level (positions -> digit reads -> value reads -> stores): in a rolled loop every
       // piece waited for its own two LDS round trips (620 cycles per piece in the stamps)
-      const float rinv = 1.0f / (float)rlen;
+      const float rinv = 1.0f / (float)rlen, ninv = 1.0f / (float)NF;
       const int nit4 = (nit + 3) >> 2;
 #if PDHR_EXP == 1
       for (int it = 0; it < nit4 && P.n < 0; ++it, e += 256)
@@ -1298,18 +1361,18 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             int c = p_;
             if (shifted)
               c = p_ == 0 ? L + R_ : (p_ - 1 + (p_ - 1 >= L + R_ ? 1 : 0));
-            const int b = (c * 3277) >> 16; // c / 20 for c < 6553
+            const int b = (int)(((float)c + 0.5f) * ninv); // c / n (c < 7 n: exact)
             int fl = b < m0 ? b : b - 1;
             fl = fl < 0 ? 0 : (fl >= MAXF ? MAXF - 1 : fl);
-            Rk[k] = R_, jk[k] = c - b * DGP_N, fk[k] = fl, own[k] = b == m0;
+            Rk[k] = R_, jk[k] = c - b * NF, fk[k] = fl, own[k] = b == m0;
           });
 #if PDHR_EXP == 6
           if (P.n < 0)
 #endif
           static_for<0, 4>([&](auto k_) {
             constexpr int k = k_;
-            dRk[k] = digf[fk[k] * DGP_N + Rk[k]];
-            dJk[k] = digf[fk[k] * DGP_N + jk[k]];
+            dRk[k] = digf[fk[k] * NF + Rk[k]];
+            dJk[k] = digf[fk[k] * NF + jk[k]];
           });
 #if PDHR_EXP == 6
           if (P.n < 0)
@@ -1317,8 +1380,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           static_for<0, 4>([&](auto k_) {
             constexpr int k = k_;
             const double cv = Call[fk[k] * 16 + (dRk[k] & 15) * 4 + (dJk[k] & 15)];
-            const double sv = M2c[fk[k] * MS + (dRk[k] >> 4) * 10 + (dJk[k] >> 4)];
-            const double dv = Dblk[Rk[k] * DGP_N + jk[k]];
+            const double sv = M2c[fk[k] * MS + (dRk[k] >> 4) * NS + (dJk[k] >> 4)];
+            const double dv = Dblk[Rk[k] * NF + jk[k]];
             val[k] = own[k] ? dv : cv * sv;
           });
           static_for<0, 4>([&](auto k_) {

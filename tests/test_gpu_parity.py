@@ -1005,51 +1005,66 @@ ROWS_CASES = [
 ]
 
 
-@pytest.mark.parametrize("basis", ["dgq", "dgp"])
+@pytest.mark.parametrize("basis,p", [("dgq", 3), ("dgp", 3), ("dgq", 2), ("dgp", 2), ("dgq", 1), ("dgp", 1)])
 @pytest.mark.parametrize("lg,b,vname,diag_first,world", ROWS_CASES)
-def test_row_kernel_parity(lg, b, vname, diag_first, world, basis):
+def test_row_kernel_parity(lg, b, vname, diag_first, world, basis, p):
     import polydeal_amd as pa
     from polydeal_amd.partition import row_range
 
-    fe = po.FE_DGQ(3, 3) if basis == "dgq" else po.FE_AggloDGP(3, 3)
+    fe = po.FE_DGQ(3, p) if basis == "dgq" else po.FE_AggloDGP(3, p)
+    nq = p + 1
     grid = po.hyper_cube_refined(3, 0.0, 1.0, lg)
     ah = po.AgglomerationHandler(grid)
     for g in (po.block_agglomerates(grid, b) if b else _box_groups(grid, 4)):
         ah.define_agglomerate(g)
-    ah.initialize_fe_values(4, 4)
+    ah.initialize_fe_values(nq, nq)
     ah.distribute_agglomerated_dofs(fe)
     var = variant(vname, fe)
     kw = flatten(ah, var, diag_first=diag_first)
     ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
     sc = np.max(np.abs(ref))
-    # general-point paths (tensor structure of the rules neither claimed nor looked for)
-    vr, used = _values(dict(kw, vq_tensor_n=-1, fq_tensor_n=-1), "rows")
-    assert used == "rows"
-    assert np.max(np.abs(vr - ref)) <= TOL * sc, np.max(np.abs(vr - ref)) / sc
-    # with the claim that the volume points are tensor rules of 4^3 points per sub-cell (verified by the library): the
-    # volume moments are then integrated cell by cell in factorised form
-    vt, used_t = _values(dict(kw, vq_tensor_n=4, fq_tensor_n=-1), "rows")
-    assert used_t == "rows"
-    assert np.max(np.abs(vt - ref)) <= TOL * sc, np.max(np.abs(vt - ref)) / sc
-    assert np.max(np.abs(vt - vr)) > 0.0  # really another path
-    # ... and the same for the sub-face rules (4^2 points each), alone and together with the volume hint
-    for hint in (dict(fq_tensor_n=4, vq_tensor_n=-1), dict(fq_tensor_n=4, vq_tensor_n=4)):
-        vf, used_f = _values(dict(kw, **hint), "rows")
-        assert used_f == "rows"
-        assert np.max(np.abs(vf - ref)) <= TOL * sc, (hint, np.max(np.abs(vf - ref)) / sc)
-        assert np.max(np.abs(vf - vr)) > 0.0
-    # a wrong claim must be harmless (the check on the points fails, the general path is taken)
-    vw, _ = _values(dict(kw, vq_tensor_n=2, fq_tensor_n=2), "rows")
-    assert np.array_equal(vw, vr)
-    # no claim at all (0): the library finds the structure itself - bit-identical to the verified claim
+    has_general_paths = basis == "dgq" and p == 3  # the other kinds of the kernel exist for tensor rules only
+    # no claim about the rules (0): the library finds their tensor structure on the points
     v0, used_0 = _values(kw, "rows")
-    assert used_0 == "rows" and np.array_equal(v0, vf)
-    vm, used_m = _values(kw, "moment" if basis == "dgq" else "direct")
-    assert used_m == ("moment" if basis == "dgq" else "direct") and np.max(np.abs(vr - vm)) <= 1e-13 * sc
+    assert used_0 == "rows"
+    assert np.max(np.abs(v0 - ref)) <= TOL * sc, np.max(np.abs(v0 - ref)) / sc
+    # verified claims: bit-identical
+    vf, used_f = _values(dict(kw, fq_tensor_n=nq, vq_tensor_n=nq), "rows")
+    assert used_f == "rows" and np.array_equal(v0, vf)
+    if has_general_paths:
+        # general-point paths (tensor structure of the rules neither claimed nor looked for)
+        vr, used = _values(dict(kw, vq_tensor_n=-1, fq_tensor_n=-1), "rows")
+        assert used == "rows"
+        assert np.max(np.abs(vr - ref)) <= TOL * sc, np.max(np.abs(vr - ref)) / sc
+        assert np.max(np.abs(v0 - vr)) > 0.0  # really another path
+        # each structure alone
+        for hint in (dict(vq_tensor_n=nq, fq_tensor_n=-1), dict(fq_tensor_n=nq, vq_tensor_n=-1)):
+            vh, used_h = _values(dict(kw, **hint), "rows")
+            assert used_h == "rows"
+            assert np.max(np.abs(vh - ref)) <= TOL * sc, (hint, np.max(np.abs(vh - ref)) / sc)
+            assert np.max(np.abs(vh - vr)) > 0.0 and np.max(np.abs(vh - v0)) > 0.0
+        # a wrong claim must be harmless (the check on the points fails, the general path is taken)
+        vw, _ = _values(dict(kw, vq_tensor_n=2, fq_tensor_n=2), "rows")
+        assert np.array_equal(vw, vr)
+    else:
+        # without the tensor structure these kinds must refuse (forced) / fall back (AUTO)
+        va, used_a = _values(dict(kw, vq_tensor_n=-1, fq_tensor_n=-1), "auto")
+        assert used_a != "rows"
+        assert np.max(np.abs(va - ref)) <= TOL * sc
+        prob = pa.Problem(**dict(kw, vq_tensor_n=-1, fq_tensor_n=-1))
+        ctx = pa.Context(0)
+        ctx.set_problem(prob)
+        ctx.set_algorithm("rows")
+        with pytest.raises(pa.PdhError):
+            ctx.assemble()
+        ctx.close()
+    other = "moment" if (basis == "dgq" and p == 3) else "direct"
+    vm, used_m = _values(kw, other)
+    assert used_m == other and np.max(np.abs(v0 - vm)) <= 1e-13 * sc
     # per block, not only against the global maximum
     n = fe.n_dofs_per_cell
     blk = np.abs(ref).reshape(-1, n).max(axis=1)
-    err = np.abs(vr - ref).reshape(-1, n).max(axis=1)
+    err = np.abs(v0 - ref).reshape(-1, n).max(axis=1)
     assert np.all(err <= 1e-11 * np.maximum(blk, 1e-3 * sc))
     if world > 1:
         parts = []
