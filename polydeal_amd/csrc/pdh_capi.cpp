@@ -179,8 +179,12 @@ struct pdh_ctx
   double *d_mtab = nullptr;
   // row kernel (pdh_rows.h): available when every face of every owned polytope is an axis-aligned plane (FE_DGQ(3), 3-D)
   bool rows_ok = false;
+  bool rows_auto = true; // AUTO takes the row kernel (degree >= 2; for n = 4 / 8 the direct kernels are as fast or faster)
   PdhRows rows;
-  bool use_rows() const { return rows_ok && d_mtab && (algorithm == PDH_ALG_AUTO || algorithm == PDH_ALG_ROWS); }
+  bool use_rows() const
+  {
+    return rows_ok && d_mtab && ((algorithm == PDH_ALG_AUTO && rows_auto) || algorithm == PDH_ALG_ROWS);
+  }
   // which form each of the two launches uses: [0] diagonal blocks, [1] coupling blocks
   bool use_moment(int kind) const
   {
@@ -917,6 +921,20 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
 // ---------------------------------------------------------------------------------------------------
 // Are the volume points of every owned polytope tensor-product rules of n^dim points on axis-aligned boxes (pdh_problem::
 // vq_tensor_n)?  Checked on the packed points to a few ulp; dim = 3.
+// Relative accuracy to expect of JxW (and of unit normals) that a caller computed from vertex coordinates of size |x| on
+// cells of size h: eps |x| / h per factor (differences of rounded coordinates), taken from the polytope's box; between
+// 1e-13 and 1e-12 (beyond that a deviation is treated as structure, not rounding).
+static double geometry_rounding(const pdh_problem *p, int a)
+{
+  double t = 1e-13;
+  for (int d = 0; d < p->dim; ++d)
+    {
+      const double lo_d = p->bbox[(size_t)a * 2 * p->dim + d], hi_d = p->bbox[(size_t)a * 2 * p->dim + p->dim + d];
+      t = std::max(t, 64.0 * 2.2e-16 * std::max(std::fabs(lo_d), std::fabs(hi_d)) / (hi_d - lo_d));
+    }
+  return std::min(t, 1e-12);
+}
+
 static bool volume_rules_are_tensor(const pdh_problem *p, const Packed &K, int n)
 {
   if (n <= 0 || n > 8 || p->dim != 3)
@@ -932,6 +950,7 @@ static bool volume_rules_are_tensor(const pdh_problem *p, const Packed &K, int n
         return;
       }
     const int a = K.own_agg[sl];
+    const double wtol = geometry_rounding(p, a);
     for (int64_t b = b0; b < e0; b += m)
       {
         const double w000 = vq_w[b];
@@ -952,14 +971,14 @@ static bool volume_rules_are_tensor(const pdh_problem *p, const Packed &K, int n
                   {
                     const double X = vq_x[d * nvq + b + idx[d] * step[d]];
                     const double h = p->bbox[(size_t)a * 6 + 3 + d] - p->bbox[(size_t)a * 6 + d];
-                    if (std::fabs(vq_x[d * nvq + q] - X) > 8e-16 * (std::fabs(X) + h))
+                    if (std::fabs(vq_x[d * nvq + q] - X) > 3e-15 * (std::fabs(X) + h))
                       {
                         bad[sl] = 1;
                         return;
                       }
                     wf *= vq_w[b + idx[d] * step[d]] / w000;
                   }
-                if (std::fabs(vq_w[q] - wf) > 1e-13 * wf)
+                if (std::fabs(vq_w[q] - wf) > wtol * wf)
                   {
                     bad[sl] = 1;
                     return;
@@ -992,6 +1011,7 @@ static bool face_rules_are_tensor(const pdh_problem *p, const Packed &K, int n, 
         return;
       }
     const int a = K.own_agg[K.run_slot[r]];
+    const double wtol = geometry_rounding(p, a);
     for (int64_t b = 0; b < cnt; b += m) // b: first point of the group inside run r
       {
         int c = 0;
@@ -1029,14 +1049,14 @@ static bool face_rules_are_tensor(const pdh_problem *p, const Packed &K, int n, 
                   const int64_t q = b + al * st_i + be * st_j;
                   const double Xi = K.ap_x(ti, r, b + al * st_i), Xj = K.ap_x(tj, r, b + be * st_j);
                   const double h_j = p->bbox[(size_t)a * 6 + 3 + tj] - p->bbox[(size_t)a * 6 + tj];
-                  if (std::fabs(K.ap_x(ti, r, q) - Xi) > 8e-16 * (std::fabs(Xi) + h_i) ||
-                      std::fabs(K.ap_x(tj, r, q) - Xj) > 8e-16 * (std::fabs(Xj) + h_j))
+                  if (std::fabs(K.ap_x(ti, r, q) - Xi) > 3e-15 * (std::fabs(Xi) + h_i) ||
+                      std::fabs(K.ap_x(tj, r, q) - Xj) > 3e-15 * (std::fabs(Xj) + h_j))
                     {
                       bad[r] = 1;
                       return;
                     }
                   const double wf = w(b + al * st_i) * (w(b + be * st_j) / w00);
-                  if (std::fabs(w(q) - wf) > 1e-13 * wf)
+                  if (std::fabs(w(q) - wf) > wtol * wf)
                     {
                       bad[r] = 1;
                       return;
@@ -1104,6 +1124,8 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
       if (cnt <= 0)
         return no("empty face");
       const int a = K.own_agg[K.run_slot[r]];
+      // (tangential components of a computed unit normal: of the order of the rounding of the geometry)
+      const double ntol = geometry_rounding(p, a);
       std::vector<double> sum;
       std::vector<int> num;
       for (int q = 0; q < cnt; ++q)
@@ -1118,7 +1140,7 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
           for (int d = 0; d < 3; ++d)
             {
               const double nd = K.ap_n(d, r, q);
-              if (d == c ? std::fabs(nd - sg) > 1e-14 : std::fabs(nd) > 1e-14)
+              if (d == c ? std::fabs(nd - sg) > ntol : std::fabs(nd) > ntol)
                 return no("normal not axis-aligned");
             }
           const double x = K.ap_x(c, r, q);
@@ -1582,6 +1604,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
           R.vq_tensor_n = vq_n;
           R.fq_tensor_n = RH.fq_tensor_n;
           ctx->rows_ok = ok;
+          ctx->rows_auto = p->degree >= 2;
           lap("row kernel: volume rule check");
         }
     }

@@ -48,7 +48,9 @@ def coefficient_vectors(ah, fe):
     return v1, vx, off
 
 
-def run_identities(dim, cells, block, fe, nq):
+def run_identities(dim, cells, block, fe, nq, unstructured_rules=None):
+    """unstructured_rules = name of the algorithm AUTO must then take: the quadrature points are declared unstructured
+    (pdh_problem::vq_tensor_n = fq_tensor_n = -1), which keeps the kinds of the row kernel that need tensor rules out."""
     lg = cells.bit_length() - 1
     grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, lg)
     ah = pa.AgglomerationHandler(grid)
@@ -56,7 +58,19 @@ def run_identities(dim, cells, block, fe, nq):
     ah.initialize_fe_values(nq, nq)
     ah.distribute_agglomerated_dofs(fe)
     var = pa.SipVariant.poisson_example(fe)
-    rp, ci, vals = pa.assemble_dg_matrix(fe, ah, var, diag_first=True)
+    if unstructured_rules is None:
+        rp, ci, vals = pa.assemble_dg_matrix(fe, ah, var, diag_first=True)
+    else:
+        flat = ah.flatten(var, True, True)
+        flat.c.vq_tensor_n = flat.c.fq_tensor_n = -1
+        ctx = pa.Context(0)
+        ctx.set_problem(flat)
+        assert ctx.algorithm_in_use() == unstructured_rules
+        vals = ctx.assemble()
+        ctx.close()
+        arr = flat.arrays()
+        rp, ci = arr["rowptr"].copy(), arr["colind"].copy()
+        del flat
     assert np.all(np.isfinite(vals))
     A = sp.csr_matrix((vals, ci, rp), shape=(ah.n_dofs, ah.n_dofs))
     sigma = var.penalty_constant / ah.diameter(0)
@@ -105,9 +119,12 @@ def test_config3_3d_p3_32768_polytopes_dgq():
 
 
 def test_3d_p2_32768_polytopes_dgq_mixed_algorithm():
-    """FE_DGQ(2), n = 27 (the element of BASELINE.json configs[3]) at 32 768 polytopes: AUTO takes the moment form for the
-    diagonal blocks and the direct form for the coupling blocks - the identities see both."""
+    """FE_DGQ(2), n = 27 (the element of BASELINE.json configs[3]) at 32 768 polytopes.  On this Cartesian mesh AUTO takes the
+    row kernel (streamed kind); with the rules declared unstructured it takes the moment form for the diagonal blocks and the
+    direct form for the coupling blocks - the identities see all three."""
     n_dofs, nnz = run_identities(3, 64, 2, pa.FE_DGQ(3, 2), 3)
+    assert n_dofs == 884736 and nnz == 27 * 27 * 223232
+    n_dofs, nnz = run_identities(3, 64, 2, pa.FE_DGQ(3, 2), 3, unstructured_rules="mixed")
     assert n_dofs == 884736 and nnz == 27 * 27 * 223232
 
 

@@ -637,11 +637,14 @@ def test_moment_form_parity(fe_cls, p, lg, b, dist, varname, diag_first):
     assert np.max(np.abs(vm - ref)) <= TOL * sc
     assert np.max(np.abs(vd - ref)) <= TOL * sc
     assert np.max(np.abs(vm - vd)) <= 1e-13 * sc
-    # AUTO: moment form for both kinds of block at FE_DGQ(3), for the diagonal blocks only at FE_DGQ(2), else direct
+    # AUTO: undistorted (every face an axis-aligned plane, tensor rules) -> row kernel from degree 2 on; else the moment
+    # form for both kinds of block at FE_DGQ(3), for the diagonal blocks only at FE_DGQ(2), else direct
     va, used_a = _values(kw, "auto")
     expect = "direct"
-    if fe_cls is po.FE_DGQ and p == 3:
-        expect = "rows" if dist == 0.0 else "moment"  # undistorted: every face an axis-aligned plane -> row kernel
+    if dist == 0.0 and p >= 2:
+        expect = "rows"
+    elif fe_cls is po.FE_DGQ and p == 3:
+        expect = "moment"
     elif fe_cls is po.FE_DGQ and p == 2:
         expect = "mixed"
     assert used_a == expect
