@@ -1338,60 +1338,74 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             digf[q] = dig[ax * NF + i];
         }
       PDH_WAVE_SYNC();
-      // four pieces per trip, level by level (positions -> digit reads -> value reads -> stores): in a rolled loop every
-      // piece waited for its own two LDS round trips (620 cycles per piece in the stamps)
-      const float rinv = 1.0f / (float)rlen, ninv = 1.0f / (float)NF;
-      const int nit4 = (nit + 3) >> 2;
+      // Row by row, a row in pieces of 64 positions.  What a lane needs to know about ITS position p of a row - block,
+      // face, digits of the column function - does not depend on the row, except in diagonal-first rows, where the column is
+      // p (rows R <= p - 1 - L) or p - 1 (the rows after): both candidates are decoded once per polytope into registers, a
+      // row then costs a few selects, four LDS reads and one multiply per piece.  (Decoding every value's position from its
+      // flat index - the first version - was 35 VALU instructions per value and the largest phase of these kinds.)
+      constexpr int MAXPC = (7 * NF + 63) / 64; // pieces per row: at most 1 + MAXF blocks of n columns
+      struct Cand
+      {
+        int cvb, svb, dvb, drb; // Call index without 4 k_c(R); slot index without NS u(R); column j; first digit entry of the face
+        bool own;
+      };
+      auto make = [&](int c) {
+        const int b = (int)(((float)c + 0.5f) * (1.0f / (float)NF)); // c / n (c < 8 n: exact)
+        const int j = c - b * NF;
+        int fl = b < m0 ? b : b - 1;
+        fl = fl < 0 ? 0 : (fl >= MAXF ? MAXF - 1 : fl);
+        const int dJ = digf[fl * NF + j];
+        Cand k;
+        k.cvb = fl * 16 + (dJ & 15), k.svb = fl * MS + (dJ >> 4), k.dvb = j, k.drb = fl * NF, k.own = b == m0;
+        return k;
+      };
+      Cand cA[MAXPC], cB[MAXPC];
+      int thr[MAXPC];
+      bool valid[MAXPC];
+      static_for<0, MAXPC>([&](auto pc_) {
+        constexpr int pc = pc_;
+        const int p = pc * 64 + lane;
+        valid[pc] = p < rlen;
+        const int pv = valid[pc] ? p : 0;
+        cA[pc] = make(pv);
+        cB[pc] = shifted ? make(pv > 0 ? pv - 1 : 0) : cA[pc];
+        thr[pc] = shifted ? pv - 1 - L : (1 << 30);
+      });
+      (void)total, (void)mis, (void)e, (void)nit;
+#pragma unroll 2
 #if PDHR_EXP == 1
-      for (int it = 0; it < nit4 && P.n < 0; ++it, e += 256)
+      for (int R = 0; R < NF && P.n < 0; ++R)
 #else
-      for (int it = 0; it < nit4; ++it, e += 256)
+      for (int R = 0; R < NF; ++R)
 #endif
         {
-          int Rk[4], jk[4], fk[4], dRk[4] = {0, 0, 0, 0}, dJk[4] = {0, 0, 0, 0};
-          bool on[4], own[4];
-          double val[4] = {0.0, 0.0, 0.0, 0.0};
-          static_for<0, 4>([&](auto k_) {
-            constexpr int k = k_;
-            const int ek = e + 64 * k;
-            on[k] = ek >= 0 && ek < total;
-            const int ec = on[k] ? ek : 0;
-            const int R_ = (int)(((float)ec + 0.5f) * rinv); // ec / rlen (ec < 2800, rlen >= 20: exact)
-            const int p_ = ec - R_ * rlen;
-            int c = p_;
-            if (shifted)
-              c = p_ == 0 ? L + R_ : (p_ - 1 + (p_ - 1 >= L + R_ ? 1 : 0));
-            const int b = (int)(((float)c + 0.5f) * ninv); // c / n (c < 7 n: exact)
-            int fl = b < m0 ? b : b - 1;
-            fl = fl < 0 ? 0 : (fl >= MAXF ? MAXF - 1 : fl);
-            Rk[k] = R_, jk[k] = c - b * NF, fk[k] = fl, own[k] = b == m0;
-          });
-#if PDHR_EXP == 6
-          if (P.n < 0)
-#endif
-          static_for<0, 4>([&](auto k_) {
-            constexpr int k = k_;
-            dRk[k] = digf[fk[k] * NF + Rk[k]];
-            dJk[k] = digf[fk[k] * NF + jk[k]];
-          });
-#if PDHR_EXP == 6
-          if (P.n < 0)
-#endif
-          static_for<0, 4>([&](auto k_) {
-            constexpr int k = k_;
-            const double cv = Call[fk[k] * 16 + (dRk[k] & 15) * 4 + (dJk[k] & 15)];
-            const double sv = M2c[fk[k] * MS + (dRk[k] >> 4) * NS + (dJk[k] >> 4)];
-            const double dv = Dblk[Rk[k] * NF + jk[k]];
-            val[k] = own[k] ? dv : cv * sv;
-          });
-          static_for<0, 4>([&](auto k_) {
-            constexpr int k = k_;
+          double *rowp = out + (int64_t)R * rlen; // uniform
+          static_for<0, MAXPC>([&](auto pc_) {
+            constexpr int pc = pc_;
+            if (pc * 64 < rlen)
+              {
+                const bool useB = R > thr[pc];
+                const int cvb = useB ? cB[pc].cvb : cA[pc].cvb, svb = useB ? cB[pc].svb : cA[pc].svb;
+                const int dvb = useB ? cB[pc].dvb : cA[pc].dvb, drb = useB ? cB[pc].drb : cA[pc].drb;
+                const bool own = useB ? cB[pc].own : cA[pc].own;
+                const int dR = digf[drb + R];
+                const double cv = Call[cvb + 4 * (dR & 15)];
+                const double sv = M2c[svb + (dR >> 4) * NS];
+                double dv = Dblk[R * NF + dvb];
+                double val = own ? dv : cv * sv;
+                if constexpr (pc == 0)
+                  if (shifted)
+                    { // position 0 of a diagonal-first row: the diagonal entry
+                      const double dd = Dblk[R * NF + R];
+                      val = lane == 0 ? dd : val;
+                    }
 #if PDHR_EXP == 5
-            if (on[k] && P.n < 0)
+                if (valid[pc] && P.n < 0)
 #else
-            if (on[k])
+                if (valid[pc])
 #endif
-              out[e + 64 * k] = val[k];
+                  rowp[pc * 64 + lane] = val;
+              }
           });
         }
     }
