@@ -373,6 +373,9 @@ def main():
                     help="N > 1: weak = N cubes stacked along the last direction, one slab per rank (default); "
                          "strong = the N = 1 problem split into N row ranges")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary FE measurement")
+    ap.add_argument("--general-points-extra", action="store_true",
+                    help="also time the row kernel's general-point paths (quadrature declared unstructured); off by default: "
+                         "it launches the same kernel symbol and would blur the per-kernel averages of a rocprofv3 trace")
     ap.add_argument("--overlap-extra", action="store_true",
                     help="also time the step with the library's default overlapped launch of its two kernels "
                          "(roofline.overlapped_ms_per_step); off by default so that a rocprofv3 trace of the default command "
@@ -440,7 +443,7 @@ def main():
         direct = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, max(3, args.steps // 3), 1, alg="direct")
 
     general = None
-    if main_res["alg"] == "rows" and not args.no_extra and world == 1:
+    if main_res["alg"] == "rows" and args.general_points_extra and world == 1:
         # the same workload with the row kernel's general-point paths (no use of the tensor structure of the rules)
         general = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, max(3, args.steps // 3), 1,
                           look_for_tensor_rules=False)

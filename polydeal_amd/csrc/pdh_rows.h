@@ -1,5 +1,7 @@
-// pdh_rows.h — the row kernel: FE_DGQ(3) in 3-D on polytopes whose faces are axis-aligned planes (agglomerates of
-// Cartesian cells: every configuration of BASELINE.json but the piston mesh).  ONE wave per owned polytope computes and
+// pdh_rows.h — the row kernel: 3-D, degree 1 .. 3, on polytopes whose faces are axis-aligned planes (agglomerates of
+// Cartesian cells: every configuration of BASELINE.json but the piston mesh).  Described here for FE_DGQ(3), n = 64, the
+// element it was designed around; the other elements run as "streamed" kinds of the same template (RowsKind below: shared
+// moment phases, their own diagonal-block and store phases).  ONE wave per owned polytope computes and
 // writes ALL values of the polytope's 64 rows - the diagonal block and every coupling block - as complete, aligned
 // 512-byte pieces.  It replaces the pair k_mdiag / k_moffdiag (pdh_moment.h) where it applies; what is computed is
 // unchanged (reference include/poly_utils.h:2040-2084 volume + boundary, :1870-1926 interface blocks), only the order
