@@ -1259,15 +1259,17 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
 // Second half of the eligibility test: structure of the volume rules (vq_n), and - every kind but FE_DGQ(3) has no
 // general-point paths - tensor rules everywhere and no face entry with more sub-faces than the 64 lane tasks of a batch
 // hold (pdh_rows.h, P2).
-static bool rows_kind_applies(const pdh_problem *p, const Packed &K, const RowsHost &RH, int &vq_n, std::string *why = nullptr)
+static bool rows_kind_applies(const pdh_problem *p, const Packed &K, const RowsHost &RH, int &vq_n, bool &tensor_only,
+                              std::string *why = nullptr)
 {
   vq_n = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
-  if (K.n1d == 4 && p->basis == PDH_BASIS_DGQ)
-    return true;
   bool ok = vq_n > 0 && RH.fq_tensor_n > 0;
   const int64_t m = (int64_t)RH.fq_tensor_n * RH.fq_tensor_n;
   for (size_t f = 0; ok && f < RH.fr_pcnt.size(); ++f)
     ok = RH.fr_pcnt[f] / m <= 32;
+  tensor_only = ok;
+  if (K.n1d == 4) // degree 3 has the general-point paths (pdh_rows.h: GENERAL)
+    return true;
   if (!ok && why)
     *why = "this element takes the row kernel only with tensor-product rules on every sub-cell and sub-face";
   return ok;
@@ -1285,7 +1287,8 @@ extern "C" int pdh_check_rows(const pdh_problem *p, int32_t row_begin, int32_t r
   RowsHost R;
   std::string why;
   int vq_n = 0;
-  if (build_rows_tables(p, K, R, &why) && rows_kind_applies(p, K, R, vq_n, &why))
+  bool tensor_only = false;
+  if (build_rows_tables(p, K, R, &why) && rows_kind_applies(p, K, R, vq_n, tensor_only, &why))
     return 1;
   g_err_noctx = why;
   return 0;
@@ -1600,7 +1603,9 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
           }
           lap("row kernel: upload");
           int vq_n = 0;
-          const bool ok = rows_kind_applies(p, K, RH, vq_n);
+          bool tensor_only = false;
+          const bool ok = rows_kind_applies(p, K, RH, vq_n, tensor_only);
+          R.tensor_only = tensor_only ? 1 : 0;
           R.vq_tensor_n = vq_n;
           R.fq_tensor_n = RH.fq_tensor_n;
           ctx->rows_ok = ok;

@@ -85,7 +85,17 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
     const int per_cu = per_cu_env > 0 ? per_cu_env : fit;
     const int resident = cus * per_cu;
     const unsigned grid = (unsigned)(count < resident ? count : resident);
-    hipLaunchKernelGGL((pdhr::k_rows<N, B>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
+    // degree 3: the instantiation without general-point paths when the host verified tensor rules everywhere
+    // (PdhRows::tensor_only, pdh_capi.cpp: rows_kind_applies)
+    if constexpr (N == 4)
+      {
+        if (R->tensor_only)
+          hipLaunchKernelGGL((pdhr::k_rows<N, B, false>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
+        else
+          hipLaunchKernelGGL((pdhr::k_rows<N, B, true>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
+      }
+    else
+      hipLaunchKernelGGL((pdhr::k_rows<N, B, false>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
     rc = hipGetLastError();
   };
   using std::integral_constant;

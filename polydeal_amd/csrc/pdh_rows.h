@@ -143,10 +143,14 @@ __device__ __forceinline__ int digits_t(int i, int c)
   return c == 0 ? (k1 + 4 * k2) : (c == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
 }
 
-template <int N1D, int BASIS = 0>
+// GENERAL = false: instantiation without the general-point paths (tensor rules verified on every sub-cell and sub-face, no
+// face entry with more than 32 sub-faces) - the MFMA moment accumulators and their operand addresses are then not part of
+// the kernel at all, which the register allocation of the remaining phases feels.
+template <int N1D, int BASIS = 0, bool GENERAL = (N1D == 4)>
 __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhRows Rw, const double *__restrict__ mt, const int n_owned)
 {
   static_assert(N1D >= 2 && N1D <= 4, "the row kernel is written for degree 1 .. 3");
+  static_assert(!GENERAL || N1D == 4, "general-point paths exist for degree 3 only");
   using RK = RowsKind<N1D, BASIS>;
   constexpr bool SMALL = RK::SMALL;
   constexpr int MS = RK::SS; // doubles per interior-face slot
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     ++n_bdry;
   // (general volume path only: MFMA accumulators and operand addresses; dead registers in the tensor path)
   pdhm::MomentAcc<N1D> ma;
-  if constexpr (N1D == 4) // (the other kinds exist for verified tensor rules only)
+  if constexpr (GENERAL) // (the other kinds exist for verified tensor rules only)
     if (Rw.vq_tensor_n == 0)
       {
         ma.init(lane);
@@ -329,7 +333,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         }
       PDH_WAVE_SYNC();
     }
-  else if constexpr (N1D == 4)
+  else if constexpr (GENERAL)
   {
     // point data two chunks ahead, in two statically addressed register sets (see P2 on why no copies)
     const int64_t qb = vq_b, qe = vq_e;
@@ -724,7 +728,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           }
 #endif
       }
-    else if constexpr (N1D == 4)
+    else if constexpr (GENERAL)
 #if PDHR_EXP == 3
     if (nfaces > 0 && P.n < 0)
 #else
@@ -1078,7 +1082,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   PDHR_MARK(4);
   // ================= P4: diagonal block ============================================================================
   PDH_WAVE_SYNC();
-  if constexpr (N1D == 4)
+  if constexpr (GENERAL)
   if (tn == 0)
   {
   {

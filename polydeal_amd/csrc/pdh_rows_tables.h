@@ -17,5 +17,6 @@ struct PdhRows
   const double *meta;      // [n_owned][ROWS_REC] per-slot records (header + face entries incl. neighbour boxes), pdh_rows.h
   int32_t fq_tensor_n;     // > 0: face points are verified tensor rules of this many points per direction on every sub-face
   int32_t vq_tensor_n;     // > 0: volume points are verified tensor rules of this many points per direction (else 0)
+  int32_t tensor_only;     // 1: both kinds of rule are tensor rules and no face entry has more than 32 sub-faces
   long long *stamps;       // [n_owned][16] s_memtime at the phase boundaries; written by -DPDHR_STAMP builds only
 };
