@@ -1026,7 +1026,7 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world, basis, p):
     kw = flatten(ah, var, diag_first=diag_first)
     ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
     sc = np.max(np.abs(ref))
-    has_general_paths = basis == "dgq" and p == 3  # the other kinds of the kernel exist for tensor rules only
+    has_general_paths = p == 3  # the kinds of lower degree exist for tensor rules only
     # no claim about the rules (0): the library finds their tensor structure on the points
     v0, used_0 = _values(kw, "rows")
     assert used_0 == "rows"
