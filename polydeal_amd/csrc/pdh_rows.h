@@ -249,9 +249,6 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   const int t_axis = (int)(i2_ & 0xff), t_flags = (int)((i2_ >> 8) & 0xff), t_blk = lane < nfaces ? (int)(i2_ >> 32) : -1;
   const double t_coord = cur.e[3], t_sigma = cur.e[4], t_nsign = cur.e[5];
   const double t_qlo0 = cur.e[6], t_qlo1 = cur.e[7], t_qlo2 = cur.e[8], t_qih0 = cur.e[9], t_qih1 = cur.e[10], t_qih2 = cur.e[11];
-  Meta nxt = cur;
-  if (slot + (int)gridDim.x < n_owned)
-    nxt = load_meta(slot + (int)gridDim.x);
   int n_bdry = 0; // boundary entries come first; coupling moments are kept per interior face
   while (n_bdry < nfaces && rl_i(t_blk, n_bdry) < 0)
     ++n_bdry;
@@ -1352,6 +1349,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   }
 
   PDHR_MARK(5);
+  // the next polytope's record is requested here: the store phase is long enough to hide the loads (~7k cycles), and
+  // before it the 24 registers of the record would sit through the phases with the highest register pressure
+  Meta nxt = cur;
+  if (slot + (int)gridDim.x < n_owned)
+    nxt = load_meta(slot + (int)gridDim.x);
   if constexpr (SMALL)
     {
       // ================= P5 (streamed kinds): the polytope's n rows are ONE contiguous range of n rlen values ==============
