@@ -435,6 +435,11 @@ def main():
                  "dofs_per_polytope": r2["n"], "n_dofs": r2["n_dofs"],
                  "value": r2["n_dofs"] / (r2["dt"] / args.steps), "ms_per_step": 1e3 * r2["dt"] / args.steps,
                  "algorithm": r2["alg"], "kernel_ms": {"diagonal_blocks": r2["kms"][0], "coupling_blocks": r2["kms"][1]}}
+        if r2.get("work"):
+            by2 = sum(r2["work"]["bytes"])
+            extra.update(algorithmic_bytes_per_step=by2, hbm_GBs=by2 / (r2["dt"] / args.steps) * 1e-9,
+                         frac_of_hbm_peak=by2 / (r2["dt"] / args.steps) * 1e-9 / HBM_PEAK_GBS,
+                         fp64_bound_ms=1e3 * sum(r2["work"]["flops"]) / (FP64_PEAK_TFLOPS * 1e12))
     if main_res.get("aux") is not None:
         extra["aux_kernels"] = main_res["aux"]
     direct = None
