@@ -78,6 +78,11 @@ __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_o
         x[c] = on ? pts[c * pts_stride + q] : lo[c];
       double r[RC::LEN]; // (value, derivative / h) of every 1-D function, in registers (static indices only)
       eval_point_record<DIM, N1D, false>(P.tab, lo, h, x, 1.0, nullptr, r);
+      // (the coefficient reads stay inside the loop: hoisted, the n coefficients would occupy 2 n VGPRs for the whole kernel -
+      // 208 registers, two waves per SIMD - where a streaming kernel wants many waves in flight; broadcasts are cheap)
+      int zoff = 0;
+      asm volatile("" : "+v"(zoff));
+      const double *cfl = lds + zoff;
       double u = 0.0, g[3] = {0.0, 0.0, 0.0};
       constexpr int NZ = DIM == 3 ? N1D : 1;
       static_for<0, NZ>([&](auto k2_) {
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_o
           double s0 = 0.0, sd = 0.0;
           static_for<0, NX>([&](auto k0_) {
             constexpr int k0 = k0_;
-            const double c = lds[function_index<DIM, N1D, BASIS>(k0, k1, k2)];
+            const double c = cfl[function_index<DIM, N1D, BASIS>(k0, k1, k2)];
             s0 += r[(0 * N1D + k0) * 2] * c;
             if constexpr (GRAD)
               sd += r[(0 * N1D + k0) * 2 + 1] * c;
