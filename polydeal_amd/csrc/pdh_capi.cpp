@@ -65,7 +65,7 @@ PDH_DECL(0) PDH_DECL(1) PDH_DECL(2) PDH_DECL(3) PDH_DECL(4) PDH_DECL(5) PDH_DECL
 
 extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int count, const double *f_vol,
                                      const double *g_face, double *rhs, const int64_t *vq_src, const int64_t *ap_src,
-                                     hipStream_t stream);
+                                     const int64_t *bd_rng, hipStream_t stream);
 
 extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *P, int count, const double *coef,
                                       const int64_t *pt_ptr, const double *pts, int64_t pts_stride, double *out_u,
@@ -134,13 +134,14 @@ struct pdh_ctx
   int64_t n_values = 0, n_vq = 0, n_ap = 0;
   // host-side maps from the caller's quadrature arrays to the packed device layout (for pdh_assemble_rhs)
   std::vector<int64_t> vq_src;                       // per owned slot: first volume point in the caller's arrays
-  struct FaceRun { int64_t ap_begin, fq_begin; int32_t count; int32_t boundary; };
+  struct FaceRun { int64_t ap_begin, fq_begin; int32_t count; int32_t boundary; int32_t slot; };
   std::vector<FaceRun> face_runs;
   int64_t n_rows_owned = 0;
   int32_t n_agg_total = 0;
   // caller-order maps for the right-hand side (device): first caller volume point of every slot; caller face point of every
   // packed face point (-1: not on the boundary); sizes of the caller's point arrays
   const int64_t *d_vq_src = nullptr, *d_ap_src = nullptr;
+  const int64_t *d_bd_rng = nullptr; // [n_owned][2] packed face points of every slot that lie on the boundary (one run)
   int64_t n_vq_caller = 0, n_fq_caller = 0;
   // grow-only device scratch for the host-pointer variants of rhs / evaluate / shape_values (no hipMalloc per call)
   struct Scratch { void *p = nullptr; size_t bytes = 0; };
@@ -251,6 +252,7 @@ static void free_problem(pdh_ctx *ctx)
   ctx->allocs.clear();
   ctx->has_problem = false;
   ctx->d_ap_src = nullptr;
+  ctx->d_bd_rng = nullptr;
 }
 
 template <class T>
@@ -1527,7 +1529,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   ctx->face_runs.clear();
   ctx->face_runs.reserve(K.run_ap.size());
   for (size_t r = 0; r < K.run_ap.size(); ++r)
-    ctx->face_runs.push_back({K.run_ap[r], K.run_fq[r], K.run_cnt[r], K.run_bdry[r]});
+    ctx->face_runs.push_back({K.run_ap[r], K.run_fq[r], K.run_cnt[r], K.run_bdry[r], K.run_slot[r]});
   lap("caller-order maps");
   ctx->n_rows_owned = (int64_t)K.n_owned * K.n;
   ctx->n_agg_total = p->n_agg;
@@ -1901,6 +1903,21 @@ static int ensure_ap_src(pdh_ctx *ctx)
       for (int32_t t = 0; t < fr.count; ++t)
         ap_src[fr.ap_begin + t] = fr.fq_begin + t;
   });
+  // the boundary points of a slot are one contiguous run (all boundary sub-faces form ONE polytopal face, reference
+  // source/agglomeration_handler.cc:1575-1613): the kernel visits only that range
+  std::vector<int64_t> bd((size_t)std::max(ctx->n_owned, 1) * 2, 0);
+  for (const auto &fr : ctx->face_runs)
+    if (fr.boundary && fr.slot >= 0 && fr.slot < ctx->n_owned)
+      {
+        int64_t &b = bd[(size_t)fr.slot * 2], &e = bd[(size_t)fr.slot * 2 + 1];
+        if (e == b)
+          b = fr.ap_begin, e = fr.ap_begin + fr.count;
+        else
+          b = std::min(b, fr.ap_begin), e = std::max(e, fr.ap_begin + fr.count); // (several runs: their hull; interior points in between carry no datum)
+      }
+  int rc = upload(ctx, bd, &ctx->d_bd_rng);
+  if (rc != PDH_OK)
+    return rc;
   return upload(ctx, ap_src, &ctx->d_ap_src);
 }
 
@@ -1917,7 +1934,7 @@ extern "C" int pdh_assemble_rhs_device(pdh_ctx *ctx, const double *d_f_vol, cons
   if (rc_map != PDH_OK)
     return rc_map;
   PDH_HIP(ctx, pdh_launch_rhs(ctx->dev.dim, ctx->dev.n1d, &ctx->dev, ctx->n_owned, d_f_vol, d_g_bdry, d_rhs, ctx->d_vq_src,
-                              ctx->d_ap_src, ctx->stream));
+                              ctx->d_ap_src, ctx->d_bd_rng, ctx->stream));
   return PDH_OK;
 }
 

@@ -15,18 +15,26 @@
 
 namespace pdh
 {
+// points per chunk of the face loop: 16 where the volume part runs on the MFMA and needs 2 KB of LDS only (then 4 KB per
+// wave instead of 15 KB: the kernel is bound by the latency of its point loads, it wants waves)
+template <int DIM, int N1D>
+constexpr int rhs_face_chunk()
+{
+  return (DIM == 3 && N1D == 4) ? 16 : PDH_WAVE;
+}
 template <int DIM, int N1D>
 constexpr int rhs_lds_doubles()
 {
-  constexpr int face = Rec<DIM, N1D>::LEN + 1 + DIM;
-  constexpr int vol = (N1D + (DIM == 3 ? N1D * N1D : N1D)) | 1;
-  return PDH_WAVE * (face > vol ? face : vol);
+  constexpr int face = rhs_face_chunk<DIM, N1D>() * (Rec<DIM, N1D>::LEN + 1 + DIM);
+  constexpr int vol = (DIM == 3 && N1D == 4) ? PDH_WAVE * 4 : PDH_WAVE * ((N1D + (DIM == 3 ? N1D * N1D : N1D)) | 1);
+  return face > vol ? face : vol;
 }
 
 template <int DIM, int N1D>
 __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_owned, const double *__restrict__ f_vol,
                                                   const double *__restrict__ g_face, double *__restrict__ rhs,
-                                                  const int64_t *__restrict__ vq_src, const int64_t *__restrict__ ap_src)
+                                                  const int64_t *__restrict__ vq_src, const int64_t *__restrict__ ap_src,
+                                                  const int64_t *__restrict__ bd_rng)
 {
   // f_vol / g_face are indexed in the CALLER's point order (the order of vq_x / fq_x of the description): vq_src[slot] is
   // the caller index of the slot's first volume point, ap_src[q] the caller index of packed face point q (-1: not a boundary
@@ -39,7 +47,8 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
     return;
   const int agg = P.own_agg[slot];
   double *rec = lds;                      // [64][RC::LEN]
-  double *aux = lds + PDH_WAVE * RC::LEN; // [64][1+DIM]
+  constexpr int FCHK = rhs_face_chunk<DIM, N1D>();
+  double *aux = lds + FCHK * RC::LEN; // [FCHK][1+DIM]
   constexpr int AUXN = 1 + DIM;
   // volume records: [64][VLEN] = F0[N1D] | P12[N1D^(DIM-1)]; odd stride
   constexpr int NP12 = DIM == 3 ? N1D * N1D : N1D;
@@ -70,7 +79,87 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
   }
 
   // volume: sum_q phi_i f JxW
-  if (f_vol)
+  if constexpr (DIM == 3 && N1D == 4)
+    {
+      // Degree 3 in 3-D: the sum over the points as a GEMM on the f64 MFMA.  rhs[k0; (k1,k2)] = sum_q (f JxW B0_k0)(q) (B1_k1
+      // B2_k2)(q) is a 4 x 16 product with K = the points: v_mfma_f64_4x4x4_4b with block b = k2, A_b[i][k] = f JxW B0_i at
+      // point 4 s + k (the same for all blocks), B_b[k][j] = B1_j B2_b.  Lane (k, blk, idx) of a step evaluates three cubics
+      // at its point (read from LDS: centred box coordinates and f JxW, 4 doubles) - 11 VALU instructions and 2 LDS reads per
+      // 4 points and lane instead of 2 LDS reads and a multiply-add per POINT and lane.  FE_AggloDGP(3) is the subset
+      // k0 + k1 + k2 <= 3 of the same 64 sums.
+      if (f_vol)
+        {
+          const int kq = lane >> 4, blk = (lane >> 2) & 3, idx = lane & 3;
+          double cI[4], cB[4]; // monomial coefficients (centred variable) of the 1-D functions idx and blk
+          static_for<0, 4>([&](auto m_) {
+            constexpr int m = m_;
+            cI[m] = idx == 0 ? P.tab.coef[0][m] : (idx == 1 ? P.tab.coef[1][m] : (idx == 2 ? P.tab.coef[2][m] : P.tab.coef[3][m]));
+            cB[m] = blk == 0 ? P.tab.coef[0][m] : (blk == 1 ? P.tab.coef[1][m] : (blk == 2 ? P.tab.coef[2][m] : P.tab.coef[3][m]));
+          });
+          double vacc = 0.0, vacc2 = 0.0; // (two accumulators: consecutive MFMAs do not wait for each other)
+          const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
+          double *pts = lds; // [64][4]: xhat0, xhat1, xhat2 (centred), f JxW
+          // point data of the NEXT chunk is requested before the current one is worked on (one wave per polytope: nothing
+          // else hides the latency of these loads)
+          struct Raw
+          {
+            double x0, x1, x2, f, w;
+          };
+          auto issue = [&](int64_t base) {
+            Raw r;
+            const bool on = base + lane < qe;
+            const int64_t q = on ? base + lane : qb;
+            const int64_t src = vq_src ? vq_src[slot] + (q - qb) : q;
+            r.x0 = P.vq_x[0 * P.vq_stride + q];
+            r.x1 = P.vq_x[1 * P.vq_stride + q];
+            r.x2 = P.vq_x[2 * P.vq_stride + q];
+            r.f = f_vol[src];
+            r.w = on ? P.vq_w[q] : 0.0;
+            return r;
+          };
+          Raw nxt = issue(qb);
+          for (int64_t base = qb; base < qe; base += PDH_WAVE)
+            {
+              const int cnt = (int)((qe - base < PDH_WAVE) ? (qe - base) : PDH_WAVE);
+              PDH_WAVE_SYNC();
+              pts[lane * 4 + 0] = (nxt.x0 - lo[0]) / h[0] - 0.5;
+              pts[lane * 4 + 1] = (nxt.x1 - lo[1]) / h[1] - 0.5;
+              pts[lane * 4 + 2] = (nxt.x2 - lo[2]) / h[2] - 0.5;
+              pts[lane * 4 + 3] = nxt.f * nxt.w; // dead points: w = 0
+              if (base + PDH_WAVE < qe)
+                nxt = issue(base + PDH_WAVE);
+              PDH_WAVE_SYNC();
+              (void)cnt; // all 16 steps of 4 points: dead points carry f JxW = 0
+              static_for<0, PDH_WAVE / 4>([&](auto st_) {
+                constexpr int st = st_;
+                const double *pq = pts + (4 * st + kq) * 4;
+                const double x0 = pq[0], x1 = pq[1], x2 = pq[2], fw = pq[3];
+                double b0 = cI[3], b1 = cI[3], b2 = cB[3];
+                static_for<0, 3>([&](auto t_) {
+                  constexpr int m = 2 - t_;
+                  b0 = b0 * x0 + cI[m];
+                  b1 = b1 * x1 + cI[m];
+                  b2 = b2 * x2 + cB[m];
+                });
+                if constexpr (st % 2 == 0)
+                  vacc = mfma4(fw * b0, b1 * b2, vacc);
+                else
+                  vacc2 = mfma4(fw * b0, b1 * b2, vacc2);
+              });
+            }
+          // D layout: lane (i, blk, j) holds rhs[k0 = i, k1 = j, k2 = blk]; hand over to the lanes = functions of this kernel
+          PDH_WAVE_SYNC();
+          lds[(lane >> 4) + 4 * (lane & 3) + 16 * ((lane >> 2) & 3)] = vacc + vacc2;
+          PDH_WAVE_SYNC();
+          if (live)
+            {
+              const uint32_t packed = (uint32_t)P.midx[lane];
+              acc += lds[(int)(packed & 0xff) + 4 * (int)((packed >> 8) & 0xff) + 16 * (int)((packed >> 16) & 0xff)];
+            }
+          PDH_WAVE_SYNC();
+        }
+    }
+  else if (f_vol)
     {
       const int64_t qb = P.vq_ptr[slot], qe = P.vq_ptr[slot + 1];
       for (int64_t base = qb; base < qe; base += PDH_WAVE)
@@ -112,13 +201,15 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
   // Nitsche boundary terms; points of interior faces carry g = 0 (set by the host)
   if (g_face)
     {
-      const int64_t pb = P.ap_ptr[slot], pe = P.ap_ptr[slot + 1];
-      for (int64_t base = pb; base < pe; base += PDH_WAVE)
+      // (bd_rng: the packed points of this slot that lie on the boundary - none for most polytopes; without it every chunk's
+      // map entries would be loaded one after the other just to find that out)
+      const int64_t pb = bd_rng ? bd_rng[2 * (int64_t)slot] : P.ap_ptr[slot], pe = bd_rng ? bd_rng[2 * (int64_t)slot + 1] : P.ap_ptr[slot + 1];
+      for (int64_t base = pb; base < pe; base += FCHK)
         {
-          const int cnt = (int)((pe - base < PDH_WAVE) ? (pe - base) : PDH_WAVE);
+          const int cnt = (int)((pe - base < FCHK) ? (pe - base) : FCHK);
           // a chunk without boundary points contributes nothing (ap_src = -1 on interior faces)
           const int64_t src_l = lane < cnt ? (ap_src ? ap_src[base + lane] : base + lane) : -1;
-          if (__ballot(src_l >= 0) == 0ull)
+          if (!bd_rng && __ballot(src_l >= 0) == 0ull) // (with bd_rng the range holds boundary points only: no need to wait)
             continue;
           PDH_WAVE_SYNC();
           if (lane < cnt)
@@ -168,7 +259,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
 
 extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int count, const double *f_vol,
                                      const double *g_face, double *rhs, const int64_t *vq_src, const int64_t *ap_src,
-                                     hipStream_t stream)
+                                     const int64_t *bd_rng, hipStream_t stream)
 {
   if (count <= 0)
     return hipSuccess;
@@ -177,7 +268,8 @@ extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int coun
   if (dim == D && n1d == N)                                                                                \
     {                                                                                                      \
       const size_t lds = (size_t)pdh::rhs_lds_doubles<D, N>() * sizeof(double);                            \
-      hipLaunchKernelGGL((pdh::k_rhs<D, N>), grid, block, lds, stream, *P, count, f_vol, g_face, rhs, vq_src, ap_src);      \
+      hipLaunchKernelGGL((pdh::k_rhs<D, N>), grid, block, lds, stream, *P, count, f_vol, g_face, rhs, vq_src, ap_src,  \
+                         bd_rng);                                                                          \
       return hipGetLastError();                                                                            \
     }
   PDH_RHS_CASE(2, 1) PDH_RHS_CASE(2, 2) PDH_RHS_CASE(2, 3) PDH_RHS_CASE(2, 4)
