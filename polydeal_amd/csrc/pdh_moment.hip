@@ -87,15 +87,24 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
     const unsigned grid = (unsigned)(count < resident ? count : resident);
     // degree 3: the instantiation without general-point paths when the host verified tensor rules everywhere
     // (PdhRows::tensor_only, pdh_capi.cpp: rows_kind_applies)
+    auto go = [&](auto general_, auto shifted_) {
+      constexpr bool G = decltype(general_)::value, S = decltype(shifted_)::value;
+      hipLaunchKernelGGL((pdhr::k_rows<N, B, G, S>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
+    };
+    using std::true_type;
+    using std::false_type;
+    const bool general = N == 4 && !R->tensor_only, shifted = P->diag_first != 0;
     if constexpr (N == 4)
       {
-        if (R->tensor_only)
-          hipLaunchKernelGGL((pdhr::k_rows<N, B, false>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
-        else
-          hipLaunchKernelGGL((pdhr::k_rows<N, B, true>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
+        if (general && shifted)
+          go(true_type{}, true_type{});
+        else if (general)
+          go(true_type{}, false_type{});
       }
-    else
-      hipLaunchKernelGGL((pdhr::k_rows<N, B, false>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
+    if (!general && shifted)
+      go(false_type{}, true_type{});
+    else if (!general)
+      go(false_type{}, false_type{});
     rc = hipGetLastError();
   };
   using std::integral_constant;

@@ -146,7 +146,9 @@ __device__ __forceinline__ int digits_t(int i, int c)
 // GENERAL = false: instantiation without the general-point paths (tensor rules verified on every sub-cell and sub-face, no
 // face entry with more than 32 sub-faces) - the MFMA moment accumulators and their operand addresses are then not part of
 // the kernel at all, which the register allocation of the remaining phases feels.
-template <int N1D, int BASIS = 0, bool GENERAL = (N1D == 4)>
+// SHIFTED: deal.II's diagonal-first rows (else ascending) - a compile-time fact of the instantiation like GENERAL, for the
+// same reason: the code of the other layout is not there to be allocated for.
+template <int N1D, int BASIS = 0, bool GENERAL = (N1D == 4), bool SHIFTED = true>
 __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhRows Rw, const double *__restrict__ mt, const int n_owned)
 {
   static_assert(N1D >= 2 && N1D <= 4, "the row kernel is written for degree 1 .. 3");
@@ -1057,7 +1059,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   auto last_column = [&](int c) { return Cbuf[digit_c(lane, c) * 4 + 3] * Sbuf[digits_t(lane, c) * 16 + 15]; };
 
   // ================= P3: carry into the own block's piece ==========================================================
-  const bool shifted = P.diag_first != 0;
+  constexpr bool shifted = SHIFTED;
   double carry_own = 0.0;
   if constexpr (SMALL)
     { // streamed kinds: S and C of every interior face now (P4 takes W over), kept until the rows are streamed out
