@@ -490,14 +490,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             constexpr int a = a_;
             lc_ = asel == a ? Lc[a] : lc_;
           });
+          // (both tensors updated, one with a zero factor: "if (c == 1) accN[1] else accN[0]" became an array indexed by a
+          // run-time value, i.e. scratch memory - twelve scratch loads / stores per face in the middle of the kernel)
+          const double l0 = c == 1 ? 0.0 : lc_, l1 = c == 1 ? lc_ : 0.0;
           for (int a = 0; a < NA; ++a)
             {
               const double mS = M2[0 * 64 + arow * 8 + a], mN = M2[1 * 64 + arow * 8 + a];
               accS[a] += lc_ * mS;
-              if (c == 1)
-                accN[1][a] += lc_ * mN;
-              else
-                accN[0][a] += lc_ * mN;
+              accN[0][a] += l0 * mN;
+              accN[1][a] += l1 * mN;
             }
         }
     };
