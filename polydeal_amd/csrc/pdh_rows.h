@@ -1480,38 +1480,65 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         for (int u = 0; u < 16; ++u)
           sc[u] = Sbuf[u * 16 + vt];
         const double next_carry = left ? last_column(c) : 0.0;
-        // rows: value = Cl[k_c(R)] * sc[u(R)]; shifted pieces: lane 0 stores the carry of row R instead (read from LDS as a
-        // broadcast - no VALU work besides the select); the row address is a scalar base + lane
-        double *carryv = diagv; // [64] carry of every row for this piece (P4 left the diagonal entries here for piece 0)
-        if (left && !first_piece)
-          carryv[lane] = carry;
-        PDH_WAVE_SYNC();
+        // rows: value = Cl[k_c(R)] * sc[u(R)].  Shifted pieces: lane 0 stores the carry of row R instead.  The carries of all
+        // rows sit in ONE register (lane R = row R: `carry` of the block before, or the diagonal entries P4 left in diagv
+        // for piece 0) and reach lane 0 through v_readlane / v_writelane - an LDS broadcast per row made every row wait for
+        // its own LDS round trip (a quarter of this phase).  The row address is a scalar base + lane.
+        const double cvec = first_piece ? diagv[lane] : carry;
+        const int cvec_lo = __double2loint(cvec), cvec_hi = __double2hiint(cvec);
         double *rowp = P.values + rbase + 64 * (int64_t)b; // uniform
-        auto rows = [&](auto c_) {
+        const uint32_t lane_off = (uint32_t)lane * 8u;
+        auto rows = [&, lane_off](auto c_, auto left_) {
           constexpr int cc = c_;
+          constexpr bool LEFT = left_;
+          const uint32_t loff = lane_off;
+          const double *rowrun = rowp;
           static_for<0, 64>([&](auto R_) {
             constexpr int R = R_;
             constexpr int kc = (R >> (2 * cc)) & 3;
             constexpr int k0 = R & 3, k1 = (R >> 2) & 3, k2 = (R >> 4) & 3;
             constexpr int u = cc == 0 ? (k1 + 4 * k2) : (cc == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
             double v = Cl[kc] * sc[u];
-            if (left)
+            if constexpr (LEFT)
               {
-                const double cin = carryv[R];
-                v = lane == 0 ? cin : v;
+                // (this compiler has no writelane builtin)
+                int lo_ = __double2loint(v), hi_ = __double2hiint(v);
+                const int slo = __builtin_amdgcn_readlane(cvec_lo, R), shi = __builtin_amdgcn_readlane(cvec_hi, R);
+                asm("v_writelane_b32 %0, %1, 0" : "+v"(lo_) : "s"(slo));
+                asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
+                v = __hiloint2double(hi_, lo_);
               }
 #if PDHR_EXP == 5
             if (P.n < 0)
 #endif
-              (rowp + (int64_t)R * rlen)[lane] = v;
+              {
+                // scalar row base + 32-bit lane offset (the compiler forms a 64-bit vector address per row otherwise)
+                const double *rp = rowrun; // (a running pointer: 64 precomputed row offsets would be spilled scalars)
+                const uint32_t lo32 = loff; // (named here: operands of an asm alone do not make the lambda capture)
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(v), "s"(rp) : "memory");
+              }
+            rowrun += rlen;
           });
         };
-        if (c == 0)
-          rows(std::integral_constant<int, 0>{});
-        else if (c == 1)
-          rows(std::integral_constant<int, 1>{});
+        using std::integral_constant;
+        if (left)
+          {
+            if (c == 0)
+              rows(integral_constant<int, 0>{}, std::true_type{});
+            else if (c == 1)
+              rows(integral_constant<int, 1>{}, std::true_type{});
+            else
+              rows(integral_constant<int, 2>{}, std::true_type{});
+          }
         else
-          rows(std::integral_constant<int, 2>{});
+          {
+            if (c == 0)
+              rows(integral_constant<int, 0>{}, std::false_type{});
+            else if (c == 1)
+              rows(integral_constant<int, 1>{}, std::false_type{});
+            else
+              rows(integral_constant<int, 2>{}, std::false_type{});
+          }
         PDH_WAVE_SYNC();
         carry = next_carry;
       }
