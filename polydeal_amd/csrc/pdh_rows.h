@@ -1233,8 +1233,6 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     double *T1B = W;                  // [4 arrays][2 bf][2 ks][64]
     double *T2B = W + 4 * 2 * 2 * 64; // [2 ks][4 cf][64]
     double *rowst = W;                // [16 rows][64 columns] (after stage 3)
-    double *carryo = W + 4 * 2 * 2 * 64 + 2 * 4 * 64; // [64] carry into the own piece (behind T1B / T2B)
-    carryo[lane] = carry_own;
     const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
     const int O = di + 4 * dj + 16 * dblk; // this lane's column in the D layout of stage 3
     pdhm::T1Off t1o;
@@ -1330,23 +1328,42 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               });
             });
             PDH_WAVE_SYNC();
-#pragma unroll 4
-            for (int r = 0; r < 16; ++r)
-              {
+            // row R: lane 0 takes column R (the diagonal entry), lane l >= 1 column l - 1 or l (the diagonal is skipped).
+            // Both candidate tile addresses of a lane do not depend on the row; the carry of row R comes out of lane R of
+            // carry_own by v_readlane and goes into lane 0 by v_writelane; scalar row pointer + 32-bit lane offset.
+            auto sw = [](int c_) { return (c_ & 48) | ((c_ + (c_ >> 4)) & 15); };
+            const int swA = sw(lane > 0 ? lane - 1 : 0), swB = sw(lane), lm1 = lane - 1;
+            const int co_lo = __double2loint(carry_own), co_hi = __double2hiint(carry_own);
+            const uint32_t loff4 = (uint32_t)lane * 8u;
+            const double *rowrun = P.values + rbase + (int64_t)(16 * k2) * rlen + L; // uniform
+            auto own_rows = [&](auto carry_) {
+              constexpr bool CARRY = carry_;
+              static_for<0, 16>([&](auto r_) {
+                constexpr int r = r_;
                 const int R = r + 16 * k2;
-                const int col = lane == 0 ? R : (lane - 1 + (lane - 1 >= R ? 1 : 0));
-                double v = rowst[r * 64 + ((col & 48) | ((col + (col >> 4)) & 15))];
-                if (m0 > 0)
+                int a = lm1 >= R ? swB : swA;
+                a = lane == 0 ? sw(R) : a;
+                double v = rowst[r * 64 + a];
+                if constexpr (CARRY)
                   {
-                    const double cin = carryo[R]; // broadcast read
                     if (lane == 0)
-                      {
-                        diagv[R] = v;
-                        v = cin;
-                      }
+                      diagv[R] = v; // kept for piece 0 (P5)
+                    int lo_ = __double2loint(v), hi_ = __double2hiint(v);
+                    const int slo = __builtin_amdgcn_readlane(co_lo, R), shi = __builtin_amdgcn_readlane(co_hi, R);
+                    asm("v_writelane_b32 %0, %1, 0" : "+v"(lo_) : "s"(slo));
+                    asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
+                    v = __hiloint2double(hi_, lo_);
                   }
-                P.values[rbase + (int64_t)R * rlen + L + lane] = v;
-              }
+                const double *rp = rowrun;
+                const uint32_t lo32 = loff4;
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(v), "s"(rp) : "memory");
+                rowrun += rlen;
+              });
+            };
+            if (m0 > 0)
+              own_rows(std::true_type{});
+            else
+              own_rows(std::false_type{});
           }
       }
   }
