@@ -273,7 +273,7 @@ static int upload(pdh_ctx *ctx, const V &h, const typename V::value_type **dptr)
   return upload_n(ctx, h.data(), h.size(), dptr);
 }
 
-extern "C" const char *pdh_version(void) { return "polydeal_hip 0.2 gfx950"; }
+extern "C" const char *pdh_version(void) { return "polydeal_hip 0.3 gfx950"; }
 
 extern "C" const char *pdh_last_error(const pdh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err_noctx.c_str(); }
 

@@ -1308,6 +1308,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               static_for<0, 4>([&](auto s0_) {
                 constexpr int s0 = s0_;
                 const int R = s0 + 4 * cf + 16 * k2;
+                // (a plain store, not the scalar-base asm of the other row stores: D3 comes straight out of the MFMA, and
+                // the hazard between an MFMA result and its reader is the compiler's to resolve - it cannot inside an asm)
                 P.values[rbase + (int64_t)R * rlen + L + O] = D3[cf][s0];
               });
             });
@@ -1432,6 +1434,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         thr[pc] = shifted ? pv - 1 - L : (1 << 30);
       });
       (void)total, (void)mis, (void)e, (void)nit;
+      const uint32_t loff5 = (uint32_t)lane * 8u;
 #pragma unroll 2
 #if PDHR_EXP == 1
       for (int R = 0; R < NF && P.n < 0; ++R)
@@ -1464,7 +1467,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
 #else
                 if (valid[pc])
 #endif
-                  rowp[pc * 64 + lane] = val;
+                  {
+                    const double *rp = rowp + pc * 64; // scalar base + 32-bit lane offset
+                    const uint32_t lo32 = loff5;
+                    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(val), "s"(rp) : "memory");
+                  }
               }
           });
         }
