@@ -1237,6 +1237,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     const int O = di + 4 * dj + 16 * dblk; // this lane's column in the D layout of stage 3
     pdhm::T1Off t1o;
     t1o.init(a0, a1);
+#ifdef PDHR_STAMP
+    long long tq1 = 0, tq2 = 0, tq3 = 0;
+#endif
 #pragma unroll 1
 #if PDHR_EXP == 2
     for (int k2 = 0; k2 < 4 && P.n < 0; ++k2)
@@ -1245,6 +1248,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
 #endif
       {
         PDH_WAVE_SYNC();
+#ifdef PDHR_STAMP
+        const long long ts0_ = (long long)__builtin_readcyclecounter();
+#endif
         if (act)
           static_for<0, 4>([&](auto ll_) {
             constexpr int ll = ll_;
@@ -1265,6 +1271,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             pdhm::t1b_store<2, ll>(T1B, t1o, n0);
             pdhm::t1b_store<3, ll>(T1B, t1o, n1);
           });
+#ifdef PDHR_STAMP
+        const long long ts1_ = (long long)__builtin_readcyclecounter();
+        tq1 += ts1_ - ts0_;
+#endif
         int zero = 0;
         asm volatile("" : "+s"(zero));
         pdhm::ASet AE, AD, AF;
@@ -1301,6 +1311,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           PDH_WAVE_SYNC();
           pdhm::mstage3(AF, T2B, lane, D3);
         }
+#ifdef PDHR_STAMP
+        const long long ts2_ = (long long)__builtin_readcyclecounter();
+        tq2 += ts2_ - ts1_;
+#endif
         if (!shifted)
           { // ascending layout: the own block is aligned, a register is a complete row
             static_for<0, 4>([&](auto cf_) {
@@ -1340,12 +1354,19 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             const double *rowrun = P.values + rbase + (int64_t)(16 * k2) * rlen + L; // uniform
             auto own_rows = [&](auto carry_) {
               constexpr bool CARRY = carry_;
+              // all 16 tile reads first (one LDS round trip for the slab, not one per row)
+              double vr[16];
               static_for<0, 16>([&](auto r_) {
                 constexpr int r = r_;
                 const int R = r + 16 * k2;
                 int a = lm1 >= R ? swB : swA;
                 a = lane == 0 ? sw(R) : a;
-                double v = rowst[r * 64 + a];
+                vr[r] = rowst[r * 64 + a];
+              });
+              static_for<0, 16>([&](auto r_) {
+                constexpr int r = r_;
+                const int R = r + 16 * k2;
+                double v = vr[r];
                 if constexpr (CARRY)
                   {
                     if (lane == 0)
@@ -1358,7 +1379,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   }
                 const double *rp = rowrun;
                 const uint32_t lo32 = loff4;
-                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(v), "s"(rp) : "memory");
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(v), "s"(rp));
                 rowrun += rlen;
               });
             };
@@ -1367,7 +1388,18 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             else
               own_rows(std::false_type{});
           }
+#ifdef PDHR_STAMP
+        tq3 += (long long)__builtin_readcyclecounter() - ts2_;
+#endif
       }
+#ifdef PDHR_STAMP
+    if (lane == 0 && Rw.stamps)
+      {
+        Rw.stamps[(int64_t)slot * 16 + 8] = tq1;
+        Rw.stamps[(int64_t)slot * 16 + 9] = tq2;
+        Rw.stamps[(int64_t)slot * 16 + 10] = tq3;
+      }
+#endif
   }
 
   PDHR_MARK(5);

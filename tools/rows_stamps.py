@@ -39,7 +39,10 @@ for k, nm in enumerate(names):
 for k, nm in ((8, "P2: issue of the next chunk's loads"), (9, "P2: record phase"), (10, "P2: MFMA steps"), (11, "P2: flush + expansion"),
               (12, "P2 (tensor rules): lane tasks"), (13, "P2 (tensor rules): per-face sums + expansion")):
     print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
-if not (basis == "dgq" and degree == 3):
+if basis == "dgq" and degree == 3:
+    for k, nm in ((8, "P4: stage 1 (a2, VALU)"), (9, "P4: stages 2 + 3 (MFMA, three groups)"), (10, "P4: rows of the own block")):
+        print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
+else:
     for k, nm in ((8, "P4 (FE_AggloDGP): stage 1"), (9, "P4 (FE_AggloDGP): stage 2"), (10, "P4 (FE_AggloDGP): stage 3")):
         print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
 span = out[:, 6].max() - out[:, 0].min()
