@@ -1502,7 +1502,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   {
                     const double *rp = rowp + pc * 64; // scalar base + 32-bit lane offset
                     const uint32_t lo32 = loff5;
-                    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(val), "s"(rp) : "memory");
+                    // (no "memory" clobber: nothing in this kernel reads the values back, and the LDS reads of the next
+                    // pieces may move across the store)
+                    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(val), "s"(rp));
                   }
               }
           });
