@@ -1118,6 +1118,29 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       // work items (row (k0,k1), column j) -> the LDS copy of the block.
       double *T1 = W, *T2 = W + RK::T1;
       constexpr int NA2 = NA * NA, NC = RK::NC;
+      // stage-2 work items of this lane, one per round of 64: item q = (k1, pair (l1,l2), a0) does not depend on the slab -
+      // decoded once (offsets of its T1 rows, its table row and its T2 entry)
+      constexpr int S2R = (N1D * NS * NA + 63) / 64;
+      int s2_r0[S2R], s2_tp[S2R], s2_out[S2R];
+      static_for<0, S2R>([&](auto rr_) {
+        constexpr int rr = rr_;
+        const int q = lane + 64 * rr;
+        const int cc = q / NA, a0_ = q - NA * cc;
+        const int k1 = cc / NS, lp = cc - NS * k1; // lp = RK::pair(l1, l2)
+        int l1, l2;
+        if constexpr (BASIS == 0)
+          l2 = lp / N1D, l1 = lp - N1D * l2;
+        else
+          {
+            l2 = 0, l1 = lp;
+            for (int w_ = N1D; l1 >= w_ && w_ > 0; --w_)
+              l1 -= w_, ++l2;
+          }
+        const bool ok = k1 < N1D && l1 < N1D && l2 < N1D;
+        s2_tp[rr] = ok ? (k1 * N1D + l1) * M::RS : 0;
+        s2_r0[rr] = ok ? l2 * NA2 + a0_ * NA : 0;
+        s2_out[rr] = ok ? cc * NA + a0_ : 0;
+      });
       const double s00 = ih0 * ih0, s11 = ih1 * ih1, s22 = ih2 * ih2;
 #ifdef PDHR_STAMP
       long long tp1 = 0, tp2 = 0, tp3 = 0;
@@ -1157,22 +1180,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           PDHR_ACC(tp1);
           const int nk1 = BASIS == 0 ? N1D : N1D - k2; // values of k1 (and, below, rows (k0, k1)) of this slab
           const long long t1_ = (long long)__builtin_readcyclecounter();
-          for (int q = lane; q < nk1 * NS * NA; q += 64)
+          static_for<0, S2R>([&](auto rr_) {
+            constexpr int rr = rr_;
+            if (lane + 64 * rr < nk1 * NS * NA)
             {
-              const int cc = q / NA, a0_ = q - NA * cc;
-              const int k1 = cc / NS, lp = cc - NS * k1; // lp = RK::pair(l1, l2)
-              int l1, l2;
-              if constexpr (BASIS == 0)
-                l2 = lp / N1D, l1 = lp - N1D * l2;
-              else
-                {
-                  l2 = 0, l1 = lp;
-                  for (int w_ = N1D; l1 >= w_; --w_)
-                    l1 -= w_, ++l2;
-                }
-              const int tp = (k1 * N1D + l1) * M::RS;
-              const double *r0 = T1 + (0 * N1D + l2) * NA2 + a0_ * NA, *r1 = r0 + N1D * NA2, *r2 = r0 + 2 * N1D * NA2,
-                           *r3 = r0 + 3 * N1D * NA2;
+              const int tp = s2_tp[rr], cc_a = s2_out[rr];
+              const double *r0 = T1 + s2_r0[rr], *r1 = r0 + N1D * NA2, *r2 = r0 + 2 * N1D * NA2, *r3 = r0 + 3 * N1D * NA2;
               double sD = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, sF = 0.0;
               static_for<0, NA>([&](auto a_) {
                 constexpr int a = a_;
@@ -1183,10 +1196,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 s3 += f * r3[a];
                 sF += e * r2[a];
               });
-              T2[(0 * NC + cc) * NA + a0_] = s00 * sD;
-              T2[(1 * NC + cc) * NA + a0_] = s11 * s1 + s2 + ih1 * s3;
-              T2[(2 * NC + cc) * NA + a0_] = ih0 * sF;
+              T2[0 * NC * NA + cc_a] = s00 * sD;
+              T2[1 * NC * NA + cc_a] = s11 * s1 + s2 + ih1 * s3;
+              T2[2 * NC * NA + cc_a] = ih0 * sF;
             }
+          });
           PDH_WAVE_SYNC();
           const long long t2_ = (long long)__builtin_readcyclecounter();
 #ifdef PDHR_STAMP
