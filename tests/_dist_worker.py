@@ -18,7 +18,11 @@ from polydeal_amd.partition import row_range  # noqa: E402
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    grid = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 3)
+    stacked = os.environ.get("PDH_DIST_STACK") == "1"
+    if stacked:  # the mesh of bench.py's weak-scaling mode: one unit cube per rank, stacked along z, ONE connected problem
+        grid = pa.BackgroundGrid.subdivided_hyper_rectangle(3, (4, 4, 4 * world), (0.0, 0.0, 0.0), (1.0, 1.0, float(world)))
+    else:
+        grid = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 3)
     ah = pa.AgglomerationHandler(grid)
     ah.define_block_agglomerates(2)
     fe = pa.FE_AggloDGP(3, 2)
@@ -69,6 +73,14 @@ def main():
     lof = loc.local_of()
     assert np.array_equal(la["dof_offset"], ga["dof_offset"][lof])
     assert np.array_equal(la["agg_rank"] == rank, (la["dof_offset"] >= r0) & (la["dof_offset"] < r1))
+    if stacked:
+        # slab r = rank r's rows: the local description names only the neighbouring slab(s) as ghosts, and qualifies for the
+        # row kernel (host-only eligibility test: planar faces, tensor rules found on the points)
+        assert ah.n_agglomerates == 8 * world and r1 - r0 == 8 * n
+        n_ghost = int(loc.c.n_agg) - 8
+        assert n_ghost == (4 if rank in (0, world - 1) else 8) or world == 1, n_ghost
+        lib.pdh_check_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        assert lib.pdh_check_rows(C.byref(loc.c), r0, r1) == 1, lib.pdh_last_error(None)
     # ghost-block exchange variant: what this rank sends to a peer is what the peer expects from it (block order is derived
     # on both sides from the global dof numbers of the cut faces; only the sizes can be checked without a GPU)
     sc, rc_ = (C.c_int64 * world)(), (C.c_int64 * world)()

@@ -29,3 +29,15 @@ def test_two_rank_gloo():
         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "DIST_OK world=2" in out.stdout
+
+
+def test_two_rank_gloo_stacked_mesh():
+    """The mesh of bench.py's weak-scaling mode (N unit cubes stacked along z, slab r = rank r) through the same worker."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", PDH_DIST_STACK="1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+         "127.0.0.1", "--master-port", "29533", os.path.join(root, "tests", "_dist_worker.py")],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "DIST_OK world=2" in out.stdout
