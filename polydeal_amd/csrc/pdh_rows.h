@@ -1064,6 +1064,95 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double carry_own = 0.0;
   if constexpr (SMALL)
     { // streamed kinds: S and C of every interior face now (P4 takes W over), kept until the rows are streamed out
+      // Uniform neighbourhoods (every neighbour's box agrees with the own one in both tangential directions of the shared
+      // face - block agglomerates): no per-face tables are needed, and the two contraction stages run for ALL faces in
+      // lock-step (two hand-offs per polytope instead of five per face).
+      bool all_same = nfaces - n_bdry <= MAXF;
+      for (int t = n_bdry; t < nfaces; ++t)
+        {
+          const int c = rl_i(t_axis, t);
+          const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
+          const double q0 = rl_d(t_qlo0, t), q1 = rl_d(t_qlo1, t), q2 = rl_d(t_qlo2, t);
+          const double i0 = rl_d(t_qih0, t), i1 = rl_d(t_qih1, t), i2 = rl_d(t_qih2, t);
+          all_same = all_same && sel3(ti, q0, q1, q2) == sel3(ti, lo0, lo1, lo2) && sel3(ti, i0, i1, i2) == sel3(ti, ih0, ih1, ih2) &&
+                     sel3(tj, q0, q1, q2) == sel3(tj, lo0, lo1, lo2) && sel3(tj, i0, i1, i2) == sel3(tj, ih0, ih1, ih2);
+        }
+      if (all_same)
+        {
+          const int nint = nfaces - n_bdry;
+          PDH_WAVE_SYNC();
+          {
+            // T_f[(k_j,l_j)][alpha] = sum_beta E[(k_j,l_j)][beta] M2c_f[alpha][beta], every face; T_f at W + 128 f
+            const int pair = lane & 15, kj_ = pair >> 2, lj_ = pair & 3;
+            const int pairT = (kj_ < N1D && lj_ < N1D) ? kj_ * N1D + lj_ : 0;
+            double ej[NA];
+            for (int b = 0; b < NA; ++b)
+              ej[b] = tabE[pairT * M::RS + b];
+            for (int f = 0; f < nint; ++f)
+              {
+                const double *m2 = M2c + f * MS;
+                static_for<0, 2>([&](auto h_) {
+                  constexpr int h = h_;
+                  const int al = (lane >> 4) + 4 * h;
+                  if (al < NA)
+                    {
+                      double sm = 0.0;
+                      for (int b = 0; b < NA; ++b)
+                        sm += ej[b] * m2[al * 8 + b];
+                      W[f * 128 + pair * 8 + al] = sm;
+                    }
+                });
+              }
+          }
+          PDH_WAVE_SYNC();
+          {
+            const int pairI = lane & 15, ki = pairI >> 2, li = pairI & 3;
+            const int pairIT = (ki < N1D && li < N1D) ? ki * N1D + li : 0;
+            double ei[NA];
+            for (int a = 0; a < NA; ++a)
+              ei[a] = tabE[pairIT * M::RS + a];
+            for (int f = 0; f < nint; ++f)
+              static_for<0, 4>([&](auto r_) {
+                constexpr int r = r_;
+                const int pairJ = (lane >> 4) + 4 * r, kj = pairJ >> 2, lj = pairJ & 3;
+                double sm = 0.0;
+                for (int a = 0; a < NA; ++a)
+                  sm += ei[a] * W[f * 128 + pairJ * 8 + a];
+                const bool okk = ki < N1D && kj < N1D && (BASIS == 0 || ki + kj < N1D);
+                const bool okl = li < N1D && lj < N1D && (BASIS == 0 || li + lj < N1D);
+                if (okk && okl)
+                  M2c[f * MS + RK::pair(ki, kj) * NS + RK::pair(li, lj)] = sm;
+              });
+            // C of every face: lanes = (face, k, l)
+            for (int r = 0; r < 2; ++r)
+              {
+                const int id = lane + 64 * r, f = id >> 4, kl = id & 15;
+                const int src = n_bdry + (f < nint ? f : 0);
+                const int c = __shfl(t_axis, src);
+                const double x = __shfl(t_coord, src), sg = __shfl(t_nsign, src), sig = __shfl(t_sigma, src);
+                const double q0 = __shfl(t_qlo0, src), q1 = __shfl(t_qlo1, src), q2 = __shfl(t_qlo2, src);
+                const double i0 = __shfl(t_qih0, src), i1 = __shfl(t_qih1, src), i2 = __shfl(t_qih2, src);
+                if (f < nint)
+                  {
+                    const double lo_c = sel3(c, lo0, lo1, lo2), ih_c = sel3(c, ih0, ih1, ih2);
+                    const double loq_c = sel3(c, q0, q1, q2), ihq_c = sel3(c, i0, i1, i2);
+                    const double zp = (x - lo_c) * ih_c - 0.5, zq = (x - loq_c) * ihq_c - 0.5;
+                    const int k = kl >> 2, l = kl & 3;
+                    double vk = coefL[k * 4 + 3], dk = 0.0, vl = coefL[l * 4 + 3], dl = 0.0;
+                    for (int m = 2; m >= 0; --m)
+                      {
+                        dk = dk * zp + vk;
+                        vk = vk * zp + coefL[k * 4 + m];
+                        dl = dl * zq + vl;
+                        vl = vl * zq + coefL[l * 4 + m];
+                      }
+                    Call[f * 16 + kl] = (0.5 * sg * dk * ih_c - sig * vk) * vl - 0.5 * sg * vk * dl * ihq_c;
+                  }
+              }
+          }
+          PDH_WAVE_SYNC();
+        }
+      else
       for (int t = n_bdry; t < nfaces; ++t)
         {
           PDH_WAVE_SYNC();
