@@ -1191,9 +1191,15 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
       int nf = 0;
       for (size_t t : idx)
         for (const Plane &pl : planes[t])
+          // A boundary run with tensor sub-face rules is cut into pieces of at most 32 sub-faces: the kernel forms the moments
+          // of a piece in one batch of 64 lane tasks (2 per sub-face), and a corner polytope of 4^3 cells already has 48
+          // boundary sub-faces in its run.  Boundary pieces only add to the diagonal block's face tensors, so the cut
+          // changes nothing but the order of summation.  (An interior face is one entry: its coupling moments are one set.)
+          for (int64_t pc0 = 0, pcs = (K.run_nbr[t] < 0 && R.fq_tensor_n > 0) ? 32 * (int64_t)R.fq_tensor_n * R.fq_tensor_n : K.run_cnt[t];
+               pc0 < K.run_cnt[t]; pc0 += pcs)
           {
-            R.fr_pbeg.push_back(K.run_ap[t]);
-            R.fr_pcnt.push_back(K.run_cnt[t]);
+            R.fr_pbeg.push_back(K.run_ap[t] + pc0);
+            R.fr_pcnt.push_back((int32_t)std::min<int64_t>(pcs, K.run_cnt[t] - pc0));
             R.fr_nbr.push_back(K.run_nbr[t]);
             R.fr_axis.push_back(pl.axis);
             R.fr_blk.push_back(K.run_blk[t]);

@@ -1005,6 +1005,7 @@ ROWS_CASES = [
     # lg, block (0: mixed boxes), variant, diag_first, world
     (2, 2, "poisson", True, 1), (2, 2, "dr", False, 1), (3, 2, "adm", True, 3), (2, 1, "test", True, 1),
     (2, 0, "poisson", True, 1), (2, 0, "dr", False, 2), (1, 2, "poisson", True, 1),
+    (3, 4, "poisson", True, 1),  # 64 cells per polytope, 16 sub-faces per face: several batches of cells / lane tasks
 ]
 
 
