@@ -98,3 +98,61 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".h", ".cpp", ".hip")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "sip_ref" not in src, f
+
+
+def _rows_applies(flat, r0=0, r1=None):
+    lib = pa.load_library()
+    lib.pdh_check_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.pdh_last_error.restype = C.c_char_p
+    rc = lib.pdh_check_rows(C.byref(flat.c), r0, flat.c.n_rows if r1 is None else r1)
+    return rc, (lib.pdh_last_error(None) or b"").decode()
+
+
+@pytest.mark.parametrize("basis,p", [("dgq", 3), ("dgp", 3), ("dgq", 2), ("dgp", 2), ("dgq", 1), ("dgp", 1)])
+def test_row_kernel_eligibility_is_decided_on_the_quadrature_data(basis, p):
+    """pdh_check_rows (host only): the row kernel applies to agglomerates of Cartesian cells - planar faces and tensor rules
+    are recognised on the points - and refuses distorted cells, staircase faces, unstructured rules (for the kinds that need
+    tensor rules) and 2-D problems, saying why."""
+    def handler(dim, refine, groups=None, distort=0.0, nq=None):
+        grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, refine)
+        if distort:
+            grid.distort(distort, seed=2)
+        ah = pa.AgglomerationHandler(grid)
+        if groups is None:
+            ah.define_block_agglomerates(2)
+        else:
+            for g in groups:
+                ah.define_agglomerate(g)
+        fe = (pa.FE_DGQ if basis == "dgq" else pa.FE_AggloDGP)(dim, p)
+        ah.initialize_fe_values(nq or p + 1, nq or p + 1)
+        ah.distribute_agglomerated_dofs(fe)
+        return ah, fe
+
+    ah, fe = handler(3, 2)
+    flat = ah.flatten(pa.SipVariant.poisson_example(fe), True, False)
+    assert _rows_applies(flat)[0] == 1
+    n = fe.n_dofs_per_cell
+    assert _rows_applies(flat, 2 * n, 5 * n)[0] == 1           # a row range
+    # claims are verified, not believed; no claim = the library looks itself; negative = do not look
+    flat.c.vq_tensor_n, flat.c.fq_tensor_n = 7, 7
+    rc, why = _rows_applies(flat)
+    assert rc == (1 if p == 3 else 0) and (p == 3 or "tensor" in why)   # degree 3 has general-point paths
+    flat.c.vq_tensor_n, flat.c.fq_tensor_n = -1, -1
+    assert _rows_applies(flat)[0] == (1 if p == 3 else 0)
+    # distorted cells: faces are no longer planar to rounding
+    ah, fe = handler(3, 2, distort=1e-6)
+    rc, why = _rows_applies(ah.flatten(pa.SipVariant.poisson_example(fe), True, False))
+    assert rc == 0 and ("planar" in why or "axis-aligned" in why), why
+    # an L-shaped polytope touches a neighbour along two planes
+    grid = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 2)
+    cell = {tuple(int(round(v * 4)) for v in grid.cell_vertices(c)[0]): c for c in range(grid.n_cells)}
+    groups = [sorted([cell[(0, 0, 0)], cell[(1, 0, 0)], cell[(0, 1, 0)]]), sorted([cell[(1, 1, 0)], cell[(1, 1, 1)]])]
+    used = {c for g in groups for c in g}
+    groups += [[c] for c in range(grid.n_cells) if c not in used]
+    ah, fe = handler(3, 2, groups=groups)
+    rc, why = _rows_applies(ah.flatten(pa.SipVariant.poisson_example(fe), True, False))
+    assert rc == 0 and "plane" in why, why
+    # 2-D
+    ah, fe = handler(2, 3)
+    rc, why = _rows_applies(ah.flatten(pa.SipVariant.poisson_example(fe), True, False))
+    assert rc == 0 and "3-D" in why, why
