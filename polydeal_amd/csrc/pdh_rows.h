@@ -24,13 +24,24 @@
 //   store instruction writes positions 64 m .. 64 m + 63 of a row: lane 0 carries the last column of the block before
 //   (or the diagonal entry), lanes 1..63 the first 63 columns of block m.
 //
-// Phases (one wave, LDS region W is re-used from phase to phase):
-//   P1 volume moments on the f64 MFMA                       (MomentAcc of pdh_moment.h, unchanged)
+// Phases (one persistent wave per resident slot, LDS region W is re-used from phase to phase):
+//   P1 volume moments: tensor rules (found on the points by the host) -> three 1-D moment vectors per cell, outer product
+//      per lane; general points -> moment GEMM on the f64 MFMA (MomentAcc of pdh_moment.h)
 //   P2 per face: 2-D moments (weights: w sigma, -w n_c/2 for the diagonal block in P's frame; w for the coupling block in
-//      the per-direction shorter frame F, see pdh_moment.h), expansion into this lane's rows of the S / N_c tensors
+//      the per-direction shorter frame F, see pdh_moment.h), expansion into this lane's rows of the S / N_c tensors;
+//      tensor sub-face rules -> all faces as one batch of lane tasks, general points -> 2 MFMA per 4 points
 //   P3 carry into the own block's piece: last column of the block left of it
 //   P4 diagonal block: three-stage contraction on the MFMA (pdh_moment.h), rows written slab by slab
 //   P5 coupling blocks in ascending column order: tables -> S, C -> 64 products per lane -> stores
+// Instantiations: <N1D, BASIS, GENERAL, SHIFTED> - GENERAL = false drops the general-point paths (the host verified tensor
+// rules everywhere), SHIFTED = diagonal-first rows; both are facts of a resident problem, and keeping the other variant's
+// code out of the kernel is worth 5-10 % (register allocation).
+//
+// Row stores (P4 epilogue, P5): scalar row pointer + 32-bit lane offset written as inline asm (the compiler forms a 64-bit
+// vector address per row otherwise), carries moved from lane R to lane 0 by v_readlane / v_writelane.  An asm statement
+// is invisible to the compiler's hazard recogniser: these stores only ever take data produced by VALU / LDS
+// instructions and row pointers produced by SALU arithmetic, for which gfx950 needs no wait states; a store placed
+// directly behind an MFMA result would need them (the ascending-layout epilogue therefore keeps a plain store).
 #pragma once
 #include "pdh_moment.h"
 
