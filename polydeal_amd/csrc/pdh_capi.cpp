@@ -208,7 +208,22 @@ struct pdh_ctx
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int overlap = 1; // pdh_set_overlap
-  bool overlapped() const { return overlap && stream2 && (int64_t)n_diag_slots + n_items >= 8192; }
+  // (two streams pay for their fork / join events only when the kernels run for a while: by the size of the matrix)
+  static constexpr int64_t small_values = 16 << 20;
+  bool overlapped() const { return overlap && stream2 && (int64_t)n_diag_slots + n_items >= 8192 && n_values >= small_values; }
+  // Small problems are bound by the launches themselves (two kernels of a few microseconds each): the pair is captured
+  // into a hipGraph once per (problem, algorithm, stream) and replayed with ONE launch.  graph_state: 0 none yet, 1 ready,
+  // -1 capture failed on this problem (plain launches from then on).
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_state = 0, graph_alg = -1;
+  hipStream_t graph_stream = nullptr;
+  void drop_graph()
+  {
+    if (graph_exec)
+      (void)hipGraphExecDestroy(graph_exec);
+    graph_exec = nullptr;
+    graph_state = 0;
+  }
   bool profiling = false;
   std::vector<hipEvent_t> events; // 4 per profiled launch: before / after the diagonal kernel, before / after the coupling kernel
   size_t ev_used = 0;
@@ -250,6 +265,7 @@ static void free_problem(pdh_ctx *ctx)
   for (void *p : ctx->allocs)
     (void)hipFree(p);
   ctx->allocs.clear();
+  ctx->drop_graph();
   ctx->has_problem = false;
   ctx->d_ap_src = nullptr;
   ctx->d_bd_rng = nullptr;
@@ -1702,6 +1718,46 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
     }
   const bool ov = ctx->overlapped();
   hipStream_t sd = ctx->stream, so = ov ? ctx->stream2 : ctx->stream;
+  // launch-bound sizes: replay the captured pair (see pdh_ctx::graph_exec)
+  const bool graphable = !ctx->profiling && !ov && ctx->n_values < pdh_ctx::small_values;
+  if (graphable && ctx->graph_state == 1 && (ctx->graph_alg != ctx->algorithm || ctx->graph_stream != ctx->stream))
+    ctx->drop_graph();
+  if (graphable && ctx->graph_state == 1)
+    {
+      PDH_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+      return PDH_OK;
+    }
+  bool capturing = false;
+  if (graphable && ctx->graph_state == 0)
+    {
+      if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess)
+        capturing = true;
+      else
+        {
+          (void)hipGetLastError();
+          ctx->graph_state = -1;
+        }
+    }
+  auto end_capture = [&](bool ok) {
+    if (!capturing)
+      return;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (ok && e == hipSuccess && g && hipGraphInstantiate(&ctx->graph_exec, g, nullptr, nullptr, 0) == hipSuccess)
+      {
+        ctx->graph_state = 1;
+        ctx->graph_alg = ctx->algorithm;
+        ctx->graph_stream = ctx->stream;
+      }
+    else
+      {
+        (void)hipGetLastError();
+        ctx->graph_exec = nullptr;
+        ctx->graph_state = -1;
+      }
+    if (g)
+      (void)hipGraphDestroy(g);
+  };
   if (ov)
     {
       PDH_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -1710,25 +1766,44 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
   // diagonal blocks
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(e0, sd));
-  if (ctx->use_moment(0))
-    PDH_HIP(ctx, pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_diag_slots, sd));
-  else
-    PDH_HIP(ctx, fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_diag_slots, ctx->lds_diag, sd));
+  {
+    const hipError_t le = ctx->use_moment(0) ? pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_diag_slots, sd)
+                                             : fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_diag_slots,
+                                                  ctx->lds_diag, sd);
+    if (le != hipSuccess)
+      {
+        end_capture(false); // (a stream must not be left in capture mode)
+        return fail(ctx, PDH_EDEVICE, std::string("diagonal-block kernel: ") + hipGetErrorString(le));
+      }
+  }
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(e1, sd));
   // coupling blocks
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(f0, so));
-  if (ctx->use_moment(1))
-    PDH_HIP(ctx, pdh_launch_moment(n1d, 1, &ctx->dev, ctx->d_mtab, ctx->n_items, so));
-  else
-    PDH_HIP(ctx, fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, so));
+  {
+    const hipError_t le = ctx->use_moment(1) ? pdh_launch_moment(n1d, 1, &ctx->dev, ctx->d_mtab, ctx->n_items, so)
+                                             : fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, so);
+    if (le != hipSuccess)
+      {
+        end_capture(false);
+        return fail(ctx, PDH_EDEVICE, std::string("coupling-block kernel: ") + hipGetErrorString(le));
+      }
+  }
   if (ctx->profiling)
     PDH_HIP(ctx, hipEventRecord(f1, so));
   if (ov)
     {
       PDH_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
       PDH_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    }
+  if (capturing)
+    { // nothing ran yet: the launches above were recorded.  Replay them now - or, if the graph could not be built, launch plainly
+      end_capture(true);
+      if (ctx->graph_state == 1)
+        PDH_HIP(ctx, hipGraphLaunch(ctx->graph_exec, ctx->stream));
+      else
+        return pdh_assemble_device(ctx);
     }
   return PDH_OK;
 }
