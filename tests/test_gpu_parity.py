@@ -1133,3 +1133,49 @@ def test_poisson_sanity_check_02_on_gpu():
             v[ah.dof_indices(P)] = f(xs)
         out.append("Test with %s = %s" % (name, gc.fmt(float(v @ A @ v))))
     assert out == gc.golden_lines("poisson_sanity_check_02.output")[:-1]
+
+
+def test_small_problem_graph_replay_is_transparent():
+    """Launch-bound problems replay their two kernels from a hipGraph (pdh_capi.cpp: graph_exec): repeated assemblies, a change of
+    algorithm, a new problem on the same context and profiling (plain launches) must all give the same matrix."""
+    import polydeal_amd as pa
+
+    fe = po.FE_DGQ(2, 2)
+    ah = build(2, 3, 2, fe, 3)
+    var = po.variant_poisson_example(fe)
+    kw = flatten(ah, var)
+    ref = po.assemble_csr(ah, var)[2]
+    sc = np.max(np.abs(ref))
+    ctx = pa.Context(0)
+    ctx.set_problem(pa.Problem(**kw))
+    first = ctx.assemble()          # captures
+    assert np.max(np.abs(first - ref)) <= TOL * sc
+    for _ in range(3):              # replays
+        assert np.array_equal(ctx.assemble(), first)
+    ctx.set_profiling(True)         # plain launches with events
+    assert np.array_equal(ctx.assemble(), first)
+    ctx.set_profiling(False)
+    assert np.array_equal(ctx.assemble(), first)
+    # another problem on the same context: the old graph must be gone
+    fe2 = po.FE_AggloDGP(2, 3)
+    ah2 = build(2, 2, 2, fe2, 4, distort=0.1)
+    var2 = po.variant_poisson_example(fe2)
+    kw2 = flatten(ah2, var2)
+    ref2 = po.assemble_csr(ah2, var2)[2]
+    ctx.set_problem(pa.Problem(**kw2))
+    for _ in range(2):
+        got = ctx.assemble()
+        assert got.shape == ref2.shape and np.max(np.abs(got - ref2)) <= TOL * np.max(np.abs(ref2))
+    # 3-D, moment form <-> direct form on the same resident problem: the graph follows the algorithm
+    fe3 = po.FE_DGQ(3, 3)
+    ah3 = build(3, 2, 2, fe3, 4, distort=0.1)
+    var3 = po.variant_poisson_example(fe3)
+    kw3 = flatten(ah3, var3)
+    ref3 = po.assemble_csr(ah3, var3)[2]
+    ctx.set_problem(pa.Problem(**kw3))
+    for alg in ("moment", "direct", "moment", "auto"):
+        ctx.set_algorithm(alg)
+        for _ in range(2):
+            got = ctx.assemble()
+            assert np.max(np.abs(got - ref3)) <= TOL * np.max(np.abs(ref3)), alg
+    ctx.close()
