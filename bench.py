@@ -7,10 +7,10 @@ examples/poisson.cc:1099-1103).  Workload = BASELINE.json configs[2]: unit cube,
 mesh, 32^3 = 32 768 polytopes of 2x2x2 cells, p = 3, QGauss(4) cell and face rules (examples/poisson.cc:
 702-709), SIP variant of examples/poisson.cc.  Headline FE is FE_DGQ(3) ((p+1)^3 = 64 dofs/polytope,
 2 097 152 dofs); the FE_AggloDGP(3) number (20 dofs/polytope, what poisson.cc instantiates) is reported
-under "extra".  N > 1 (one rank per GPU): weak scaling by default - the mesh is N such cubes stacked along z
-(subdivided_hyper_rectangle, 64 x 64 x 64N cells, ONE connected problem), rank r owns the polytopes (matrix rows) of
-slab r and describes only them and their ghost neighbours; `--scaling strong` splits the N = 1 problem into N row
-ranges instead.  Either way every rank owns its rows outright (owner-computes-rows): the data path has no collective.
+under "extra".  N > 1 (one rank per GPU): STRONG scaling by default (BASELINE.json north_star: ">= 6x strong scaling to
+8 GPUs") - the N = 1 problem split into N contiguous row ranges of whole polytopes, every rank describing only its own
+polytopes and their ghost neighbours; `--scaling weak` stacks N such cubes along z instead (subdivided_hyper_rectangle,
+64 x 64 x 64N cells, ONE connected problem, rank r owns slab r).  Either way every rank owns its rows outright (owner-computes-rows): the data path has no collective.
 
 Prints ONE JSON line on rank 0.
 """
@@ -28,12 +28,16 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measur
 
 
 def algorithmic_work(flat, n, owned=None):
-    """flops and compulsory HBM bytes, split per kernel.
-    volume 2 d Nq n^2 per polytope; interior face 24 Nqf n^2 (12 of them in the two diagonal blocks,
-    12 in the two coupling blocks); boundary face 6 Nqf n^2.  Bytes: every CSR value written once
-    + quadrature data read once (8 (d+1) per volume point, 8 (2d+1) per face point per side).
+    """flops and compulsory HBM bytes of one pass.
+    flops: volume 2 d Nq n^2 per polytope; interior face 24 Nqf n^2 (12 of them in the two diagonal blocks, 12 in the two
+    coupling blocks); boundary face 6 Nqf n^2.
+    bytes: every CSR value written once (8 n^2 (1 + #nbrs) per polytope) + quadrature data read ONCE: 8 (d+1) per volume point,
+    8 (2d+1) per face point - an interior face counts once, not once per side - + the small tables of 8(d) (16 d bbox, 4 per
+    sub-cell, 16 per face, 4 per block offset).  `bytes_total` is that figure for the whole pass (what a single-launch
+    algorithm - the row kernel - is charged with); `bytes[k]` are the compulsory bytes of the diagonal-block / coupling-block
+    launch of the two-kernel algorithms, each of which has to read the face data it works on itself.
     `owned` (rank-local descriptions): mask of the polytopes whose rows this rank writes - a face cut by the partition
-    then counts with its owned side only (one diagonal-block contribution, one coupling block)."""
+    then counts with its owned side only (one diagonal-block contribution, one coupling block; its points read once)."""
     import numpy as np
     c = flat.c
     d = c.dim
@@ -43,23 +47,34 @@ def algorithmic_work(flat, n, owned=None):
     cnt = np.diff(fq_ptr).astype(np.float64) if fq_ptr is not None else np.zeros(0)
     n2 = float(n) * n
     if not c.n_faces:
-        sides_pts = bdr_pts = 0.0
-        n_blocks = 0
+        sides_pts = bdr_pts = int_pts = 0.0
+        n_blocks = 0.0
+        n_faces_read = 0.0
     else:
         interior = arr["face_out"] >= 0
         if owned is None:
             sides = np.where(interior, 2.0, 0.0)  # owned sides of every interior face
+            bdr = ~interior
         else:
             sides = np.where(interior, owned[arr["face_in"]].astype(np.float64) + owned[np.maximum(arr["face_out"], 0)], 0.0)
+            bdr = (~interior) & owned[arr["face_in"]]
         sides_pts = float((cnt * sides).sum())     # face points x owned sides
-        bdr_pts = float(cnt[~interior].sum())
+        int_pts = float(cnt[sides > 0].sum())      # points of the interior faces this rank works on, once each
+        bdr_pts = float(cnt[bdr].sum())
         n_blocks = float(sides.sum())              # coupling blocks written
+        n_faces_read = float((sides > 0).sum() + bdr.sum())
     n_own = c.n_agg if owned is None else int(owned.sum())
-    fl_diag = 2.0 * d * nq * n2 + 6.0 * sides_pts * n2 + 6.0 * bdr_pts * n2
+    nq_own = float(nq) if owned is None else float(np.diff(arr["vq_ptr"])[owned].sum())
+    fl_diag = 2.0 * d * nq_own * n2 + 6.0 * sides_pts * n2 + 6.0 * bdr_pts * n2
     fl_off = 6.0 * sides_pts * n2
-    by_diag = 8.0 * n2 * n_own + 8.0 * (d + 1) * nq + 8.0 * (2 * d + 1) * (sides_pts + bdr_pts)
-    by_off = 8.0 * n2 * n_blocks + 8.0 * (2 * d + 1) * sides_pts
-    return dict(flops=[fl_diag, fl_off], bytes=[by_diag, by_off])
+    sub_cells = nq_own / float(max(1, (c.degree + 1) ** d))  # informational: 4 B of sub-cell map per cell (QGauss(p+1) rules)
+    tables = (16.0 * d + 4.0) * n_own + 4.0 * sub_cells + 16.0 * n_faces_read + 4.0 * n_blocks
+    by_diag = 8.0 * n2 * n_own + 8.0 * (d + 1) * nq_own + 8.0 * (2 * d + 1) * (int_pts + bdr_pts) + tables
+    by_off = 8.0 * n2 * n_blocks + 8.0 * (2 * d + 1) * int_pts
+    by_total = 8.0 * n2 * (n_own + n_blocks) + 8.0 * (d + 1) * nq_own + 8.0 * (2 * d + 1) * (int_pts + bdr_pts) + tables
+    return dict(flops=[fl_diag, fl_off], bytes=[by_diag, by_off], bytes_total=by_total,
+                bytes_parts={"values": 8.0 * n2 * (n_own + n_blocks), "volume_qdata": 8.0 * (d + 1) * nq_own,
+                             "face_qdata": 8.0 * (2 * d + 1) * (int_pts + bdr_pts), "tables": tables})
 
 
 def make_variant(pa, name, fe):
@@ -157,6 +172,11 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stats = ctx.stats()
+    nnz = int(stats["n_values"])  # values of the rows this rank owns; the matrix has the sum over ranks
+    if world > 1:
+        tn = torch.tensor([float(nnz)], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+        dist.all_reduce(tn)
+        nnz = int(round(float(tn.item())))
     mfma = ctx.kernel_work()
     own_mask = None
     if world > 1:
@@ -199,7 +219,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
         except Exception as exc:  # the measured default path above must not be lost to a failure of the extra variant
             ghost = {"error": repr(exc)}
     return dict(n_dofs=ah.n_dofs, n_agg=n_agg, n=n, dt=dt, kms=kms, nl=nl, stats=stats, work=work, mfma=mfma,
-                t_setup=t_setup, nnz=flat.nnz if world == 1 else None, checksum=chk, alg=alg_used, dt_overlap=dt_overlap,
+                t_setup=t_setup, nnz=nnz, checksum=chk, alg=alg_used, dt_overlap=dt_overlap,
                 ghost=ghost, local=world > 1, aux=aux, setup_parts=setup_parts)
 
 
@@ -369,9 +389,9 @@ def main():
     ap.add_argument("--fe", choices=["dgq", "dgp"], default="dgq")
     ap.add_argument("--variant", choices=["poisson", "diffusion_reaction", "assemble_dg_matrix"], default="poisson",
                     help="caller variant (penalty / face ownership / reaction term), SURVEY.md 8(a)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = N cubes stacked along the last direction, one slab per rank (default); "
-                         "strong = the N = 1 problem split into N row ranges")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="N > 1: strong (default; BASELINE.json north_star asks for strong scaling to 8 GPUs) = the N = 1 problem "
+                         "split into N contiguous row ranges; weak = N cubes stacked along the last direction, one slab per rank")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary FE measurement")
     ap.add_argument("--general-points-extra", action="store_true",
                     help="also time the row kernel's general-point paths (quadrature declared unstructured); off by default: "
@@ -436,7 +456,8 @@ def main():
                  "value": r2["n_dofs"] / (r2["dt"] / args.steps), "ms_per_step": 1e3 * r2["dt"] / args.steps,
                  "algorithm": r2["alg"], "kernel_ms": {"diagonal_blocks": r2["kms"][0], "coupling_blocks": r2["kms"][1]}}
         if r2.get("work"):
-            by2 = sum(r2["work"]["bytes"])
+            # one launch writes everything (row kernel): SURVEY 8(d) bytes of the pass; two launches: each reads its own face data
+            by2 = r2["work"]["bytes_total"] if r2["alg"] == "rows" else sum(r2["work"]["bytes"])
             extra.update(algorithmic_bytes_per_step=by2, hbm_GBs=by2 / (r2["dt"] / args.steps) * 1e-9,
                          frac_of_hbm_peak=by2 / (r2["dt"] / args.steps) * 1e-9 / HBM_PEAK_GBS,
                          fp64_bound_ms=1e3 * sum(r2["work"]["flops"]) / (FP64_PEAK_TFLOPS * 1e12))
@@ -510,7 +531,8 @@ def main():
         ke = [kernel_entry(0), kernel_entry(1)]
         if r["alg"] == "rows":
             # ONE kernel writes every block of the rows (pdh_rows.h): its algorithmic bytes / flops are those of the whole step
-            tot_b, tot_f = (w["bytes"][0] + w["bytes"][1]) * frac_rows, (w["flops"][0] + w["flops"][1]) * frac_rows
+            # (values once, volume q-data once, every face's q-data ONCE)
+            tot_b, tot_f = w["bytes_total"] * frac_rows, (w["flops"][0] + w["flops"][1]) * frac_rows
             ke[0] = {"kernel": "k_rows", "kernel_ms": t_k[0] * 1e3, "algorithmic_flops_per_launch": tot_f,
                      "algorithmic_bytes_per_launch": tot_b, "algorithmic_TFLOPs": tot_f / t_k[0] * 1e-12,
                      "hbm_achieved_GBs": tot_b / t_k[0] * 1e-9, "traffic": tj.get("k_rows_bytes")}
@@ -519,6 +541,7 @@ def main():
                     "frac": ke[0]["hbm_achieved_GBs"] / HBM_PEAK_GBS, "traffic": ke[0]["traffic"],
                     "kernel_ms": ke[0]["kernel_ms"], "launches_timed": r["nl"],
                     "algorithmic_bytes_per_launch": ke[0]["algorithmic_bytes_per_launch"],
+                    "algorithmic_bytes_parts": {k: v * frac_rows for k, v in w["bytes_parts"].items()},
                     "algorithmic_flops_per_launch": ke[0]["algorithmic_flops_per_launch"],
                     "algorithm": "row kernel (pdh_rows.h): one wave per polytope writes all blocks of its 64 rows as whole 128-byte "
                                  "lines; planar axis-aligned faces -> rank-one face moments, Kronecker form C (x) S of the coupling "
@@ -548,7 +571,7 @@ def main():
                     "overlapped_ms_per_step": None if r["dt_overlap"] is None else 1e3 * r["dt_overlap"] / args.steps,
                     "overlap_note": "library default: the two kernels run concurrently on two streams (pdh_set_overlap); the timed "
                                     "region above serialises them so that kernel_ms are undisturbed per-kernel durations",
-                    "whole_step_GBs": (w["bytes"][0] + w["bytes"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-9,
+                    "whole_step_GBs": w["bytes_total"] * frac_rows / (r["dt"] / args.steps) * 1e-9,
                     "whole_step_algorithmic_TFLOPs": (w["flops"][0] + w["flops"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-12}
             if names[dom] in ("k_diag", "k_offdiag"):
                 # mixed form whose dominant kernel is a DIRECT (MFMA contraction) one: that kernel is bound by the f64 MFMA
@@ -598,7 +621,7 @@ def main():
                                       "FE_DGQ" if args.fe == "dgq" else "FE_AggloDGP", args.degree, r["n"],
                                       args.degree + 1, {"poisson": "examples/poisson.cc", "diffusion_reaction": "examples/diffusion_reaction.cc",
                                                         "assemble_dg_matrix": "PolyUtils::assemble_dg_matrix"}[args.variant],
-                                      r["n_dofs"], r["nnz"] if r["nnz"] is not None else -1),
+                                      r["n_dofs"], r["nnz"]),
                        "algorithm": r["alg"],
                        "parallelism": ("rows(polytopes) split in %d contiguous ranges" % world if args.scaling == "strong" or world == 1
                                        else "rank r owns the rows of slab r (%d polytopes per rank)" % (r["n_agg"] // world))

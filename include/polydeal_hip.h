@@ -232,7 +232,7 @@ int pdh_values_checksum(pdh_ctx *ctx, double *out4);
 /* Host-only: 1 if PDH_ALG_ROWS applies to this description / row range, 0 if not (pdh_last_error(NULL) says why). */
 int pdh_check_rows(const pdh_problem *problem, int32_t row_begin, int32_t row_end);
 int pdh_set_algorithm(pdh_ctx *ctx, int algorithm);
-int pdh_algorithm_in_use(pdh_ctx *ctx); /* PDH_ALG_DIRECT, PDH_ALG_MOMENT or PDH_ALG_MIXED for the resident problem, < 0 on error */
+int pdh_algorithm_in_use(pdh_ctx *ctx); /* PDH_ALG_DIRECT, PDH_ALG_MOMENT, PDH_ALG_MIXED or PDH_ALG_ROWS for the resident problem, < 0 on error */
 
 /* On large problems the two kernels of a step (diagonal blocks / coupling blocks: disjoint values, complementary
  * bottlenecks) run concurrently, the second on an internal stream forked from and joined into pdh_stream() - callers

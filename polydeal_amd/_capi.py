@@ -274,6 +274,16 @@ class Context:
         self._chk(self.lib.pdh_device_values(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def poison_values(self):
+        """Tests: overwrite the resident CSR values with NaN bit patterns (0xFF bytes), so that a value an assembly fails
+        to write is seen."""
+        ptr, n = self.device_values()
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.synchronize()
+        if hip.hipMemset(C.c_void_p(ptr), 0xFF, C.c_size_t(8 * n)) != 0 or hip.hipDeviceSynchronize() != 0:
+            raise PdhError(-1, "hipMemset of the values failed")
+
     def set_algorithm(self, alg):
         """'auto' | 'direct' (MFMA contraction over the points) | 'moment' (Legendre moments + sum factorisation)."""
         self._chk(self.lib.pdh_set_algorithm(self.h, {"auto": 0, "direct": 1, "moment": 2, "rows": 4}[alg]))

@@ -1683,7 +1683,7 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
   if (ctx->algorithm == PDH_ALG_MOMENT && !ctx->d_mtab)
     return fail(ctx, PDH_EUNSUPPORTED, "the moment form exists for 3-D bases of degree 1..3 only");
   if (ctx->algorithm == PDH_ALG_ROWS && !ctx->use_rows())
-    return fail(ctx, PDH_EUNSUPPORTED, "the row kernel needs 3-D FE_DGQ(3), axis-aligned planar faces and no exchange variant");
+    return fail(ctx, PDH_EUNSUPPORTED, "the row kernel does not apply to the resident problem (3-D FE_DGQ / FE_AggloDGP of degree 1 .. 3 on polytopes whose faces are unions of axis-aligned planes, no exchange variant; pdh_check_rows says why)");
   if (ctx->use_rows())
     { // one launch writes everything; reported as kernel 0, kernel 1 takes no time
       hipEvent_t r0 = nullptr, r1 = nullptr, z0 = nullptr, z1 = nullptr;

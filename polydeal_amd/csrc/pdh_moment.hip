@@ -77,34 +77,51 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
     constexpr int N = decltype(n1d_)::value, B = decltype(basis_)::value;
     if (P->n != pdhr::RowsKind<N, B>::NF)
       return;
-    constexpr size_t lds = pdhr::lds_doubles_rows<N, B>() * sizeof(double);
+    // MULTI instantiation (FE_DGQ(3), PdhRows::multi): the coupling-moment slots (one per interior plane entry) are sized for
+    // the resident problem
+    const bool multi = N == 4 && B == 0 && R->multi != 0;
+    const size_t lds = (pdhr::lds_doubles_rows<N, B>() + (multi ? (R->maxf - pdhr::MAXF) * pdhr::RowsKind<N, B>::SS : 0)) * sizeof(double);
     // resident single-wave workgroups per CU: by LDS (160 KB, handed out in granules of 1280 bytes - measured: 26 624 bytes
     // fit six times, 27 136 do not), at most 8 (two waves per SIMD at 256 VGPRs)
-    constexpr size_t granules = (lds + 1279) / 1280 * 1280;
-    constexpr int fit = (int)(160 * 1024 / granules) < 8 ? (int)(160 * 1024 / granules) : 8;
+    const size_t granules = (lds + 1279) / 1280 * 1280;
+    const int fit = (int)(160 * 1024 / granules) < 8 ? (int)(160 * 1024 / granules) : 8;
     const int per_cu = per_cu_env > 0 ? per_cu_env : fit;
     const int resident = cus * per_cu;
     const unsigned grid = (unsigned)(count < resident ? count : resident);
     // degree 3: the instantiation without general-point paths when the host verified tensor rules everywhere
     // (PdhRows::tensor_only, pdh_capi.cpp: rows_kind_applies)
-    auto go = [&](auto general_, auto shifted_) {
-      constexpr bool G = decltype(general_)::value, S = decltype(shifted_)::value;
-      hipLaunchKernelGGL((pdhr::k_rows<N, B, G, S>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
+    auto go = [&](auto general_, auto shifted_, auto multi_) {
+      constexpr bool G = decltype(general_)::value, S = decltype(shifted_)::value, MU = decltype(multi_)::value;
+      hipLaunchKernelGGL((pdhr::k_rows<N, B, G, S, MU>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
     };
     using std::true_type;
     using std::false_type;
     const bool general = N == 4 && !R->tensor_only, shifted = P->diag_first != 0;
+    if constexpr (N == 4 && B == 0)
+      if (multi)
+        {
+          if (general && shifted)
+            go(true_type{}, true_type{}, true_type{});
+          else if (general)
+            go(true_type{}, false_type{}, true_type{});
+          else if (shifted)
+            go(false_type{}, true_type{}, true_type{});
+          else
+            go(false_type{}, false_type{}, true_type{});
+          rc = hipGetLastError();
+          return;
+        }
     if constexpr (N == 4)
       {
         if (general && shifted)
-          go(true_type{}, true_type{});
+          go(true_type{}, true_type{}, false_type{});
         else if (general)
-          go(true_type{}, false_type{});
+          go(true_type{}, false_type{}, false_type{});
       }
     if (!general && shifted)
-      go(false_type{}, true_type{});
+      go(false_type{}, true_type{}, false_type{});
     else if (!general)
-      go(false_type{}, false_type{});
+      go(false_type{}, false_type{}, false_type{});
     rc = hipGetLastError();
   };
   using std::integral_constant;

@@ -159,11 +159,19 @@ __device__ __forceinline__ int digits_t(int i, int c)
 // the kernel at all, which the register allocation of the remaining phases feels.
 // SHIFTED: deal.II's diagonal-first rows (else ascending) - a compile-time fact of the instantiation like GENERAL, for the
 // same reason: the code of the other layout is not there to be allocated for.
-template <int N1D, int BASIS = 0, bool GENERAL = (N1D == 4), bool SHIFTED = true>
+// MULTI (FE_DGQ(3) only): the interface with a neighbour may span SEVERAL planes - "staircase" faces of METIS-like agglomerates of
+// Cartesian cells (reference examples/poisson.cc:543-566 partitions the cell graph; source/agglomeration_handler.cc:1129-1165
+// collects all sub-faces shared with one neighbour into one polytopal face).  Every plane is one entry of the record; the
+// entries of a neighbour share its block, and the block is the SUM of their Kronecker products C_e (x) S_e.  The numbers of
+// entries per polytope (PdhRows::maxe, <= 48) and of interior entries (coupling-moment slots in LDS, PdhRows::maxf) are then
+// run-time facts of the resident problem, and the slots move to the end of the LDS allocation, sized at launch.  A separate
+// instantiation, so that the kernel of the block-shaped polytopes keeps its registers and its LDS footprint.
+template <int N1D, int BASIS = 0, bool GENERAL = (N1D == 4), bool SHIFTED = true, bool MULTI = false>
 __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhRows Rw, const double *__restrict__ mt, const int n_owned)
 {
   static_assert(N1D >= 2 && N1D <= 4, "the row kernel is written for degree 1 .. 3");
   static_assert(!GENERAL || N1D == 4, "general-point paths exist for degree 3 only");
+  static_assert(!MULTI || (N1D == 4 && BASIS == 0), "several planes per neighbour: FE_DGQ(3) only");
   using RK = RowsKind<N1D, BASIS>;
   constexpr bool SMALL = RK::SMALL;
   constexpr int MS = RK::SS; // doubles per interior-face slot
@@ -176,11 +184,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   // LDS tables: once per wave (the kernel is persistent: a wave works through slots blockIdx.x, blockIdx.x + gridDim.x, ...)
   auto sel3 = [](int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); };
   double *tabE = lds, *tabD = lds + M::LTAB, *tabF = lds + 2 * M::LTAB;
-  double *M2c = lds + 3 * M::LTAB;  // [MAXF][8][8] coupling moments of every interior face
-  double *diagv = M2c + MAXF * MS;  // [64] diagonal entries A[R,R]
+  double *diagv = lds + 3 * M::LTAB + (MULTI ? 0 : MAXF * MS); // [64] diagonal entries A[R,R]
   double *Cbuf = diagv + (!SMALL ? 64 : 0); // [4][4]  (the streamed kinds have no diagv)
   double *coefL = Cbuf + 16;        // [4][4] monomial coefficients of the 1-D basis (centred variable)
   double *W = coefL + 16;           // phase-local
+  // [maxf][8][8] coupling moments of every interior entry: in front of diagv, or (MULTI) behind everything else
+  double *M2c = MULTI ? W + w_doubles_rows<N1D, BASIS>() : lds + 3 * M::LTAB;
+  const int maxf = MULTI ? Rw.maxf : MAXF, maxe = MULTI ? Rw.maxe : ROWS_MAXE;
   // streamed kinds only: behind W
   double *Call = W + w_doubles_rows<N1D, BASIS>(); // [MAXF][4][4] C of every interior face
   double *Dblk = Call + MAXF * 16;          // [n][n] diagonal block
@@ -215,18 +225,19 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   // used to cost three of them at the head of every polytope.
   struct Meta
   {
-    double e[ROWS_ENT]; // lanes 0 .. ROWS_MAXE-1: the face entry; lanes 16 .. 16+ROWS_HDR-1: e[0] = header value
+    double e[ROWS_ENT]; // lanes 0 .. maxe-1: the face entry; lanes maxe .. maxe+ROWS_HDR-1: e[0] = header value
   };
+  const int hb = maxe; // first header lane (maxe <= 48, pdh_capi.cpp: build_rows_tables)
   auto load_meta = [&](int s_) {
     Meta m;
-    const double *r = Rw.meta + (int64_t)s_ * ROWS_REC;
+    const double *r = Rw.meta + (int64_t)s_ * (ROWS_HDR + maxe * ROWS_ENT);
     for (int k = 0; k < ROWS_ENT; ++k)
       m.e[k] = 0.0;
-    if (lane < ROWS_MAXE)
+    if (lane < maxe)
       for (int k = 0; k < ROWS_ENT; ++k)
         m.e[k] = r[ROWS_HDR + lane * ROWS_ENT + k];
-    else if (lane < 16 + ROWS_HDR)
-      m.e[0] = r[lane - 16];
+    else if (lane < maxe + ROWS_HDR)
+      m.e[0] = r[lane - maxe];
     return m;
   };
   int slot = blockIdx.x;
@@ -246,13 +257,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   PDHR_MARK(0);
   PDH_WAVE_SYNC();
   // ---- decode this polytope's record; request the next one's
-  const double lo0 = rl_d(cur.e[0], 16 + 1), lo1 = rl_d(cur.e[0], 16 + 2), lo2 = rl_d(cur.e[0], 16 + 3);
-  const double ih0 = rl_d(cur.e[0], 16 + 4), ih1 = rl_d(cur.e[0], 16 + 5), ih2 = rl_d(cur.e[0], 16 + 6);
-  const int nfaces = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 0));
-  const int64_t rbase = __double_as_longlong(rl_d(cur.e[0], 16 + 7));
-  const int rlen = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 8));
-  const int L = (int)__double_as_longlong(rl_d(cur.e[0], 16 + 9));
-  const int64_t vq_b = __double_as_longlong(rl_d(cur.e[0], 16 + 10)), vq_e = __double_as_longlong(rl_d(cur.e[0], 16 + 11));
+  const double lo0 = rl_d(cur.e[0], hb + 1), lo1 = rl_d(cur.e[0], hb + 2), lo2 = rl_d(cur.e[0], hb + 3);
+  const double ih0 = rl_d(cur.e[0], hb + 4), ih1 = rl_d(cur.e[0], hb + 5), ih2 = rl_d(cur.e[0], hb + 6);
+  const int nfaces = (int)__double_as_longlong(rl_d(cur.e[0], hb + 0));
+  const int64_t rbase = __double_as_longlong(rl_d(cur.e[0], hb + 7));
+  const int rlen = (int)__double_as_longlong(rl_d(cur.e[0], hb + 8));
+  const int L = (int)__double_as_longlong(rl_d(cur.e[0], hb + 9));
+  const int64_t vq_b = __double_as_longlong(rl_d(cur.e[0], hb + 10)), vq_e = __double_as_longlong(rl_d(cur.e[0], hb + 11));
   const int m0 = !SMALL ? (L >> 6) : L / NF;
   // the face table of the polytope lives in the lanes (lane t = face t); a face's entries are read with v_readlane
   const long long pb_ = __double_as_longlong(cur.e[0]);
@@ -663,7 +674,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                     PDH_WAVE_SYNC();
                     expand(fp, M2);
                     const int fl = t - n_bdry;
-                    if (fp.nbr >= 0 && fl >= 0 && fl < MAXF)
+                    if (fp.nbr >= 0 && fl >= 0 && fl < maxf)
                       M2c[fl * MS + lane] = M2[2 * 64 + lane];
                     PDH_WAVE_SYNC();
                   }
@@ -717,7 +728,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                       }
                   }
                 const int fl = t - n_bdry;
-                if (nbr >= 0 && fl >= 0 && fl < MAXF)
+                if (nbr >= 0 && fl >= 0 && fl < maxf)
                   {
                     double Gc = 0.0;
                     for (int sb = 0; sb < ns; ++sb)
@@ -905,7 +916,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 if (pass == 0)
                   expand(fp, M2);
                 const int fl = t - n_bdry;
-                if (fp.nbr >= 0 && (pass == 1 || !fp.sep) && fl >= 0 && fl < MAXF)
+                if (fp.nbr >= 0 && (pass == 1 || !fp.sep) && fl >= 0 && fl < maxf)
                   M2c[fl * MS + lane] = M2[2 * 64 + lane];
                 PDH_WAVE_SYNC();
                 PDHR_ACC(tm_flush);
@@ -1176,7 +1187,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         {
           PDH_WAVE_SYNC();
           build_S(t);
-          carry_own = last_column(rl_i(t_axis, t));
+          // (MULTI: the block left of the own one may be the sum over several planes)
+          carry_own = (MULTI ? carry_own : 0.0) + last_column(rl_i(t_axis, t));
         }
 
   PDHR_MARK(4);
@@ -1336,9 +1348,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
 #ifdef PDHR_STAMP
       if (lane == 0 && Rw.stamps)
         {
-          Rw.stamps[(int64_t)slot * 16 + 8] = tp1;
-          Rw.stamps[(int64_t)slot * 16 + 9] = tp2;
-          Rw.stamps[(int64_t)slot * 16 + 10] = tp3;
+          Rw.stamps[(int64_t)slot * 16 + 7] = tp1; // (slots 8 .. 13 belong to P2)
+          Rw.stamps[(int64_t)slot * 16 + 14] = tp2;
+          Rw.stamps[(int64_t)slot * 16 + 15] = tp3;
         }
 #endif
     }
@@ -1509,9 +1521,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
 #ifdef PDHR_STAMP
     if (lane == 0 && Rw.stamps)
       {
-        Rw.stamps[(int64_t)slot * 16 + 8] = tq1;
-        Rw.stamps[(int64_t)slot * 16 + 9] = tq2;
-        Rw.stamps[(int64_t)slot * 16 + 10] = tq3;
+        Rw.stamps[(int64_t)slot * 16 + 7] = tq1; // (slots 8 .. 13 belong to P2)
+        Rw.stamps[(int64_t)slot * 16 + 14] = tq2;
+        Rw.stamps[(int64_t)slot * 16 + 15] = tq3;
       }
 #endif
   }
@@ -1624,6 +1636,106 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           });
         }
     }
+  else if constexpr (MULTI)
+  // ================= P5 (MULTI): coupling blocks in ascending column order, a block = sum over the planes of its neighbour ===
+  {
+    double carry = 0.0; // lane R: the value that lane 0 stores in row R of the next piece
+    bool first_left = true;
+    int t = n_bdry;
+#if PDHR_EXP == 1
+    while (t < nfaces && P.n < 0)
+#else
+    while (t < nfaces)
+#endif
+      {
+        const int b = rl_i(t_blk, t);
+        int te = t + 1;
+        while (te < nfaces && rl_i(t_blk, te) == b)
+          ++te; // entries [t, te): the planes shared with this neighbour
+        const bool left = shifted && b < m0;
+        const bool first_piece = left && first_left; // piece 0 starts with the diagonal entry (diagv, written in P4)
+        if (left)
+          first_left = false;
+        // this lane's column of the block: shifted pieces hold columns -1 .. 62 (lane 0: the carry)
+        const int jcol = left ? (lane > 0 ? lane - 1 : 0) : lane;
+        // acc[R] = sum_e C_e[k_c(R), l_c(j)] S_e[u(R), v(j)]: one register per row, the planes one after the other (a
+        // single plane takes the same path: one pass of multiply-adds into zeros instead of the fused multiply + store of the
+        // block-shaped kernel - this instantiation serves irregular agglomerates, where most neighbours span several planes)
+        double acc[64];
+        static_for<0, 64>([&](auto R_) { acc[R_] = 0.0; });
+        double next_carry = 0.0;
+        for (int e = t; e < te; ++e)
+          {
+            PDH_WAVE_SYNC();
+            build_S(e);
+            const int c = rl_i(t_axis, e);
+            const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
+            double Cl[4], sc[16];
+            for (int k = 0; k < 4; ++k)
+              Cl[k] = Cbuf[k * 4 + lc];
+            for (int u = 0; u < 16; ++u)
+              sc[u] = Sbuf[u * 16 + vt];
+            if (left)
+              next_carry += last_column(c);
+            auto add = [&](auto c_) {
+              constexpr int cc = c_;
+              static_for<0, 64>([&](auto R_) {
+                constexpr int R = R_;
+                constexpr int kc = (R >> (2 * cc)) & 3;
+                constexpr int k0 = R & 3, k1 = (R >> 2) & 3, k2 = (R >> 4) & 3;
+                constexpr int u = cc == 0 ? (k1 + 4 * k2) : (cc == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
+                acc[R] += Cl[kc] * sc[u];
+              });
+            };
+            using std::integral_constant;
+            if (c == 0)
+              add(integral_constant<int, 0>{});
+            else if (c == 1)
+              add(integral_constant<int, 1>{});
+            else
+              add(integral_constant<int, 2>{});
+          }
+        // rows out: as in the single-plane kernel below (carries through v_readlane / v_writelane, scalar row base)
+        const double cvec = first_piece ? diagv[lane] : carry;
+        const int cvec_lo = __double2loint(cvec), cvec_hi = __double2hiint(cvec);
+        double *rowp = P.values + rbase + 64 * (int64_t)b; // uniform
+        const uint32_t lane_off = (uint32_t)lane * 8u;
+        auto rows = [&, lane_off](auto left_) {
+          constexpr bool LEFT = left_;
+          const uint32_t loff = lane_off;
+          const double *rowrun = rowp;
+          static_for<0, 64>([&](auto R_) {
+            constexpr int R = R_;
+            double v = acc[R];
+            if constexpr (LEFT)
+              {
+                int lo_ = __double2loint(v), hi_ = __double2hiint(v);
+                const int slo = __builtin_amdgcn_readlane(cvec_lo, R), shi = __builtin_amdgcn_readlane(cvec_hi, R);
+                asm("v_writelane_b32 %0, %1, 0" : "+v"(lo_) : "s"(slo));
+                asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
+                v = __hiloint2double(hi_, lo_);
+              }
+#if PDHR_EXP == 5
+            if (P.n < 0)
+#endif
+              {
+                const double *rp = rowrun;
+                const uint32_t lo32 = loff;
+                // (data from VALU results only - see the note on asm stores at the top of this file)
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(v), "s"(rp) : "memory");
+              }
+            rowrun += rlen;
+          });
+        };
+        if (left)
+          rows(std::true_type{});
+        else
+          rows(std::false_type{});
+        PDH_WAVE_SYNC();
+        carry = next_carry;
+        t = te;
+      }
+  }
   else
   // ================= P5: coupling blocks in ascending column order ====================================================
   {

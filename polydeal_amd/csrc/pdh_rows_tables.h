@@ -18,5 +18,10 @@ struct PdhRows
   int32_t fq_tensor_n;     // > 0: face points are verified tensor rules of this many points per direction on every sub-face
   int32_t vq_tensor_n;     // > 0: volume points are verified tensor rules of this many points per direction (else 0)
   int32_t tensor_only;     // 1: both kinds of rule are tensor rules and no face entry has more than 32 sub-faces
+  // MULTI instantiation (pdh_rows.h): polytopes whose interface with a neighbour spans several planes ("staircase" faces of
+  // METIS-like agglomerates of Cartesian cells), more than 6 interior plane entries or more than 16 entries in all
+  int32_t multi;           // 1: take the MULTI instantiation
+  int32_t maxe;            // face entries a record provides for (16 unless multi): record = 12 + 12 maxe doubles
+  int32_t maxf;            // interior entries (coupling-moment slots in LDS) a polytope may have (6 unless multi)
   long long *stamps;       // [n_owned][16] s_memtime at the phase boundaries; written by -DPDHR_STAMP builds only
 };

@@ -36,14 +36,18 @@ tot = (out[:, 6] - out[:, 0]).astype(np.float64)
 print("waves %d, mean lifetime %.0f ticks (median %.0f)" % (n, tot.mean(), np.median(tot)))
 for k, nm in enumerate(names):
     print("%-32s mean %9.0f  median %9.0f  (%4.1f %%)" % (nm, d[:, k].mean(), np.median(d[:, k]), 100 * d[:, k].mean() / tot.mean()))
-for k, nm in ((8, "P2: issue of the next chunk's loads"), (9, "P2: record phase"), (10, "P2: MFMA steps"), (11, "P2: flush + expansion"),
-              (12, "P2 (tensor rules): lane tasks"), (13, "P2 (tensor rules): per-face sums + expansion")):
-    print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
-if basis == "dgq" and degree == 3:
-    for k, nm in ((8, "P4: stage 1 (a2, VALU)"), (9, "P4: stages 2 + 3 (MFMA, three groups)"), (10, "P4: rows of the own block")):
+tensor = out[:, 12].any() or out[:, 13].any()
+if tensor:  # P2 ran on verified tensor sub-face rules (slots 12, 13); slots 8 .. 11 belong to the general-point path
+    for k, nm in ((12, "P2 (tensor rules): lane tasks"), (13, "P2 (tensor rules): per-face sums + expansion")):
         print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
 else:
-    for k, nm in ((8, "P4 (FE_AggloDGP): stage 1"), (9, "P4 (FE_AggloDGP): stage 2"), (10, "P4 (FE_AggloDGP): stage 3")):
+    for k, nm in ((8, "P2: issue of the next chunk's loads"), (9, "P2: record phase"), (10, "P2: MFMA steps"), (11, "P2: flush + expansion")):
+        print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
+if basis == "dgq" and degree == 3:
+    for k, nm in ((7, "P4: stage 1 (a2, VALU)"), (14, "P4: stages 2 + 3 (MFMA, three groups)"), (15, "P4: rows of the own block")):
+        print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
+else:
+    for k, nm in ((7, "P4 (streamed kinds): stage 1"), (14, "P4 (streamed kinds): stage 2"), (15, "P4 (streamed kinds): stage 3")):
         print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
 span = out[:, 6].max() - out[:, 0].min()
 print("first start -> last end: %d ticks" % span)
