@@ -85,7 +85,7 @@ def make_variant(pa, name, fe):
     return pa.SipVariant.poisson_example(fe)
 
 
-def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1):
+def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1, grown=False):
     lg = cells.bit_length() - 1
     if stack > 1:  # `stack` unit cubes on top of each other (last direction), lexicographic cells: slab r = rank r's rows
         grid = pa.BackgroundGrid.subdivided_hyper_rectangle(dim, (cells,) * (dim - 1) + (cells * stack,), (0.0,) * dim,
@@ -95,17 +95,20 @@ def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1):
     else:
         grid = pa.BackgroundGrid.subdivided_hyper_cube(dim, cells, 0.0, 1.0)
     ah = pa.AgglomerationHandler(grid)
-    ah.define_block_agglomerates(block)
+    if grown:  # METIS stand-in: connected irregular agglomerates of about block^dim cells (staircase faces, many neighbours)
+        ah.define_grown_agglomerates(block ** dim, seed=1)
+    else:
+        ah.define_block_agglomerates(block)
     fe = (pa.FE_DGQ if basis == "dgq" else pa.FE_AggloDGP)(dim, degree)
     ah.initialize_fe_values(nq, nq)
     ah.distribute_agglomerated_dofs(fe)
     return grid, ah, fe
 
 
-def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto", look_for_tensor_rules=True):
+def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto", look_for_tensor_rules=True, grown=False):
     t0 = time.time()
     stack = world if args.scaling == "weak" else 1
-    grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1, stack)
+    grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1, stack, grown)
     t_handler = time.time() - t0
     var = make_variant(pa, args.variant, fe)
     n = fe.n_dofs_per_cell
@@ -206,7 +209,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     vals = ctx.assemble() if stats["n_values"] <= 64_000_000 else None
     chk = validity
     aux = None
-    if world == 1 and args.aux_kernels and alg == "auto" and look_for_tensor_rules:
+    if world == 1 and args.aux_kernels and alg == "auto" and look_for_tensor_rules and not grown:
         try:
             aux = time_aux_kernels(torch, ctx, flat, n, stats)
         except Exception as exc:
@@ -463,6 +466,21 @@ def main():
                          fp64_bound_ms=1e3 * sum(r2["work"]["flops"]) / (FP64_PEAK_TFLOPS * 1e12))
     if main_res.get("aux") is not None:
         extra["aux_kernels"] = main_res["aux"]
+    if not args.no_extra and world == 1 and args.dim == 3:
+        # the same cells agglomerated the way the reference's own callers do it (examples/poisson.cc:543-566: METIS on the cell
+        # graph; here regions grown over the graph - METIS is not available offline): irregular connected polytopes of about
+        # block^3 cells, neighbours met along several planes ("staircase" faces), 2-3x as many neighbours as a block has
+        try:
+            r3 = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, max(3, args.steps // 2), 1, grown=True)
+            by3 = r3["work"]["bytes_total"] if r3["alg"] == "rows" else sum(r3["work"]["bytes"])
+            t3 = r3["dt"] / max(3, args.steps // 2)
+            extra["irregular_agglomerates"] = {
+                "what": "same %d^3 cells, %d connected agglomerates of ~%d cells grown over the cell graph (METIS stand-in)" % (args.cells, r3["n_agg"], args.block ** 3),
+                "n_dofs": r3["n_dofs"], "nnz": r3["nnz"], "algorithm": r3["alg"], "ms_per_step": 1e3 * t3, "value": r3["n_dofs"] / t3,
+                "kernel_ms": r3["kms"], "algorithmic_bytes_per_step": by3, "hbm_GBs": by3 / t3 * 1e-9,
+                "frac_of_hbm_peak": by3 / t3 * 1e-9 / HBM_PEAK_GBS, "setup_s": r3["t_setup"], "checksum": r3["checksum"]}
+        except Exception as exc:
+            extra["irregular_agglomerates"] = {"error": repr(exc)}
     direct = None
     if main_res["alg"] != "direct" and not args.no_extra:
         # the same workload through the direct (MFMA contraction) form, for the record

@@ -1185,6 +1185,93 @@ inline void define_block_agglomerates(AgglomerationHandler &ah, int b)
     }
 }
 
+// Connected agglomerates of about `cells_per_polytope` cells each, grown over the cell connectivity graph - the stand-in for
+// PolyUtils::partition_locally_owned_regions (METIS_PartGraphKway on that graph: reference examples/poisson.cc:543-566,
+// include/poly_utils.h:465-540; METIS is not available offline).  What matters for the assembly path is the KIND of polytope
+// METIS produces - connected, irregular, of similar size, meeting a neighbour along several sub-faces that need not be
+// coplanar - not the particular partition.  Seeds are spread by a stride over the cells, every region then takes one free
+// neighbouring cell per round (breadth first, deterministic for a given seed); cells no region reached (enclosed pockets)
+// join the region of a neighbour.  Cells of a polytope are passed in ascending order, so the master is the lowest one
+// (PolyUtils::collect_cells_for_agglomeration: include/poly_utils.h:532-538).
+inline void define_grown_agglomerates(AgglomerationHandler &ah, int cells_per_polytope, unsigned seed = 0)
+{
+  const BackgroundGrid &g = ah.get_triangulation();
+  const int nc = g.n_active_cells(), nf = g.n_faces_per_cell();
+  if (cells_per_polytope < 1)
+    throw std::invalid_argument("cells_per_polytope must be >= 1");
+  const int np = std::max(1, nc / cells_per_polytope);
+  std::mt19937_64 rng(seed);
+  std::vector<int> owner((size_t)nc, -1);
+  std::vector<std::vector<int>> frontier((size_t)np);
+  // seeds: one random cell out of every stride of nc / np consecutive cells (consecutive cells are close in space for both
+  // the Morton and the lexicographic numbering)
+  for (int k = 0; k < np; ++k)
+    {
+      const int64_t b0 = (int64_t)nc * k / np, b1 = (int64_t)nc * (k + 1) / np;
+      const int c = (int)(b0 + (int64_t)(rng() % (uint64_t)std::max<int64_t>(1, b1 - b0)));
+      owner[c] = k;
+      frontier[k].push_back(c);
+    }
+  int64_t remaining = nc - np;
+  std::vector<size_t> head((size_t)np, 0);
+  while (remaining > 0)
+    {
+      bool progressed = false;
+      for (int k = 0; k < np && remaining > 0; ++k)
+        {
+          // next free neighbour of the oldest frontier cell that still has one
+          std::vector<int> &fr = frontier[k];
+          while (head[k] < fr.size())
+            {
+              const int c = fr[head[k]];
+              int pick = -1;
+              const int f0 = (int)(rng() % (uint64_t)nf);
+              for (int df = 0; df < nf && pick < 0; ++df)
+                {
+                  const int nb = g.neighbor(c, (f0 + df) % nf);
+                  if (nb != invalid_index && owner[nb] < 0)
+                    pick = nb;
+                }
+              if (pick < 0)
+                {
+                  ++head[k];
+                  continue;
+                }
+              owner[pick] = k;
+              fr.push_back(pick);
+              --remaining;
+              progressed = true;
+              break;
+            }
+        }
+      if (!progressed)
+        break;
+    }
+  // pockets no region could reach: give them to a neighbour's region
+  for (bool again = remaining > 0; again;)
+    {
+      again = false;
+      for (int c = 0; c < nc; ++c)
+        if (owner[c] < 0)
+          {
+            for (int f = 0; f < nf && owner[c] < 0; ++f)
+              {
+                const int nb = g.neighbor(c, f);
+                if (nb != invalid_index && owner[nb] >= 0)
+                  owner[c] = owner[nb];
+              }
+            if (owner[c] < 0)
+              again = true;
+          }
+    }
+  std::vector<std::vector<int>> groups((size_t)np);
+  for (int c = 0; c < nc; ++c)
+    groups[(size_t)owner[c]].push_back(c); // ascending
+  for (const auto &cells : groups)
+    if (!cells.empty())
+      ah.define_agglomerate(cells);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Drop-in for PolyUtils::assemble_dg_matrix (include/poly_utils.h:2000-2195): fills `values` (CSR value
 // array of the pattern create_agglomeration_sparsity_pattern produces) on the GPU.  Throws on error, like

@@ -932,10 +932,13 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
 
 
 // ---------------------------------------------------------------------------------------------------
-// Face tables of the row kernel (pdh_rows.h).  Eligible: 3-D FE_DGQ(3), no exchange variant, and for every owned polytope
-// at most pdh_rows_max_faces() faces, each lying in ONE axis-aligned plane (agglomerates of Cartesian cells).  The test
-// is made on the packed points themselves, so any description qualifies that has the geometry - there is no mesh-type
-// flag.  Planarity is required to a few ulp: the kernel evaluates the bases at ONE plane coordinate per face (the mean).
+// Face tables of the row kernel (pdh_rows.h).  Eligible: 3-D FE_DGQ / FE_AggloDGP of degree 1 .. 3, no exchange variant, and
+// every polytopal face of every owned polytope a union of pieces of axis-aligned planes (agglomerates of Cartesian cells).
+// Block-shaped polytopes meet every neighbour along ONE plane; METIS-like agglomerates meet some along several ("staircase"
+// faces): FE_DGQ(3) has an instantiation for those (RowsHost::multi), the other elements need one plane per neighbour and at
+// most pdh_rows_max_faces() neighbours.  The test is made on the packed points themselves, so any description qualifies that
+// has the geometry - there is no mesh-type flag.  Planarity is required to a few ulp: the kernel evaluates the bases at ONE
+// plane coordinate per entry (the mean).
 // ---------------------------------------------------------------------------------------------------
 // Are the volume points of every owned polytope tensor-product rules of n^dim points on axis-aligned boxes (pdh_problem::
 // vq_tensor_n)?  Checked on the packed points to a few ulp; dim = 3.
@@ -1109,8 +1112,12 @@ struct RowsHost
   std::vector<int32_t> fr_ptr, fr_pcnt, fr_nbr, fr_axis, fr_blk, fr_flags;
   std::vector<int64_t> fr_pbeg;
   std::vector<double> fr_coord, fr_sigma, fr_nsign;
-  std::vector<double> meta; // per-slot records of the kernel (pdh_rows.h: ROWS_REC doubles each)
+  std::vector<double> meta; // per-slot records of the kernel (pdh_rows.h: 12 + 12 maxe doubles each)
   int fq_tensor_n = 0; // verified (or detected) points per direction of the sub-face rules, 0: none
+  // pdh_rows.h, MULTI instantiation: some neighbour is met along several planes, or a polytope has more interior plane
+  // entries / entries than the block-shaped kernel provides for (6 / 16)
+  bool multi = false;
+  int maxe = 16, maxf = 6;
 };
 static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R, std::string *why = nullptr)
 {
@@ -1176,8 +1183,8 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
           sum[k] += x;
           num[k] += 1;
         }
-      if (K.run_nbr[r] >= 0 && planes[r].size() != 1)
-        return no("an interior face spans more than one plane");
+      // (an interior face may span several planes - one entry each, like the boundary run of a corner polytope: whether
+      // the element's kernel can take that is decided below)
       // the kernel evaluates the bases at ONE coordinate per plane (the mean): the points must agree with it to a few ulp
       for (size_t k = 0; k < planes[r].size(); ++k)
         planes[r][k].coord = sum[k] / num[k];
@@ -1224,18 +1231,38 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
             R.fr_sigma.push_back(K.run_sig[t]);
             R.fr_nsign.push_back(pl.sign);
             if (K.run_nbr[t] >= 0)
-              ++nf; // the LDS layout of the kernel limits the INTERIOR faces (coupling moments kept per face)
+              {
+                ++nf; // the LDS layout of the kernel limits the INTERIOR entries (coupling moments kept per entry)
+                if (planes[t].size() > 1)
+                  R.multi = true;
+              }
           }
-      if (nf > maxf || (int)R.fr_pbeg.size() - R.fr_ptr.back() > 64)
-        return no("too many faces on a polytope");
+      const int ne = (int)R.fr_pbeg.size() - R.fr_ptr.back();
+      R.maxf = std::max(R.maxf, nf);
+      R.maxe = std::max(R.maxe, ne);
       R.fr_ptr.push_back((int32_t)R.fr_pbeg.size());
     }
   if (r != nruns)
     return no("run bookkeeping");
+  if (R.maxf > maxf || R.maxe > 16)
+    R.multi = true;
+  if (R.multi)
+    {
+      // the MULTI instantiation exists for FE_DGQ(3); its records hold up to 48 entries (the face table of a polytope lives in
+      // the lanes of the wave, twelve of which carry the header) and LDS provides one 512-byte slot per interior entry
+      if (!(K.n1d == 4 && p->basis != PDH_BASIS_AGGLODGP))
+        return no("a neighbour is met along several planes, or a polytope has more than 6 interior / 16 face entries: FE_DGQ(3) only");
+      if (R.maxe > 48 || R.maxf > 40)
+        return no("too many face entries on a polytope (48 plane entries, 40 of them interior)");
+      R.maxe = (R.maxe + 3) / 4 * 4;
+    }
+  else
+    R.maxe = 16, R.maxf = maxf;
   // per-slot records: header (number of entries, own box as lo / 1/h, row base / length / position of the own block,
   // volume point range) + one entry per face with the neighbour's box - everything the kernel needs about a polytope in
   // one contiguous block
-  constexpr int HDR = 12, MAXE = 16, ENT = 12, REC = HDR + MAXE * ENT;
+  constexpr int HDR = 12, ENT = 12;
+  const int MAXE = R.maxe, REC = HDR + MAXE * ENT;
   auto as_d = [](long long v) {
     double d;
     std::memcpy(&d, &v, sizeof(d));
@@ -1630,6 +1657,9 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
           bool tensor_only = false;
           const bool ok = rows_kind_applies(p, K, RH, vq_n, tensor_only);
           R.tensor_only = tensor_only ? 1 : 0;
+          R.multi = RH.multi ? 1 : 0;
+          R.maxe = RH.maxe;
+          R.maxf = RH.maxf;
           R.vq_tensor_n = vq_n;
           R.fq_tensor_n = RH.fq_tensor_n;
           ctx->rows_ok = ok;

@@ -124,6 +124,22 @@ int pdhh_define_block_agglomerates(void *h, int b)
     return 0;
   });
 }
+int pdhh_define_grown_agglomerates(void *h, int cells_per_polytope, unsigned seed)
+{
+  return guarded([&] {
+    define_grown_agglomerates(AH, cells_per_polytope, seed);
+    return 0;
+  });
+}
+int pdhh_get_agglomerate(void *h, int P, int32_t *cells, int cap)
+{
+  return guarded([&] {
+    const std::vector<int> c = AH.get_agglomerate(P);
+    for (int i = 0; i < (int)c.size() && i < cap; ++i)
+      cells[i] = c[i];
+    return (int)c.size();
+  });
+}
 int pdhh_initialize_fe_values(void *h, int nq, int nqf)
 {
   return guarded([&] {

@@ -37,11 +37,16 @@
 // rules everywhere), SHIFTED = diagonal-first rows; both are facts of a resident problem, and keeping the other variant's
 // code out of the kernel is worth 5-10 % (register allocation).
 //
-// Row stores (P4 epilogue, P5): scalar row pointer + 32-bit lane offset written as inline asm (the compiler forms a 64-bit
-// vector address per row otherwise), carries moved from lane R to lane 0 by v_readlane / v_writelane.  An asm statement
-// is invisible to the compiler's hazard recogniser: these stores only ever take data produced by VALU / LDS
-// instructions and row pointers produced by SALU arithmetic, for which gfx950 needs no wait states; a store placed
-// directly behind an MFMA result would need them (the ascending-layout epilogue therefore keeps a plain store).
+// Row stores (P4 epilogue, P5): BUFFER stores through one resource per polytope - address = base of the polytope's rows (four
+// SGPRs) + scalar offset (row and piece, advanced by SALU adds) + 32-bit lane offset; with a plain pointer the compiler forms a
+// 64-bit vector address per row.  Written with the compiler's own builtin (__builtin_amdgcn_raw_buffer_store_b64), so the
+// hazard recogniser and the scheduler see them: rounds 2's version wrote `global_store_dwordx2 v, v[..], s[..]` as inline asm,
+// which they cannot see - correct behind VALU / LDS results and SALU-made row pointers, and twice found wrong by the parity
+// tests otherwise (a store directly behind an MFMA result; a row pointer restored from a spilled SGPR by v_readlane right in
+// front of the store: "VALU writes SGPR -> VMEM reads it" needs five wait states, the store went to a stale address).  The
+// resource's size is the polytope's n rows: an offset that is off is DROPPED by the bounds check instead of written.
+// Carries still move from lane R to lane 0 by v_readlane / v_writelane (the latter as asm: this compiler has no builtin; it
+// reads its SGPR as data, for which there is no hazard).
 #pragma once
 #include "pdh_moment.h"
 
@@ -51,6 +56,28 @@
 // 2 no diagonal block (P4), 3 no faces (P2), 4 no volume (P1), 5 P5 without its global stores
 #ifndef PDHR_EXP
 #define PDHR_EXP 0
+#endif
+
+// -DPDHR_CHECK (diagnostic builds only): every data-dependent point index of a global load is checked against the size of
+// its array; a violation is recorded in the stamp buffer (slot 15: code | index << 8, slot 14: the wave's slot) and the index is
+// clamped to 0 - a software bounds check for a kernel whose fault would otherwise take the process (and the box) down.
+#ifdef PDHR_CHECK
+#define PDHR_IDX(idx, n, code) pdhr_checked((int64_t)(idx), (int64_t)(n), (code), Rw.stamps, slot)
+__device__ __forceinline__ int64_t pdhr_checked(int64_t idx, int64_t n, int code, long long *dbg, int slot)
+{
+  if (idx < 0 || idx >= n)
+    {
+      if (dbg)
+        {
+          dbg[(int64_t)slot * 16 + 15] = (long long)code | (long long)(idx << 8);
+          dbg[(int64_t)slot * 16 + 14] = slot;
+        }
+      return 0;
+    }
+  return idx;
+}
+#else
+#define PDHR_IDX(idx, n, code) (idx)
 #endif
 
 #ifdef PDHR_STAMP
@@ -74,6 +101,7 @@ namespace pdhr
 {
 using pdh::static_for;
 using pdhm::d2_t;
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 
 constexpr int ROWS_HDR = 12, ROWS_MAXE = 16, ROWS_ENT = 12, ROWS_REC = ROWS_HDR + ROWS_MAXE * ROWS_ENT; // per-slot record
 constexpr int MAXF = 6;  // INTERIOR faces per polytope the LDS layout provides for (6: 20.3 KB per wave = 8 waves per CU)
@@ -265,6 +293,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   const int L = (int)__double_as_longlong(rl_d(cur.e[0], hb + 9));
   const int64_t vq_b = __double_as_longlong(rl_d(cur.e[0], hb + 10)), vq_e = __double_as_longlong(rl_d(cur.e[0], hb + 11));
   const int m0 = !SMALL ? (L >> 6) : L / NF;
+  // the polytope's rows as a buffer: n rows of rlen values from rbase on (see "Row stores" at the top of this file)
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(P.values + rbase, 0, NF * rlen * 8, 0x00020000);
+  auto row_store = [&](double v, uint32_t lane_bytes, uint32_t row_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v), vrs, (int)lane_bytes, (int)row_bytes, 0);
+  };
   // the face table of the polytope lives in the lanes (lane t = face t); a face's entries are read with v_readlane
   const long long pb_ = __double_as_longlong(cur.e[0]);
   const int t_pblo = (int)(uint32_t)pb_, t_pbhi = (int)(pb_ >> 32);
@@ -316,7 +349,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               const int64_t base = qb + (int64_t)(c0 + cl) * m3;
               const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
               const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
-              const double w000 = P.vq_w[base];
+              const double w000 = P.vq_w[PDHR_IDX(base, P.vq_stride, 1)];
               const double sc = d == 0 ? 1.0 : 1.0 / w000;
               double mo[NA];
               for (int a = 0; a < NA; ++a)
@@ -326,8 +359,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               double xr[8], wr[8];
               static_for<0, 8>([&](auto i_) {
                 constexpr int i = i_;
-                xr[i] = i < tn ? P.vq_x[(int64_t)d * P.vq_stride + base + i * step] : 0.0;
-                wr[i] = i < tn ? P.vq_w[base + i * step] : 0.0;
+                xr[i] = i < tn ? P.vq_x[(int64_t)d * P.vq_stride + PDHR_IDX(base + i * step, P.vq_stride, 2)] : 0.0;
+                wr[i] = i < tn ? P.vq_w[PDHR_IDX(base + i * step, P.vq_stride, 3)] : 0.0;
               });
               static_for<0, 8>([&](auto i_) {
                 constexpr int i = i_;
@@ -602,9 +635,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                     }
                   bool member = true;
                   if (masked) // boundary run of a corner polytope: sub-faces of the other planes do not count
-                    member = P.ap_n[(int64_t)c * P.ap_stride + base] * nsg > 0.5 &&
-                             fabs(P.ap_x[(int64_t)c * P.ap_stride + base] - xpl) <= 1e-9 / sel3(c, ih0, ih1, ih2);
-                  const double sS = dir ? 1.0 / P.ap_wself[base] : 1.0, sC = dir ? 1.0 / P.ap_wcross[base] : 1.0;
+                    member = P.ap_n[(int64_t)c * P.ap_stride + PDHR_IDX(base, P.ap_stride, 4)] * nsg > 0.5 &&
+                             fabs(P.ap_x[(int64_t)c * P.ap_stride + PDHR_IDX(base, P.ap_stride, 5)] - xpl) <= 1e-9 / sel3(c, ih0, ih1, ih2);
+                  const double sS = dir ? 1.0 / P.ap_wself[PDHR_IDX(base, P.ap_stride, 6)] : 1.0,
+                               sC = dir ? 1.0 / P.ap_wcross[PDHR_IDX(base, P.ap_stride, 7)] : 1.0;
                   double ms[NA], mc[NA];
                   for (int a = 0; a < NA; ++a)
                     ms[a] = mc[a] = 0.0;
@@ -612,7 +646,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   double xr[8], wsr[8], wcr[8];
                   static_for<0, 8>([&](auto i_) {
                     constexpr int al = i_;
-                    const int64_t q = base + al * stp;
+                    const int64_t q = PDHR_IDX(al < fn ? base + al * stp : 0, P.ap_stride, 8);
                     xr[al] = al < fn ? P.ap_x[(int64_t)ax * P.ap_stride + q] : 0.0;
                     wsr[al] = al < fn ? P.ap_wself[q] : 0.0;
                     wcr[al] = (al < fn && nbr >= 0) ? P.ap_wcross[q] : 0.0;
@@ -1448,9 +1482,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               static_for<0, 4>([&](auto s0_) {
                 constexpr int s0 = s0_;
                 const int R = s0 + 4 * cf + 16 * k2;
-                // (a plain store, not the scalar-base asm of the other row stores: D3 comes straight out of the MFMA, and
-                // the hazard between an MFMA result and its reader is the compiler's to resolve - it cannot inside an asm)
-                P.values[rbase + (int64_t)R * rlen + L + O] = D3[cf][s0];
+                // (D3 comes straight out of the MFMA: the hazard between an MFMA result and the store that reads it is the
+                // compiler's to resolve)
+                row_store(D3[cf][s0], (uint32_t)O * 8u, (uint32_t)(R * rlen + L) * 8u);
               });
             });
           }
@@ -1477,7 +1511,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             const int swA = sw(lane > 0 ? lane - 1 : 0), swB = sw(lane), lm1 = lane - 1;
             const int co_lo = __double2loint(carry_own), co_hi = __double2hiint(carry_own);
             const uint32_t loff4 = (uint32_t)lane * 8u;
-            const double *rowrun = P.values + rbase + (int64_t)(16 * k2) * rlen + L; // uniform
+            uint32_t rowrun = (uint32_t)(16 * k2 * rlen + L) * 8u; // uniform: byte offset of the row's piece
             auto own_rows = [&](auto carry_) {
               constexpr bool CARRY = carry_;
               // all 16 tile reads first (one LDS round trip for the slab, not one per row)
@@ -1503,10 +1537,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                     asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
                     v = __hiloint2double(hi_, lo_);
                   }
-                const double *rp = rowrun;
-                const uint32_t lo32 = loff4;
-                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(v), "s"(rp));
-                rowrun += rlen;
+                row_store(v, loff4, rowrun);
+                rowrun += (uint32_t)rlen * 8u;
               });
             };
             if (m0 > 0)
@@ -1600,7 +1632,6 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       for (int R = 0; R < NF; ++R)
 #endif
         {
-          double *rowp = out + (int64_t)R * rlen; // uniform
           static_for<0, MAXPC>([&](auto pc_) {
             constexpr int pc = pc_;
             if (pc * 64 < rlen)
@@ -1626,11 +1657,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 if (valid[pc])
 #endif
                   {
-                    const double *rp = rowp + pc * 64; // scalar base + 32-bit lane offset
-                    const uint32_t lo32 = loff5;
-                    // (no "memory" clobber: nothing in this kernel reads the values back, and the LDS reads of the next
-                    // pieces may move across the store)
-                    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(val), "s"(rp));
+                    row_store(val, loff5, (uint32_t)(R * rlen + pc * 64) * 8u); // scalar row / piece offset + lane offset
                   }
               }
           });
@@ -1653,84 +1680,94 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         while (te < nfaces && rl_i(t_blk, te) == b)
           ++te; // entries [t, te): the planes shared with this neighbour
         const bool left = shifted && b < m0;
+        PDH_WAVE_SYNC();
         const bool first_piece = left && first_left; // piece 0 starts with the diagonal entry (diagv, written in P4)
         if (left)
           first_left = false;
         // this lane's column of the block: shifted pieces hold columns -1 .. 62 (lane 0: the carry)
         const int jcol = left ? (lane > 0 ? lane - 1 : 0) : lane;
-        // acc[R] = sum_e C_e[k_c(R), l_c(j)] S_e[u(R), v(j)]: one register per row, the planes one after the other (a
-        // single plane takes the same path: one pass of multiply-adds into zeros instead of the fused multiply + store of the
-        // block-shaped kernel - this instantiation serves irregular agglomerates, where most neighbours span several planes)
-        double acc[64];
-        static_for<0, 64>([&](auto R_) { acc[R_] = 0.0; });
-        double next_carry = 0.0;
-        for (int e = t; e < te; ++e)
-          {
-            PDH_WAVE_SYNC();
-            build_S(e);
-            const int c = rl_i(t_axis, e);
-            const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
-            double Cl[4], sc[16];
-            for (int k = 0; k < 4; ++k)
-              Cl[k] = Cbuf[k * 4 + lc];
-            for (int u = 0; u < 16; ++u)
-              sc[u] = Sbuf[u * 16 + vt];
-            if (left)
-              next_carry += last_column(c);
-            auto add = [&](auto c_) {
-              constexpr int cc = c_;
-              static_for<0, 64>([&](auto R_) {
-                constexpr int R = R_;
-                constexpr int kc = (R >> (2 * cc)) & 3;
-                constexpr int k0 = R & 3, k1 = (R >> 2) & 3, k2 = (R >> 4) & 3;
-                constexpr int u = cc == 0 ? (k1 + 4 * k2) : (cc == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
-                acc[R] += Cl[kc] * sc[u];
-              });
-            };
-            using std::integral_constant;
-            if (c == 0)
-              add(integral_constant<int, 0>{});
-            else if (c == 1)
-              add(integral_constant<int, 1>{});
-            else
-              add(integral_constant<int, 2>{});
-          }
-        // rows out: as in the single-plane kernel below (carries through v_readlane / v_writelane, scalar row base)
+        // carries of all rows in ONE register (lane R = row R), see the single-plane kernel below
         const double cvec = first_piece ? diagv[lane] : carry;
         const int cvec_lo = __double2loint(cvec), cvec_hi = __double2hiint(cvec);
-        double *rowp = P.values + rbase + 64 * (int64_t)b; // uniform
+        const uint32_t rowp = 64u * 8u * (uint32_t)b; // uniform: byte offset of the piece in row 0
         const uint32_t lane_off = (uint32_t)lane * 8u;
-        auto rows = [&, lane_off](auto left_) {
+        // one row out: lane 0 of a shifted piece takes the carry of the row; scalar row / piece offset + 32-bit lane offset
+        auto put_row = [&, lane_off](auto left_, auto R_, double v, uint32_t rp) {
           constexpr bool LEFT = left_;
-          const uint32_t loff = lane_off;
-          const double *rowrun = rowp;
-          static_for<0, 64>([&](auto R_) {
-            constexpr int R = R_;
-            double v = acc[R];
-            if constexpr (LEFT)
-              {
-                int lo_ = __double2loint(v), hi_ = __double2hiint(v);
-                const int slo = __builtin_amdgcn_readlane(cvec_lo, R), shi = __builtin_amdgcn_readlane(cvec_hi, R);
-                asm("v_writelane_b32 %0, %1, 0" : "+v"(lo_) : "s"(slo));
-                asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
-                v = __hiloint2double(hi_, lo_);
-              }
+          constexpr int R = R_;
+          if constexpr (LEFT)
+            {
+              int lo_ = __double2loint(v), hi_ = __double2hiint(v);
+              const int slo = __builtin_amdgcn_readlane(cvec_lo, R), shi = __builtin_amdgcn_readlane(cvec_hi, R);
+              asm("v_writelane_b32 %0, %1, 0" : "+v"(lo_) : "s"(slo));
+              asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
+              v = __hiloint2double(hi_, lo_);
+            }
 #if PDHR_EXP == 5
-            if (P.n < 0)
+          if (P.n < 0)
 #endif
-              {
-                const double *rp = rowrun;
-                const uint32_t lo32 = loff;
-                // (data from VALU results only - see the note on asm stores at the top of this file)
-                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(v), "s"(rp) : "memory");
-              }
-            rowrun += rlen;
-          });
+            row_store(v, lane_off, rp);
         };
-        if (left)
-          rows(std::true_type{});
-        else
-          rows(std::false_type{});
+        double next_carry = 0.0;
+        using std::integral_constant;
+        {
+          // acc[r] = sum_e C_e[k_c(R), l_c(j)] S_e[u(R), v(j)], in two halves of 32 rows (64 accumulators do not fit the
+          // register file next to what lives across this phase).  S_e / C_e of a neighbour met along SEVERAL planes are
+          // rebuilt for the second half; a single plane's stay in LDS.  (A variant that multiplied and stored the rows of
+          // single-plane neighbours directly, like the block-shaped kernel does, faulted on the device in all its four
+          // instantiations - stores through a corrupted base - while this form is correct; the cause was not found in the
+          // generated code, see profiles/README.md, r03.)
+          const bool single = te == t + 1;
+          uint32_t rowrun = rowp;
+          static_for<0, 2>([&](auto half_) {
+            constexpr int half = half_;
+            double acc[32];
+            static_for<0, 32>([&](auto r_) { acc[r_] = 0.0; });
+            for (int e = t; e < te; ++e)
+              {
+                if (!(single && half == 1))
+                  {
+                    PDH_WAVE_SYNC();
+                    build_S(e);
+                  }
+                const int c = rl_i(t_axis, e);
+                const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
+                double Cl[4], sc[16];
+                for (int k = 0; k < 4; ++k)
+                  Cl[k] = Cbuf[k * 4 + lc];
+                for (int u = 0; u < 16; ++u)
+                  sc[u] = Sbuf[u * 16 + vt];
+                if (half == 0 && left)
+                  next_carry += last_column(c);
+                auto add = [&](auto c_) {
+                  constexpr int cc = c_;
+                  static_for<0, 32>([&](auto r_) {
+                    constexpr int R = 32 * half + r_;
+                    constexpr int kc = (R >> (2 * cc)) & 3;
+                    constexpr int k0 = R & 3, k1 = (R >> 2) & 3, k2 = (R >> 4) & 3;
+                    constexpr int u = cc == 0 ? (k1 + 4 * k2) : (cc == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
+                    acc[r_] += Cl[kc] * sc[u];
+                  });
+                };
+                if (c == 0)
+                  add(integral_constant<int, 0>{});
+                else if (c == 1)
+                  add(integral_constant<int, 1>{});
+                else
+                  add(integral_constant<int, 2>{});
+              }
+            auto out = [&](auto left_) {
+              static_for<0, 32>([&](auto r_) {
+                put_row(left_, integral_constant<int, 32 * half + r_>{}, acc[r_], rowrun);
+                rowrun += (uint32_t)rlen * 8u;
+              });
+            };
+            if (left)
+              out(std::true_type{});
+            else
+              out(std::false_type{});
+          });
+        }
         PDH_WAVE_SYNC();
         carry = next_carry;
         t = te;
@@ -1770,13 +1807,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         // its own LDS round trip (a quarter of this phase).  The row address is a scalar base + lane.
         const double cvec = first_piece ? diagv[lane] : carry;
         const int cvec_lo = __double2loint(cvec), cvec_hi = __double2hiint(cvec);
-        double *rowp = P.values + rbase + 64 * (int64_t)b; // uniform
+        const uint32_t rowp = 64u * 8u * (uint32_t)b; // uniform: byte offset of the piece in row 0
         const uint32_t lane_off = (uint32_t)lane * 8u;
         auto rows = [&, lane_off](auto c_, auto left_) {
           constexpr int cc = c_;
           constexpr bool LEFT = left_;
           const uint32_t loff = lane_off;
-          const double *rowrun = rowp;
+          uint32_t rowrun = rowp;
           static_for<0, 64>([&](auto R_) {
             constexpr int R = R_;
             constexpr int kc = (R >> (2 * cc)) & 3;
@@ -1795,13 +1832,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
 #if PDHR_EXP == 5
             if (P.n < 0)
 #endif
-              {
-                // scalar row base + 32-bit lane offset (the compiler forms a 64-bit vector address per row otherwise)
-                const double *rp = rowrun; // (a running pointer: 64 precomputed row offsets would be spilled scalars)
-                const uint32_t lo32 = loff; // (named here: operands of an asm alone do not make the lambda capture)
-                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(lo32), "v"(v), "s"(rp) : "memory");
-              }
-            rowrun += rlen;
+              row_store(v, loff, rowrun); // (a running offset: 64 precomputed row offsets would be spilled scalars)
+            rowrun += (uint32_t)rlen * 8u;
           });
         };
         using std::integral_constant;

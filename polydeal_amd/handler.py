@@ -35,6 +35,8 @@ def _lib():
         lib.pdhh_handler_destroy.restype = None
         lib.pdhh_define_agglomerate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.pdhh_define_block_agglomerates.argtypes = [C.c_void_p, C.c_int]
+        lib.pdhh_define_grown_agglomerates.argtypes = [C.c_void_p, C.c_int, C.c_uint]
+        lib.pdhh_get_agglomerate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         lib.pdhh_initialize_fe_values.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.pdhh_distribute_agglomerated_dofs.argtypes = [C.c_void_p, C.c_int, C.c_int]
         for name in ("pdhh_n_agglomerates", "pdhh_n_dofs", "pdhh_n_dofs_per_cell"):
@@ -270,6 +272,24 @@ class AgglomerationHandler:
     def define_block_agglomerates(self, b):
         if _lib().pdhh_define_block_agglomerates(self.h, b) < 0:
             _raise()
+
+    def define_grown_agglomerates(self, cells_per_polytope, seed=0):
+        """Connected irregular agglomerates grown over the cell graph (stand-in for the METIS partition of
+        reference examples/poisson.cc:543-566)."""
+        if _lib().pdhh_define_grown_agglomerates(self.h, int(cells_per_polytope), int(seed)) < 0:
+            _raise()
+
+    def get_agglomerate(self, P):
+        """Cells of polytope P: slaves in insertion order, then the master (reference include/agglomeration_handler.h:1022-1032)."""
+        cap = 64
+        while True:
+            a = np.zeros(cap, dtype=np.int32)
+            n = _lib().pdhh_get_agglomerate(self.h, int(P), a.ctypes.data, cap)
+            if n < 0:
+                _raise()
+            if n <= cap:
+                return a[:n].tolist()
+            cap = n
 
     def initialize_fe_values(self, n_q_points_1d, n_face_q_points_1d):
         if _lib().pdhh_initialize_fe_values(self.h, n_q_points_1d, n_face_q_points_1d) < 0:

@@ -1074,32 +1074,85 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world, basis, p):
 
 
 def test_row_kernel_falls_back_when_faces_are_not_planar():
-    """AUTO must not pick the row kernel on distorted grids or when a polytopal face spans two planes; forcing it fails."""
+    """AUTO must not pick the row kernel on distorted grids (forcing it fails).  A polytopal face that spans two planes of a
+    Cartesian grid is no reason to fall back any more for FE_DGQ(3) (pdh_rows.h: MULTI); the other elements still do."""
     import polydeal_amd as pa
 
-    fe = po.FE_DGQ(3, 3)
-    for mode in ("distorted", "staircase"):
+    for mode, fe, expect in (("distorted", po.FE_DGQ(3, 3), "moment"), ("staircase", po.FE_DGQ(3, 3), "rows"),
+                             ("staircase", po.FE_DGQ(3, 2), "mixed"), ("staircase", po.FE_AggloDGP(3, 3), "direct")):
         grid = po.hyper_cube_refined(3, 0.0, 1.0, 2)
         if mode == "distorted":
             grid.distort(1e-9, seed=1)  # even a tiny perturbation: the kernel evaluates ONE plane coordinate per face
         ah = po.AgglomerationHandler(grid)
         for g in (po.block_agglomerates(grid, 2) if mode == "distorted" else _staircase_groups(grid)):
             ah.define_agglomerate(g)
-        ah.initialize_fe_values(4, 4)
+        nq = fe.degree + 1
+        ah.initialize_fe_values(nq, nq)
         ah.distribute_agglomerated_dofs(fe)
         var = po.variant_poisson_example(fe)
         kw = flatten(ah, var)
         ref = po.assemble_csr(ah, var)[2]
         va, used = _values(kw, "auto")
-        assert used == "moment"
-        assert_parity_ah(va, ref, ah)
-        prob = pa.Problem(**kw)
-        ctx = pa.Context(0)
-        ctx.set_problem(prob)
-        ctx.set_algorithm("rows")
-        with pytest.raises(pa.PdhError):
-            ctx.assemble()
-        ctx.close()
+        assert used == expect, (mode, fe.name, used)
+        assert_parity_ah(va, ref, ah, what="%s %s" % (mode, fe.name))
+        if expect != "rows":
+            prob = pa.Problem(**kw)
+            ctx = pa.Context(0)
+            ctx.set_problem(prob)
+            ctx.set_algorithm("rows")
+            with pytest.raises(pa.PdhError):
+                ctx.assemble()
+            ctx.close()
+
+
+def _grown_agglomerates(grid, cells_per_polytope, seed):
+    """METIS stand-in (METIS is not available offline; reference examples/poisson.cc:543-566 partitions the cell connectivity
+    graph into connected parts of about equal size): regions grown over the cell adjacency graph from random seeds."""
+    rng = np.random.default_rng(seed)
+    return random_agglomeration(grid, max(2, grid.n_cells // cells_per_polytope), rng)
+
+
+@pytest.mark.parametrize("cells,per,vname,diag_first,seed", [(4, 4, "poisson", True, 0), (4, 8, "dr", False, 1), (6, 6, "adm", True, 2),
+                                                             (6, 3, "test", True, 3), (8, 8, "poisson", True, 4)])
+def test_row_kernel_staircase_agglomerates(cells, per, vname, diag_first, seed):
+    """Irregular agglomerates of Cartesian cells (regions grown over the cell graph, the METIS stand-in): neighbours are met
+    along several planes, polytopes have many more than six faces, boundary runs span up to five planes.  FE_DGQ(3) takes the row
+    kernel (MULTI instantiation: a coupling block is the sum of the Kronecker products of its planes): parity with the oracle
+    per block, both CSR layouts, with and without the tensor structure of the rules, on row ranges; agreement with the moment
+    form to rounding."""
+    from polydeal_amd.partition import row_range
+
+    fe = po.FE_DGQ(3, 3)
+    grid = po.subdivided_hyper_cube(3, cells, 0.0, 1.0)
+    groups = _grown_agglomerates(grid, per, seed)
+    ah = po.AgglomerationHandler(grid)
+    order = np.random.default_rng(seed).permutation(len(groups))  # polytope index order != master cell order
+    for k in order:
+        ah.define_agglomerate(groups[k])
+    ah.initialize_fe_values(4, 4)
+    ah.distribute_agglomerated_dofs(fe)
+    assert max(ah.n_faces) > 6  # more neighbours than a box has
+    var = variant(vname, fe)
+    kw = flatten(ah, var, diag_first=diag_first)
+    ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
+    v0, used = _values(kw, "auto")
+    assert used == "rows"
+    assert_parity_ah(v0, ref, ah, diag_first, what="rows (tensor rules found)")
+    vg, used = _values(dict(kw, vq_tensor_n=-1, fq_tensor_n=-1), "rows")
+    assert used == "rows"
+    assert_parity_ah(vg, ref, ah, diag_first, what="rows (general points)")
+    assert np.max(np.abs(vg - v0)) > 0.0  # really the other path
+    vm, used = _values(kw, "moment")
+    assert used == "moment"
+    assert np.max(np.abs(v0 - vm)) <= 1e-13 * np.max(np.abs(ref))
+    n = fe.n_dofs_per_cell
+    parts = []
+    for r in range(3):
+        rb, re = row_range(ah.n_agglomerates, n, r, 3)
+        v, u = _values(kw, "rows", rb, re)
+        assert u == "rows"
+        parts.append(v)
+    assert_parity_ah(np.concatenate(parts), ref, ah, diag_first, what="row ranges")
 
 
 def test_poisson_sanity_check_02_on_gpu():
