@@ -267,6 +267,69 @@ def time_aux_kernels(torch, ctx, flat, n, stats):
                        "frac_of_hbm_peak": by_ev / t_ev * 1e-9 / HBM_PEAK_GBS, "note": "u_h and grad u_h at the volume quadrature points"}}
 
 
+def strong_proxy(pa, args, steps):
+    """Strong-scaling readiness measured on ONE device (last bullet: at ~2 k polytopes per GPU occupancy, not xGMI, is
+    the risk): the share of rank 0 in an N-rank strong-scaling run - the first 1/N of the rows, with its ghost neighbours - timed
+    for N = 1, 2, 4, 8, on the N = 1 bench problem and on the "~1 M DoF" problem of the north star (16 384 polytopes).  With
+    owner-computes-rows there is no exchange step, so t(1) / t(1/N) on one device is what N devices would give, up to load
+    imbalance between the ranges (none on these meshes) and the barrier."""
+    from polydeal_amd.partition import row_range
+    out = {}
+    nq = args.degree + 1
+    probs = {"bench_problem": None}
+    if args.dim == 3:
+        probs["about_1M_dofs"] = (args.cells, args.cells, max(args.block, args.cells // 2))
+    for name, shape in probs.items():
+        if shape is None:
+            grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, args.fe, args.degree, nq)
+        else:
+            grid = pa.BackgroundGrid.subdivided_hyper_rectangle(args.dim, shape, (0.0,) * args.dim,
+                                                                tuple(float(c) / shape[0] for c in shape))
+            ah = pa.AgglomerationHandler(grid)
+            ah.define_block_agglomerates(args.block)
+            fe = (pa.FE_DGQ if args.fe == "dgq" else pa.FE_AggloDGP)(args.dim, args.degree)
+            ah.initialize_fe_values(nq, nq)
+            ah.distribute_agglomerated_dofs(fe)
+        var = make_variant(pa, args.variant, fe)
+        n, n_agg = fe.n_dofs_per_cell, ah.n_agglomerates
+        res = {"n_polytopes": n_agg, "n_dofs": ah.n_dofs, "ranges": {}}
+        t1 = None
+        for N in (1, 2, 4, 8):
+            r0, r1 = row_range(n_agg, n, 0, N)
+            splits = [row_range(n_agg, n, r, N)[0] for r in range(N)] + [n_agg * n]
+            flat = ah.flatten(var, True, False) if N == 1 else ah.flatten_local(var, r0, r1, diag_first=True, with_colind=False,
+                                                                                 row_splits=splits)
+            ctx = pa.Context(0)
+            ctx.set_overlap(False)
+            ctx.set_problem(flat, r0, r1)
+            for _ in range(3):
+                ctx.assemble_device()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ctx.assemble_device()
+            ctx.synchronize()
+            wall = (time.perf_counter() - t0) / steps
+            ctx.set_profiling(True)
+            for _ in range(steps):
+                ctx.assemble_device()
+            ctx.synchronize()
+            kms, _ = ctx.kernel_times_ms()
+            ctx.set_profiling(False)
+            alg = ctx.algorithm_in_use()
+            ctx.close()
+            if N == 1:
+                t1 = wall
+            res["ranges"]["1/%d" % N] = {"polytopes": (r1 - r0) // n, "ms_per_step": 1e3 * wall, "kernel_ms": kms[0] + kms[1],
+                                          "algorithm": alg, "speedup_vs_whole": t1 / wall}
+        res["t1_over_t8"] = res["ranges"]["1/1"]["ms_per_step"] / res["ranges"]["1/8"]["ms_per_step"]
+        res["kernel_t1_over_t8"] = res["ranges"]["1/1"]["kernel_ms"] / max(res["ranges"]["1/8"]["kernel_ms"], 1e-9)
+        out[name] = res
+    out["note"] = ("one device, rank 0's share of an N-rank strong-scaling split (first 1/N of the rows, rank-local description with ghosts); "
+                   "ms_per_step = back-to-back launches incl. launch overhead, kernel_ms = HIP-event kernel time")
+    return out
+
+
 def run_ghost_exchange(pa, torch, dist, args, flat, r0, r1, rank, world, local_rank, steps, warmup, ref_vals):
     """The same step in the reference's distributed form (include/poly_utils.h:1930-1992, 2134-2194): the owner of a face cut
     by the partition computes M21 / M22 and ships them; transport = one all-to-all-v over RCCL (xGMI) per step."""
@@ -404,6 +467,8 @@ def main():
                          "(roofline.overlapped_ms_per_step); off by default so that a rocprofv3 trace of the default command "
                          "contains serialised launches only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-proxy", dest="strong_proxy", action="store_false",
+                    help="N = 1: skip extra.strong_proxy (rank 0's share of 2-, 4-, 8-rank strong-scaling splits timed on this device)")
     ap.add_argument("--no-aux-kernels", dest="aux_kernels", action="store_false",
                     help="skip the timing of the right-hand-side and evaluation kernels (extra.aux_kernels)")
     ap.add_argument("--no-exchange-extra", dest="exchange_extra", action="store_false",
@@ -481,6 +546,11 @@ def main():
                 "frac_of_hbm_peak": by3 / t3 * 1e-9 / HBM_PEAK_GBS, "setup_s": r3["t_setup"], "checksum": r3["checksum"]}
         except Exception as exc:
             extra["irregular_agglomerates"] = {"error": repr(exc)}
+    if world == 1 and args.strong_proxy and not args.no_extra:
+        try:
+            extra["strong_proxy"] = strong_proxy(pa, args, max(5, args.steps))
+        except Exception as exc:
+            extra["strong_proxy"] = {"error": repr(exc)}
     direct = None
     if main_res["alg"] != "direct" and not args.no_extra:
         # the same workload through the direct (MFMA contraction) form, for the record

@@ -230,8 +230,12 @@ class Grid:
         return int(self.ijk_to_cell[tuple(ijk)])
 
     @staticmethod
-    def neighbor_of_neighbor(f: int) -> int:
+    def neighbor_of_neighbor(f: int, cell: int = -1) -> int:
         return f ^ 1
+
+    @staticmethod
+    def face_points_reversed(cell: int, f: int) -> bool:
+        return False
 
     def distort(self, factor: float, seed: int = 0):
         """Random interior-vertex jitter, in the spirit of GridTools::distort_random as used by
@@ -281,6 +285,125 @@ def _build_grid(dim, n, lo, hi, order):
         off = np.array([(v >> c) & 1 for c in range(dim)])
         verts[:, v, :] = lo + (cell_ijk + off) * h
     return Grid(dim, nd[0], cell_ijk, lut, verts, None if len(set(nd)) == 1 else nd)
+
+
+class UnstructuredGrid:
+    """2-D quadrilateral mesh with explicit adjacency: GridIn<2>::read_msh + Triangulation::refine_global  [deal.II], as the
+    reference's callers use it on meshes/t3.msh (examples/minimal_SIP.cc:94-118, test/polydeal/poisson_sanity_check_03.cc:
+    103-113).  Same interface as Grid where the handler needs it (neighbor, neighbor_of_neighbor, vertices, n_cells).
+    vertex_id numbers the vertices globally: two cells that share an edge agree on its direction through it
+    (face_points_reversed), which is what makes their face quadrature points coincide index by index, as deal.II's face
+    orientation does (asserted by the reference: test/polydeal/reinit_cell_face_quad_pts.cc)."""
+
+    FACE_VERTICES = ((0, 2), (1, 3), (0, 1), (2, 3))  # face f runs from the first to the second (free coordinate increasing)
+
+    def __init__(self, vertices, vertex_id):
+        self.dim = 2
+        self.vertices = np.asarray(vertices, dtype=np.float64)  # [n_cells, 4, 2]
+        self.vertex_id = np.asarray(vertex_id, dtype=np.int64)  # [n_cells, 4]
+        self._adjacency()
+
+    @property
+    def n_cells(self):
+        return self.vertices.shape[0]
+
+    def _adjacency(self):
+        n = self.n_cells
+        self.nbr = np.full((n, 4), INVALID, dtype=np.int64)
+        self.nofn = np.full((n, 4), INVALID, dtype=np.int64)
+        first = {}
+        for c in range(n):
+            for f, (a, b) in enumerate(self.FACE_VERTICES):
+                key = tuple(sorted((int(self.vertex_id[c, a]), int(self.vertex_id[c, b]))))
+                if key in first:
+                    oc, of = first[key]
+                    assert self.nbr[oc, of] == INVALID, "an edge is shared by more than two cells"
+                    self.nbr[c, f], self.nofn[c, f] = oc, of
+                    self.nbr[oc, of], self.nofn[oc, of] = c, f
+                else:
+                    first[key] = (c, f)
+
+    def neighbor(self, cell: int, f: int) -> int:
+        return int(self.nbr[cell, f])
+
+    def neighbor_of_neighbor(self, f: int, cell: int = -1) -> int:
+        return int(self.nofn[cell, f])
+
+    def face_points_reversed(self, cell: int, f: int) -> bool:
+        a, b = self.FACE_VERTICES[f]
+        return bool(self.vertex_id[cell, a] > self.vertex_id[cell, b])
+
+    def refine_global(self, times: int = 1):
+        """Children of cell i become cells 4i .. 4i+3, child c at ((c&1),(c>>1)) of the parent; new vertices at the edge
+        midpoints and at the mean of the four vertices (FlatManifold on straight-sided cells)  [deal.II]."""
+        for _ in range(times):
+            nv = int(self.vertex_id.max()) + 1
+            mids = {}
+            new_xy = []
+
+            def mid(c, a, b):
+                nonlocal nv
+                key = tuple(sorted((int(self.vertex_id[c, a]), int(self.vertex_id[c, b]))))
+                if key not in mids:
+                    mids[key] = (nv + len(new_xy), 0.5 * (self.vertices[c, a] + self.vertices[c, b]))
+                    new_xy.append(mids[key][1])
+                return mids[key]
+
+            verts, ids = [], []
+            for c in range(self.n_cells):
+                V = [(int(self.vertex_id[c, v]), self.vertices[c, v]) for v in range(4)]
+                EL, ER, EB, ET = mid(c, 0, 2), mid(c, 1, 3), mid(c, 0, 1), mid(c, 2, 3)
+                C = (nv + len(new_xy), 0.25 * self.vertices[c].sum(axis=0))
+                new_xy.append(C[1])
+                for ch in ((V[0], EB, EL, C), (EB, V[1], C, ER), (EL, C, V[2], ET), (C, ER, ET, V[3])):
+                    ids.append([k[0] for k in ch])
+                    verts.append([k[1] for k in ch])
+            self.vertices = np.asarray(verts, dtype=np.float64)
+            self.vertex_id = np.asarray(ids, dtype=np.int64)
+            self._adjacency()
+        return self
+
+
+def read_msh(path) -> UnstructuredGrid:
+    """gmsh 4.1 ASCII, 4-node quadrilaterals (element type 3).  gmsh lists a quadrilateral counter-clockwise; deal.II's vertex
+    order is lexicographic, i.e. nodes (0, 1, 3, 2)  [deal.II GridIn::read_msh]."""
+    tok = open(path).read().split("\n")
+    pos = {name: i for i, name in enumerate(tok) if name.startswith("$")}
+    ver = float(tok[pos["$MeshFormat"] + 1].split()[0])
+    assert 4.0 <= ver < 5.0, "only the ASCII format 4.x is read"
+    nodes = {}
+    i = pos["$Nodes"] + 1
+    nblocks = int(tok[i].split()[0])
+    i += 1
+    for _ in range(nblocks):
+        edim, _tag, parametric, nb = (int(t) for t in tok[i].split())
+        tags = [int(tok[i + 1 + k]) for k in range(nb)]
+        for k in range(nb):
+            nodes[tags[k]] = [float(t) for t in tok[i + 1 + nb + k].split()[:3]]
+        i += 1 + 2 * nb
+    quads = []
+    i = pos["$Elements"] + 1
+    nblocks = int(tok[i].split()[0])
+    i += 1
+    for _ in range(nblocks):
+        _edim, _tag, etype, nb = (int(t) for t in tok[i].split())
+        for k in range(nb):
+            row = [int(t) for t in tok[i + 1 + k].split()]
+            if etype == 3:
+                quads.append(row[1:5])
+            else:
+                assert etype in (15, 1), "quadrilateral meshes only"
+        i += 1 + nb
+    used = sorted({t for q in quads for t in q})
+    vid = {t: k for k, t in enumerate(used)}
+    verts, ids = [], []
+    for q in quads:
+        xy = np.array([nodes[t][:2] for t in q])
+        area2 = sum(xy[v, 0] * xy[(v + 1) % 4, 1] - xy[v, 1] * xy[(v + 1) % 4, 0] for v in range(4))
+        order = (0, 1, 3, 2) if area2 > 0 else (1, 0, 2, 3)  # a clockwise list is mirrored
+        ids.append([vid[q[o]] for o in order])
+        verts.append([nodes[q[o]][:2] for o in order])
+    return UnstructuredGrid(verts, ids)
 
 
 def hyper_cube_refined(dim, lo, hi, n_refine) -> Grid:
@@ -365,6 +488,8 @@ def face_quadrature(grid: Grid, cell: int, f: int, nqf: int):
     """Real q-points, JxW and outward unit normals of QGauss<dim-1>(nqf) on face f of a cell."""
     dim = grid.dim
     xi, w, tang = _face_unit_points(dim, f, nqf)
+    if grid.face_points_reversed(cell, f):  # the direction both cells sharing the face agree on (UnstructuredGrid)
+        xi, w = xi[::-1].copy(), w[::-1].copy()
     N, dN = _q1_shape(dim, xi)
     X = grid.vertices[cell]
     x = N @ X
@@ -465,7 +590,7 @@ class AgglomerationHandler:
                     if nb != INVALID:
                         if self.master_of[nb] != self.master_of[cell]:
                             Q = self.polytope_of_cell(nb)
-                            nof = g.neighbor_of_neighbor(f)
+                            nof = g.neighbor_of_neighbor(f, cell)
                             if Q not in seen:
                                 self.face_info[(P, self.n_faces[P])] = (False, Q)
                                 self.n_faces[P] += 1

@@ -32,6 +32,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <exception>
+#include <fstream>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -152,6 +153,13 @@ public:
   std::vector<std::array<int, 3>> cell_ijk;
   std::vector<int> lut;             // ijk -> cell
   std::vector<double> vertices;     // [cell][2^dim][dim]
+  // Unstructured meshes (read_msh): explicit adjacency instead of the ijk lattice.  vertex_id numbers the vertices globally
+  // (what makes two cells agree on the direction in which they walk a shared face), nbr_tab / nofn_tab are
+  // cell->neighbor(f) and cell->neighbor_of_neighbor(f) of deal.II.
+  bool unstructured = false;
+  std::vector<int> vertex_id; // [cell][2^dim]
+  std::vector<int> nbr_tab;   // [cell][2 dim], invalid_index on the boundary
+  std::vector<int> nofn_tab;  // [cell][2 dim]
 
   static BackgroundGrid hyper_cube_refined(int dim, double lo, double hi, int n_refine)
   {
@@ -173,12 +181,198 @@ public:
     const double l3[3] = {lo[0], lo[1], dim == 3 ? lo[2] : 0.0}, h3[3] = {hi[0], hi[1], dim == 3 ? hi[2] : 1.0};
     return build(dim, nd, l3, h3, false);
   }
+  // GridIn<2>::read_msh [deal.II] for the gmsh 4.1 ASCII format, 4-node quadrilaterals only (what meshes/t3.msh of the
+  // reference holds: examples/minimal_SIP.cc:94-118, test/polydeal/poisson_sanity_check_03.cc:103-113).  gmsh lists a quad
+  // counter-clockwise; deal.II's vertex order is lexicographic (v at ((v&1),(v>>1)&1)), i.e. nodes (0,1,3,2).
+  static BackgroundGrid read_msh(const std::string &path)
+  {
+    std::ifstream in(path);
+    if (!in)
+      throw std::invalid_argument("read_msh: cannot open " + path);
+    std::string line;
+    std::map<long long, std::array<double, 3>> nodes;
+    std::vector<std::array<long long, 4>> quads;
+    double version = 0.0;
+    while (std::getline(in, line))
+      {
+        if (line.rfind("$MeshFormat", 0) == 0)
+          {
+            int ft, ds;
+            in >> version >> ft >> ds;
+            if (version < 4.0 || version >= 5.0 || ft != 0)
+              throw std::invalid_argument("read_msh: only the ASCII format 4.x is read");
+          }
+        else if (line.rfind("$Nodes", 0) == 0)
+          {
+            long long nblocks, nnodes, mn, mx;
+            in >> nblocks >> nnodes >> mn >> mx;
+            for (long long b = 0; b < nblocks; ++b)
+              {
+                int edim, etag, parametric;
+                long long nb;
+                in >> edim >> etag >> parametric >> nb;
+                std::vector<long long> tags((size_t)nb);
+                for (auto &t : tags)
+                  in >> t;
+                for (long long k = 0; k < nb; ++k)
+                  {
+                    std::array<double, 3> x;
+                    in >> x[0] >> x[1] >> x[2];
+                    for (int pc = 0; pc < (parametric ? edim : 0); ++pc)
+                      {
+                        double u;
+                        in >> u;
+                      }
+                    nodes[tags[(size_t)k]] = x;
+                  }
+              }
+          }
+        else if (line.rfind("$Elements", 0) == 0)
+          {
+            long long nblocks, nel, mn, mx;
+            in >> nblocks >> nel >> mn >> mx;
+            for (long long b = 0; b < nblocks; ++b)
+              {
+                int edim, etag, etype;
+                long long nb;
+                in >> edim >> etag >> etype >> nb;
+                // nodes per element of the types that can occur next to quads in a 2-D mesh file
+                int npe = 0;
+                switch (etype)
+                  {
+                  case 15: npe = 1; break; // point
+                  case 1: npe = 2; break;  // line
+                  case 2: npe = 3; break;  // triangle
+                  case 3: npe = 4; break;  // quadrilateral
+                  default: throw std::invalid_argument("read_msh: unsupported element type " + std::to_string(etype));
+                  }
+                for (long long k = 0; k < nb; ++k)
+                  {
+                    long long tag, nd[4] = {0, 0, 0, 0};
+                    in >> tag;
+                    for (int v = 0; v < npe; ++v)
+                      in >> nd[v];
+                    if (etype == 3)
+                      quads.push_back({nd[0], nd[1], nd[2], nd[3]});
+                    else if (etype == 2)
+                      throw std::invalid_argument("read_msh: triangles are not supported (quadrilateral meshes only)");
+                  }
+              }
+          }
+        if (!in)
+          throw std::invalid_argument("read_msh: malformed file " + path);
+      }
+    if (quads.empty())
+      throw std::invalid_argument("read_msh: no quadrilaterals in " + path);
+    BackgroundGrid g;
+    g.dim = 2;
+    g.unstructured = true;
+    g.n_per_dir = 0;
+    g.n_dir = {0, 0, 0};
+    std::map<long long, int> vid; // node tag -> consecutive vertex number (ascending tags, like deal.II's vertex list)
+    for (const auto &q : quads)
+      for (long long t : q)
+        if (!nodes.count(t))
+          throw std::invalid_argument("read_msh: element refers to an unknown node");
+        else
+          vid.emplace(t, 0);
+    int nvtx = 0;
+    for (auto &kv : vid)
+      kv.second = nvtx++;
+    const size_t nc = quads.size();
+    g.cell_ijk.assign(nc, {0, 0, 0});
+    g.vertices.resize(nc * 4 * 2);
+    g.vertex_id.resize(nc * 4);
+    static const int order[4] = {0, 1, 3, 2};
+    for (size_t c = 0; c < nc; ++c)
+      {
+        // orientation: counter-clockwise node lists have positive area; a clockwise one is mirrored (deal.II inverts such cells)
+        double area2 = 0.0;
+        for (int v = 0; v < 4; ++v)
+          {
+            const auto &a = nodes[quads[c][v]], &b = nodes[quads[c][(v + 1) % 4]];
+            area2 += a[0] * b[1] - a[1] * b[0];
+          }
+        for (int v = 0; v < 4; ++v)
+          {
+            const long long tag = quads[c][area2 > 0 ? order[v] : order[v ^ 1]];
+            g.vertex_id[c * 4 + v] = vid[tag];
+            g.vertices[(c * 4 + v) * 2 + 0] = nodes[tag][0];
+            g.vertices[(c * 4 + v) * 2 + 1] = nodes[tag][1];
+          }
+      }
+    g.build_adjacency();
+    return g;
+  }
+  // Triangulation::refine_global(times) [deal.II] for the unstructured 2-D mesh: every quadrilateral is split by its edge
+  // midpoints and the mean of its vertices (FlatManifold on straight-sided cells); child c sits at ((c&1),(c>>1)) of the
+  // parent and the children of cell i become cells 4i .. 4i+3 (all active cells are on one level, ordered by parent).
+  void refine_global(int times)
+  {
+    if (!unstructured || dim != 2)
+      throw std::logic_error("refine_global: implemented for meshes read by read_msh (structured grids are built at their final size)");
+    for (int it = 0; it < times; ++it)
+      {
+        const size_t nc = (size_t)n_active_cells();
+        int nvtx = 0;
+        for (int v : vertex_id)
+          nvtx = std::max(nvtx, v + 1);
+        std::map<std::pair<int, int>, int> mid; // edge (sorted vertex pair) -> new vertex
+        std::vector<double> nv_x;               // coordinates of the new vertices
+        auto midpoint = [&](size_t c, int a, int b) {
+          int va = vertex_id[c * 4 + a], vb = vertex_id[c * 4 + b];
+          const std::pair<int, int> k = std::minmax(va, vb);
+          auto f = mid.find(k);
+          if (f != mid.end())
+            return f->second;
+          const int id = nvtx + (int)(nv_x.size() / 2);
+          for (int d = 0; d < 2; ++d)
+            nv_x.push_back(0.5 * (vertices[(c * 4 + a) * 2 + d] + vertices[(c * 4 + b) * 2 + d]));
+          mid.emplace(k, id);
+          return id;
+        };
+        std::vector<int> nid(nc * 16);
+        std::vector<double> nx(nc * 16 * 2);
+        auto coord = [&](size_t c, int id, int local, double *out) {
+          if (local >= 0)
+            {
+              out[0] = vertices[(c * 4 + local) * 2], out[1] = vertices[(c * 4 + local) * 2 + 1];
+              return;
+            }
+          const size_t k = (size_t)(id - nvtx);
+          out[0] = nv_x[2 * k], out[1] = nv_x[2 * k + 1];
+        };
+        for (size_t c = 0; c < nc; ++c)
+          {
+            const int V[4] = {vertex_id[c * 4], vertex_id[c * 4 + 1], vertex_id[c * 4 + 2], vertex_id[c * 4 + 3]};
+            const int EL = midpoint(c, 0, 2), ER = midpoint(c, 1, 3), EB = midpoint(c, 0, 1), ET = midpoint(c, 2, 3);
+            const int C = nvtx + (int)(nv_x.size() / 2);
+            for (int d = 0; d < 2; ++d)
+              nv_x.push_back(0.25 * (vertices[(c * 4) * 2 + d] + vertices[(c * 4 + 1) * 2 + d] + vertices[(c * 4 + 2) * 2 + d] +
+                                     vertices[(c * 4 + 3) * 2 + d]));
+            const int ch[4][4] = {{V[0], EB, EL, C}, {EB, V[1], C, ER}, {EL, C, V[2], ET}, {C, ER, ET, V[3]}};
+            const int loc[4][4] = {{0, -1, -1, -1}, {-1, 1, -1, -1}, {-1, -1, 2, -1}, {-1, -1, -1, 3}};
+            for (int k = 0; k < 4; ++k)
+              for (int v = 0; v < 4; ++v)
+                {
+                  nid[(c * 4 + k) * 4 + v] = ch[k][v];
+                  coord(c, ch[k][v], loc[k][v], &nx[((c * 4 + k) * 4 + v) * 2]);
+                }
+          }
+        vertex_id.swap(nid);
+        vertices.swap(nx);
+        cell_ijk.assign(nc * 4, {0, 0, 0});
+        build_adjacency();
+      }
+  }
   int n_active_cells() const { return (int)cell_ijk.size(); }
   int n_faces_per_cell() const { return 2 * dim; }
   int nv() const { return 1 << dim; }
   const double *vertex(int cell, int v) const { return &vertices[((size_t)cell * nv() + v) * dim]; }
   int neighbor(int cell, int f) const
   {
+    if (unstructured)
+      return nbr_tab[(size_t)cell * n_faces_per_cell() + f];
     std::array<int, 3> ijk = cell_ijk[cell];
     const int ax = f / 2;
     ijk[ax] += (f & 1) ? 1 : -1;
@@ -186,12 +380,31 @@ public:
       return invalid_index;
     return lut[lin(ijk)];
   }
-  static int neighbor_of_neighbor(int f) { return f ^ 1; }
-  int cell_at(int ix, int iy, int iz = 0) const { return lut[lin({ix, iy, iz})]; }
+  // which face of neighbor(cell, f) is the shared one (cell->neighbor_of_neighbor(f) [deal.II])
+  int neighbor_of_neighbor(int cell, int f) const { return unstructured ? nofn_tab[(size_t)cell * n_faces_per_cell() + f] : (f ^ 1); }
+  int cell_at(int ix, int iy, int iz = 0) const
+  {
+    if (unstructured)
+      throw std::logic_error("cell_at: the mesh has no ijk lattice");
+    return lut[lin({ix, iy, iz})];
+  }
+  // Do the quadrature points of face f of `cell` run AGAINST the direction both cells sharing the face agree on (ascending
+  // global vertex number)?  deal.II gets matching points on the two sides of a face from the face's own orientation
+  // (line_orientation); on the ijk lattice both neighbours walk a face the same way and nothing has to be reversed.
+  bool face_points_reversed(int cell, int f) const
+  {
+    if (!unstructured)
+      return false;
+    // 2-D faces: 0: v0->v2, 1: v1->v3, 2: v0->v1, 3: v2->v3 (the free unit coordinate increases from the first to the second)
+    static const int fv[4][2] = {{0, 2}, {1, 3}, {0, 1}, {2, 3}};
+    return vertex_id[(size_t)cell * 4 + fv[f][0]] > vertex_id[(size_t)cell * 4 + fv[f][1]];
+  }
 
   // random interior-vertex jitter (stand-in for GridTools::distort_random, exact_solutions_dgp.cc:306)
   void distort(double factor, unsigned seed)
   {
+    if (unstructured)
+      throw std::logic_error("distort: implemented for lattice grids");
     std::mt19937_64 rng(seed);
     std::uniform_real_distribution<double> U(-1.0, 1.0);
     const double h = vertex(0, nv() - 1)[0] - vertex(0, 0)[0];
@@ -232,6 +445,31 @@ public:
   }
 
 private:
+  // neighbour tables of an unstructured 2-D mesh from shared edges
+  void build_adjacency()
+  {
+    static const int fv[4][2] = {{0, 2}, {1, 3}, {0, 1}, {2, 3}};
+    const size_t nc = (size_t)n_active_cells();
+    nbr_tab.assign(nc * 4, invalid_index);
+    nofn_tab.assign(nc * 4, invalid_index);
+    std::map<std::pair<int, int>, std::pair<int, int>> first; // edge -> (cell, face) that met it first
+    for (size_t c = 0; c < nc; ++c)
+      for (int f = 0; f < 4; ++f)
+        {
+          const std::pair<int, int> k = std::minmax(vertex_id[c * 4 + fv[f][0]], vertex_id[c * 4 + fv[f][1]]);
+          auto it = first.find(k);
+          if (it == first.end())
+            first.emplace(k, std::make_pair((int)c, f));
+          else
+            {
+              const int oc = it->second.first, of = it->second.second;
+              if (nbr_tab[(size_t)oc * 4 + of] != invalid_index)
+                throw std::invalid_argument("mesh: an edge is shared by more than two cells");
+              nbr_tab[c * 4 + f] = oc, nofn_tab[c * 4 + f] = of;
+              nbr_tab[(size_t)oc * 4 + of] = (int)c, nofn_tab[(size_t)oc * 4 + of] = f;
+            }
+        }
+  }
   int lin(const std::array<int, 3> &ijk) const
   {
     return ijk[0] + n_dir[0] * (ijk[1] + (dim == 3 ? n_dir[1] * ijk[2] : 0));
@@ -359,6 +597,7 @@ inline void face_quadrature(const BackgroundGrid &g, int cell, int f, int nqf, Q
   qgauss_1d(nqf, x1, w1);
   const int dim = g.dim, ax = f / 2, side = f & 1;
   const int np = (dim == 2) ? nqf : nqf * nqf;
+  const bool rev = g.face_points_reversed(cell, f);
   int tang[2];
   if (dim == 2)
     tang[0] = tang[1] = 1 - ax;
@@ -374,8 +613,9 @@ inline void face_quadrature(const BackgroundGrid &g, int cell, int f, int nqf, Q
       xi[ax] = side;
       if (dim == 2)
         {
-          xi[tang[0]] = x1[q];
-          w = w1[q];
+          const int qq = rev ? nqf - 1 - q : q; // the direction both sides of the face agree on (face_points_reversed)
+          xi[tang[0]] = x1[qq];
+          w = w1[qq];
         }
       else
         {
@@ -500,6 +740,7 @@ inline void face_quadrature_soa(const BackgroundGrid &g, int cell, int f, int nq
 {
   const int dim = g.dim, ax = f / 2, side = f & 1;
   const int np = (dim == 2) ? nqf : nqf * nqf;
+  const bool rev = g.face_points_reversed(cell, f);
   int tang[2];
   if (dim == 2)
     tang[0] = tang[1] = 1 - ax;
@@ -515,8 +756,9 @@ inline void face_quadrature_soa(const BackgroundGrid &g, int cell, int f, int nq
       xi[ax] = side;
       if (dim == 2)
         {
-          xi[tang[0]] = x1[q];
-          w = w1[q];
+          const int qq = rev ? nqf - 1 - q : q; // the direction both sides of the face agree on (face_points_reversed)
+          xi[tang[0]] = x1[qq];
+          w = w1[qq];
         }
       else
         {
@@ -1108,7 +1350,7 @@ private:
                   if (master_of[nb] == master_of[cell])
                     continue; // are_cells_agglomerated (:1300-1301)
                   const int Q = master2polygon.at(master_of[nb]);
-                  const int nof = g.neighbor_of_neighbor(f);
+                  const int nof = g.neighbor_of_neighbor(cell, f);
                   if (seen_stamp[Q] != P)
                     { // first contact with polytope Q: new polytopal face (:1346-1367 / 1412-1433)
                       face_nbr[P].push_back(Q);
@@ -1166,6 +1408,8 @@ inline void define_block_agglomerates(AgglomerationHandler &ah, int b)
 {
   const BackgroundGrid &g = ah.get_triangulation();
   const int dim = g.dim;
+  if (g.unstructured)
+    throw std::invalid_argument("block agglomerates need a lattice grid (use define_grown_agglomerates)");
   if (b <= 0 || g.n_dir[0] % b || g.n_dir[1] % b || (dim == 3 && g.n_dir[2] % b))
     throw std::invalid_argument("block size must divide the number of cells per direction");
   const int nbx = g.n_dir[0] / b, nby = g.n_dir[1] / b, nbz = dim == 3 ? g.n_dir[2] / b : 1;
@@ -1193,13 +1437,15 @@ inline void define_block_agglomerates(AgglomerationHandler &ah, int b)
 // neighbouring cell per round (breadth first, deterministic for a given seed); cells no region reached (enclosed pockets)
 // join the region of a neighbour.  Cells of a polytope are passed in ascending order, so the master is the lowest one
 // (PolyUtils::collect_cells_for_agglomeration: include/poly_utils.h:532-538).
-inline void define_grown_agglomerates(AgglomerationHandler &ah, int cells_per_polytope, unsigned seed = 0)
+// n_subdomains connected agglomerates (GridTools::partition_triangulation(n_subdomains, tria, metis) + one agglomerate per
+// subdomain: reference examples/minimal_SIP.cc:107-139)
+inline void partition_into_grown_agglomerates(AgglomerationHandler &ah, int n_subdomains, unsigned seed = 0)
 {
   const BackgroundGrid &g = ah.get_triangulation();
   const int nc = g.n_active_cells(), nf = g.n_faces_per_cell();
-  if (cells_per_polytope < 1)
-    throw std::invalid_argument("cells_per_polytope must be >= 1");
-  const int np = std::max(1, nc / cells_per_polytope);
+  if (n_subdomains < 1 || n_subdomains > nc)
+    throw std::invalid_argument("n_subdomains must be between 1 and the number of cells");
+  const int np = n_subdomains;
   std::mt19937_64 rng(seed);
   std::vector<int> owner((size_t)nc, -1);
   std::vector<std::vector<int>> frontier((size_t)np);
@@ -1270,6 +1516,12 @@ inline void define_grown_agglomerates(AgglomerationHandler &ah, int cells_per_po
   for (const auto &cells : groups)
     if (!cells.empty())
       ah.define_agglomerate(cells);
+}
+inline void define_grown_agglomerates(AgglomerationHandler &ah, int cells_per_polytope, unsigned seed = 0)
+{
+  if (cells_per_polytope < 1)
+    throw std::invalid_argument("cells_per_polytope must be >= 1");
+  partition_into_grown_agglomerates(ah, std::max(1, ah.get_triangulation().n_active_cells() / cells_per_polytope), seed);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -89,6 +89,23 @@ void *pdhh_grid_create(int dim, int n_per_dir, int morton, double lo, double hi)
       return nullptr;
     }
 }
+// GridIn::read_msh (gmsh 4.1 ASCII, quadrilaterals) followed by refine_global(n_refine)
+void *pdhh_grid_read_msh(const char *path, int n_refine)
+{
+  try
+    {
+      auto *h = new GridH;
+      h->g = BackgroundGrid::read_msh(path);
+      h->g.refine_global(n_refine);
+      return h;
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return nullptr;
+    }
+}
+int pdhh_grid_neighbor(void *g, int cell, int f) { return static_cast<GridH *>(g)->g.neighbor(cell, f); }
 void pdhh_grid_destroy(void *g) { delete static_cast<GridH *>(g); }
 int pdhh_grid_n_cells(void *g) { return static_cast<GridH *>(g)->g.n_active_cells(); }
 int pdhh_grid_distort(void *g, double factor, unsigned seed)
@@ -128,6 +145,13 @@ int pdhh_define_grown_agglomerates(void *h, int cells_per_polytope, unsigned see
 {
   return guarded([&] {
     define_grown_agglomerates(AH, cells_per_polytope, seed);
+    return 0;
+  });
+}
+int pdhh_partition_into_grown_agglomerates(void *h, int n_subdomains, unsigned seed)
+{
+  return guarded([&] {
+    partition_into_grown_agglomerates(AH, n_subdomains, seed);
     return 0;
   });
 }

@@ -35,8 +35,12 @@ def _lib():
         lib.pdhh_handler_destroy.restype = None
         lib.pdhh_define_agglomerate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.pdhh_define_block_agglomerates.argtypes = [C.c_void_p, C.c_int]
+        lib.pdhh_grid_read_msh.argtypes = [C.c_char_p, C.c_int]
+        lib.pdhh_grid_read_msh.restype = C.c_void_p
+        lib.pdhh_grid_neighbor.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.pdhh_define_grown_agglomerates.argtypes = [C.c_void_p, C.c_int, C.c_uint]
         lib.pdhh_get_agglomerate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        lib.pdhh_partition_into_grown_agglomerates.argtypes = [C.c_void_p, C.c_int, C.c_uint]
         lib.pdhh_initialize_fe_values.argtypes = [C.c_void_p, C.c_int, C.c_int]
         lib.pdhh_distribute_agglomerated_dofs.argtypes = [C.c_void_p, C.c_int, C.c_int]
         for name in ("pdhh_n_agglomerates", "pdhh_n_dofs", "pdhh_n_dofs_per_cell"):
@@ -164,6 +168,19 @@ class BackgroundGrid:
         return BackgroundGrid(dim, 2 ** n_refine, lo, hi, True)
 
     @staticmethod
+    def read_msh(path, n_refine=0):
+        """GridIn<2>::read_msh (gmsh 4.1 ASCII, quadrilaterals) + Triangulation::refine_global(n_refine): an unstructured
+        background mesh (reference examples/minimal_SIP.cc:94-118 reads meshes/t3.msh this way)."""
+        h = _lib().pdhh_grid_read_msh(str(path).encode(), int(n_refine))
+        if not h:
+            _raise()
+        return BackgroundGrid(2, 0, _handle=h)
+
+    def neighbor(self, cell, f):
+        """cell->neighbor(f), -1 on the domain boundary."""
+        return _lib().pdhh_grid_neighbor(self.h, int(cell), int(f))
+
+    @staticmethod
     def subdivided_hyper_cube(dim, n, lo=0.0, hi=1.0):
         return BackgroundGrid(dim, n, lo, hi, False)
 
@@ -277,6 +294,12 @@ class AgglomerationHandler:
         """Connected irregular agglomerates grown over the cell graph (stand-in for the METIS partition of
         reference examples/poisson.cc:543-566)."""
         if _lib().pdhh_define_grown_agglomerates(self.h, int(cells_per_polytope), int(seed)) < 0:
+            _raise()
+
+    def partition_into_grown_agglomerates(self, n_subdomains, seed=0):
+        """n_subdomains connected agglomerates (stand-in for GridTools::partition_triangulation(n, tria, metis) + one
+        agglomerate per subdomain, reference examples/minimal_SIP.cc:107-139)."""
+        if _lib().pdhh_partition_into_grown_agglomerates(self.h, int(n_subdomains), int(seed)) < 0:
             _raise()
 
     def get_agglomerate(self, P):

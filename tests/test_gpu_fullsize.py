@@ -209,3 +209,31 @@ def test_config4_diffusion_reaction_128cubed_dgq2_one_gpu():
     # a polytope is interior iff its row sum needs no boundary term; count them through the value itself
     interior = np.abs(sums - c * volP) <= 1e-11 * scale
     assert interior.sum() == (nb - 2) ** 3, interior.sum()
+
+
+def test_bench_strong_scaling_rehearsal_on_one_gpu():
+    """`bench.py --gpus 4 --scaling strong` (the default scaling, BASELINE.json north_star: strong scaling to 8 GPUs) rehearsed on
+    this box's ONE GPU: four ranks (gloo, all on device 0 - the box admits at most six processes on the card, so the 8-rank
+    case is left to the driver's 8-GPU node) split the rows of one problem, each from its rank-local description; the JSON line
+    must carry the strong-scaling fields, the global number of non-zeros, and a valid matrix on every rank's device values
+    (rank 0's checksum against its closed form).  The timing is meaningless here."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--rehearse-on-one-gpu", "--cells", "16", "--steps", "2",
+           "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--no-exchange-extra"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["scaling"] == "strong" and d["n_gpus"] == 4
+    n_agg, n = 8 ** 3, 64
+    assert d["config"]["workload"].endswith("%d dofs, %d nnz" % (n_agg * n, n * n * (n_agg + 2 * 3 * 8 * 8 * 7)))
+    assert "split in 4 contiguous ranges" in d["config"]["parallelism"]
+    assert d["checksum"]["non_finite"] == 0 and d["checksum"]["rel_err"] < 1e-9
+    assert d["value"] > 0 and d["roofline"]["kernel"] == "k_rows"

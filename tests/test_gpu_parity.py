@@ -147,9 +147,17 @@ def test_cpp_examples_run():
     exe = os.path.join(root, "examples", "minimal_SIP")
     if not os.path.exists(exe):
         pytest.skip("examples not built")
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    # examples/minimal_SIP.cc on ITS mesh (meshes/t3.msh = tests/golden/t3.msh, refined 3 times, N = 50 .. 800 agglomerates): the
+    # stdout is the reference's test/polydeal/poisson_sanity_check_03.output, up to the round-off sized "Test with 1" values
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "t3.msh")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "Test with f(x,y)=x: 1" in out.stdout
+    got, want = out.stdout.split("\n"), gc.golden_lines("poisson_sanity_check_03.output")
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        if w.startswith("Test with 1:"):
+            assert g.startswith("Test with 1: ") and abs(float(g.split(":")[1])) < 1e-12
+        else:
+            assert g == w
     out = subprocess.run([os.path.join(root, "examples", "poisson")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Assembled DoF/s" in out.stdout
@@ -1324,3 +1332,64 @@ def test_row_store_sites_every_variant_repeatable():
                 ctx.poison_values()
                 assert np.array_equal(ctx.assemble(), first)
             ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Unstructured background mesh (meshes/t3.msh of the reference = tests/golden/t3.msh): the reference's own callers run on it
+# (examples/minimal_SIP.cc:94-139, test/polydeal/poisson_sanity_check_03.cc:103-135).
+# ---------------------------------------------------------------------------------------------------------------------
+def test_poisson_sanity_check_03_on_t3_mesh_on_gpu():
+    """All six runs of test/polydeal/poisson_sanity_check_03.output (N = 50 .. 800 agglomerates of t3.msh refined 3 times,
+    FE_DGQ(1), QGauss(3), boundary terms dropped) with the matrix from the HIP path - product mirror (gmsh reader, refine_global,
+    grown agglomerates: METIS stand-in, the identities hold for any agglomeration) -> C ABI -> kernels."""
+    import os
+    import scipy.sparse as sp
+    import polydeal_amd as pa
+
+    mesh = os.path.join(gc.GOLDEN_DIR, "t3.msh")
+    out = []
+    for n_sub in (50, 100, 120, 300, 400, 800):
+        grid = pa.BackgroundGrid.read_msh(mesh, 3)
+        assert grid.n_cells == 5824
+        ah = pa.AgglomerationHandler(grid)
+        ah.partition_into_grown_agglomerates(n_sub, seed=n_sub)
+        assert ah.n_agglomerates == n_sub
+        fe = pa.FE_DGQ(2, 1)
+        ah.initialize_fe_values(3, 3)
+        ah.distribute_agglomerated_dofs(fe)
+        var = pa.SipVariant(10.0, 1, 0, 1)  # penalty 10 / h, index()<index(), boundary zeroed (:96, 230-262)
+        rp, ci, vals = pa.assemble_dg_matrix(fe, ah, var)
+        A = sp.csr_matrix((vals, ci, rp), shape=(ah.n_dofs, ah.n_dofs))
+        arr = ah.flatten(var, True, False).arrays()
+        bb = arr["bbox"].reshape(-1, 2, 2)
+        corner = np.array([[0, 0], [1, 0], [0, 1], [1, 1]])  # FE_DGQ(1) nodes: corners of the box, x fastest
+        x = np.zeros(ah.n_dofs)
+        y = np.zeros(ah.n_dofs)
+        for i in range(4):
+            x[arr["dof_offset"] + i] = bb[np.arange(n_sub), corner[i, 0], 0]
+            y[arr["dof_offset"] + i] = bb[np.arange(n_sub), corner[i, 1], 1]
+        one = np.ones(ah.n_dofs)
+        forms = [float(v @ (A @ v)) for v in (x, x + y, one)]
+        assert abs(forms[0] - 1.0) < 1e-12 and abs(forms[1] - 2.0) < 1e-12 and abs(forms[2]) < 1e-12, (n_sub, forms)
+        out += ["N subdomains: %d" % n_sub, "Test with f(x,y)=x:" + gc.fmt(round(forms[0], 10)),
+                "Test with f(x,y)=x+y:" + gc.fmt(round(forms[1], 10))]
+    want = [l for l in gc.golden_lines("poisson_sanity_check_03.output") if l and not l.startswith("Test with 1:")]
+    assert out == want
+
+
+@pytest.mark.parametrize("n_refine,n_sub,basis,p,vname", [(2, 64, "dgq", 1, "minsip"), (1, 30, "dgp", 2, "poisson"), (1, 25, "dgq", 3, "adm")])
+def test_t3_mesh_parity_with_the_oracle(n_refine, n_sub, basis, p, vname):
+    """Agglomerates of the unstructured mesh, entry by entry against the oracle (product mirror on the input side, the oracle
+    reading the same file with its own reader): non-axis-aligned faces, irregular polytopes, 2-D kernels."""
+    from test_host_golden import _t3_pair, VARIANTS
+    import polydeal_amd as pa
+
+    grid, ah, fe, og, oah, ofe = _t3_pair(n_refine, n_sub, basis, p, p + 1)
+    pv, ov = VARIANTS[vname]
+    pvar = pv(fe) if vname in ("poisson", "dr") else pv()
+    ovar = ov(ofe) if vname in ("poisson", "dr") else ov()
+    for diag_first in (True, False):
+        rp, ci, vals = pa.assemble_dg_matrix(fe, ah, pvar, diag_first=diag_first)
+        orp, oci, ref = po.assemble_csr(oah, ovar, diag_first=diag_first)
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+        assert_parity(vals, ref, orp, oci, fe.n_dofs_per_cell)

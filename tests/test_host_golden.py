@@ -225,3 +225,71 @@ def test_rtree_level_counts_of_block_hierarchies():
                                   "%d cells have subdomain id = %d") == gc.golden_lines("rtree_mesh.output")[:-1]
     assert gc.render_rtree_levels(sizes, 0, "Extract level: ", "Size of tria: ",
                                   "%d cells are composing agglomerate %d") == gc.golden_lines("extract_last_level.output")[:-1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Unstructured background mesh: meshes/t3.msh of the reference (91 quadrilaterals, gmsh 4.1; tests/golden/t3.msh is that data
+# file), read + refine_global as examples/minimal_SIP.cc:94-118 and test/polydeal/poisson_sanity_check_03.cc:103-113 do.
+# ---------------------------------------------------------------------------------------------------------------------
+T3 = __import__("os").path.join(gc.GOLDEN_DIR, "t3.msh")
+
+
+def _t3_pair(n_refine, n_subdomains, basis="dgq", p=1, nq=3, seed=1):
+    grid = pa.BackgroundGrid.read_msh(T3, n_refine)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_grown_agglomerates(max(1, grid.n_cells // n_subdomains), seed=seed)  # METIS stand-in (connected, irregular)
+    fe = (pa.FE_DGQ if basis == "dgq" else pa.FE_AggloDGP)(2, p)
+    ah.initialize_fe_values(nq, nq)
+    ah.distribute_agglomerated_dofs(fe)
+    og = po.read_msh(T3).refine_global(n_refine)
+    oah = po.AgglomerationHandler(og)
+    for P in range(ah.n_agglomerates):
+        cells = ah.get_agglomerate(P)           # slaves in insertion order, then the master
+        oah.define_agglomerate([cells[-1]] + cells[:-1])
+    ofe = (po.FE_DGQ if basis == "dgq" else po.FE_AggloDGP)(2, p)
+    oah.initialize_fe_values(nq, nq)
+    oah.distribute_agglomerated_dofs(ofe)
+    return grid, ah, fe, og, oah, ofe
+
+
+def test_read_msh_and_refine_global_agree_with_the_oracle():
+    grid = pa.BackgroundGrid.read_msh(T3, 0)
+    og = po.read_msh(T3)
+    assert grid.n_cells == og.n_cells == 91
+    for k in (1, 2):
+        grid = pa.BackgroundGrid.read_msh(T3, k)
+        og.refine_global(1)
+        assert grid.n_cells == og.n_cells == 91 * 4 ** k
+        area = 0.0
+        for c in range(og.n_cells):
+            v = grid.cell_vertices(c)
+            assert np.array_equal(v, og.vertices[c])
+            assert all(grid.neighbor(c, f) == og.neighbor(c, f) for f in range(4))
+            area += 0.5 * abs((v[3] - v[0])[0] * (v[2] - v[1])[1] - (v[3] - v[0])[1] * (v[2] - v[1])[0])
+        assert abs(area - 1.0) < 1e-13  # the unit square
+        # every interior edge is seen from both sides, each naming the other's face
+        for c in range(og.n_cells):
+            for f in range(4):
+                nb = og.neighbor(c, f)
+                if nb != po.INVALID:
+                    assert og.neighbor(nb, og.neighbor_of_neighbor(f, c)) == c
+
+
+@pytest.mark.parametrize("n_refine,n_sub,basis,p,vname", [(1, 20, "dgq", 1, "minsip"), (1, 40, "dgp", 2, "poisson"), (2, 50, "dgq", 2, "adm")])
+def test_flatten_on_t3_mesh_matches_oracle(n_refine, n_sub, basis, p, vname):
+    """Product flattening == oracle flattening on agglomerates of the unstructured mesh: both sides of every polytopal face see
+    the same points in the same order (deal.II's face orientation; here: the direction of ascending global vertex numbers)."""
+    grid, ah, fe, og, oah, ofe = _t3_pair(n_refine, n_sub, basis, p, p + 1)
+    pv, ov = VARIANTS[vname]
+    pvar = pv(fe) if vname in ("poisson", "dr") else pv()
+    ovar = ov(ofe) if vname in ("poisson", "dr") else ov()
+    flat = ah.flatten(pvar, diag_first=True, with_colind=True).arrays()
+    ref = oracle_flatten(oah, ovar, diag_first=True)
+    for k in ("dof_offset", "vq_ptr", "face_in", "face_out", "fq_ptr", "rowptr", "colind"):
+        assert np.array_equal(np.asarray(ref[k]).ravel(), flat[k]), k
+    for k in ("bbox", "vq_x", "vq_w", "fq_x", "fq_n", "fq_w", "fq_w_out", "face_sigma"):
+        a, bb = np.asarray(ref[k], dtype=float).ravel(), flat[k]
+        assert a.shape == bb.shape, k
+        assert np.max(np.abs(a - bb)) <= 4e-15 * max(1.0, np.max(np.abs(a))), k
+    # the two sides of a straight shared edge carry the same JxW point by point
+    assert np.max(np.abs(flat["fq_w"] - flat["fq_w_out"])) <= 1e-15

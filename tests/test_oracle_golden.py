@@ -349,3 +349,44 @@ def test_rtree_level_counts_of_block_hierarchies():
                                   "%d cells have subdomain id = %d") == gc.golden_lines("rtree_mesh.output")[:-1]
     assert gc.render_rtree_levels(sizes, 0, "Extract level: ", "Size of tria: ",
                                   "%d cells are composing agglomerate %d") == gc.golden_lines("extract_last_level.output")[:-1]
+
+
+@pytest.mark.parametrize("n_sub", [50, 300])
+def test_poisson_sanity_check_03_on_t3_mesh(n_sub):
+    """test/polydeal/poisson_sanity_check_03.cc on ITS mesh: meshes/t3.msh (tests/golden/t3.msh, 91 quadrilaterals), refined 3
+    times, N agglomerates - the reference partitions with METIS, here regions grown over the cell graph; the printed identities
+    (v^T A v = 1, 2 for v = x, x + y and ~1e-14 for v = 1, boundary terms dropped, FE_DGQ(1), QGauss(3): :166-172) hold for ANY
+    agglomeration.  Oracle only (the GPU suite runs all six N of the reference's output file through the HIP path)."""
+    import os
+    grid = po.read_msh(os.path.join(gc.GOLDEN_DIR, "t3.msh")).refine_global(3)
+    assert grid.n_cells == 5824
+    rng = np.random.default_rng(n_sub)
+    owner = -np.ones(grid.n_cells, dtype=np.int64)
+    seeds = rng.choice(grid.n_cells, size=n_sub, replace=False)
+    front = [[int(s)] for s in seeds]
+    owner[seeds] = np.arange(n_sub)
+    left = grid.n_cells - n_sub
+    while left:
+        for k in range(n_sub):
+            while front[k]:
+                c = front[k][0]
+                free = [x for x in (grid.neighbor(c, f) for f in range(4)) if x != po.INVALID and owner[x] < 0]
+                if not free:
+                    front[k].pop(0)
+                    continue
+                owner[free[0]] = k
+                front[k].append(int(free[0]))
+                left -= 1
+                break
+    ah = po.AgglomerationHandler(grid)
+    for k in range(n_sub):
+        ah.define_agglomerate(sorted(np.nonzero(owner == k)[0].tolist()))
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(po.FE_DGQ(2, 1))
+    var = po.SipVariant("sanity", 10.0, "index", "diameter_in", boundary="zero")
+    x, xy, one = _sanity_forms(ah, var)
+    lines = gc.golden_lines("poisson_sanity_check_03.output")
+    at = lines.index("N subdomains: %d" % n_sub)
+    assert "Test with f(x,y)=x:" + gc.fmt(round(x, 10)) == lines[at + 1]
+    assert "Test with f(x,y)=x+y:" + gc.fmt(round(xy, 10)) == lines[at + 2]
+    assert abs(x - 1.0) < 1e-12 and abs(xy - 2.0) < 1e-12 and abs(one) < 1e-12
