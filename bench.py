@@ -257,6 +257,15 @@ def time_aux_kernels(torch, ctx, flat, n, stats):
 
     t_rhs = timed(lambda: ctx.assemble_rhs_device(f_vol.data_ptr(), g_b.data_ptr(), rhs.data_ptr()))
     t_ev = timed(lambda: ctx.evaluate_device(sol.data_ptr(), ptr.data_ptr(), pts.data_ptr(), nq, u.data_ptr(), g.data_ptr()))
+    # PolyUtils::compute_global_error fused on the device (pdh_global_error_device): evaluation + JxW-weighted sums in one
+    # kernel, 16 bytes per polytope come back
+    w_d = torch.from_numpy(np.ascontiguousarray(arr["vq_w"])).to(dev)
+    eu_d = torch.rand(nq, dtype=torch.float64, device=dev)
+    eg_d = torch.rand(d * nq, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t_err = timed(lambda: ctx.global_error_sums_device(sol.data_ptr(), ptr.data_ptr(), pts.data_ptr(), nq, w_d.data_ptr(),
+                                                       eu_d.data_ptr(), eg_d.data_ptr()))
+    by_err = 8.0 * d * nq + 8.0 * (d + 2) * nq + 8.0 * sol.numel() + 16.0 * stats["n_owned_agg"]
     nbd = float(np.diff(arr["fq_ptr"])[arr["face_out"] < 0].sum()) if flat.c.n_faces else 0.0
     # compulsory bytes of the right-hand side: volume points (x, JxW, f); of the face points only the boundary ones carry a
     # datum (x, n, JxW, sigma, g) - the kernel reads the 8-byte map entry of every packed face point to find them
@@ -264,7 +273,11 @@ def time_aux_kernels(torch, ctx, flat, n, stats):
     by_ev = 8.0 * d * nq + 8.0 * (d + 1) * nq + 8.0 * sol.numel()
     return {"k_rhs": {"ms": 1e3 * t_rhs, "algorithmic_bytes": by_rhs, "GBs": by_rhs / t_rhs * 1e-9, "frac_of_hbm_peak": by_rhs / t_rhs * 1e-9 / HBM_PEAK_GBS},
             "k_eval": {"ms": 1e3 * t_ev, "points": nq, "algorithmic_bytes": by_ev, "GBs": by_ev / t_ev * 1e-9,
-                       "frac_of_hbm_peak": by_ev / t_ev * 1e-9 / HBM_PEAK_GBS, "note": "u_h and grad u_h at the volume quadrature points"}}
+                       "frac_of_hbm_peak": by_ev / t_ev * 1e-9 / HBM_PEAK_GBS, "note": "u_h and grad u_h at the volume quadrature points"},
+            "k_eval_error_sums": {"ms": 1e3 * t_err, "points": nq, "algorithmic_bytes": by_err, "GBs": by_err / t_err * 1e-9,
+                                  "frac_of_hbm_peak": by_err / t_err * 1e-9 / HBM_PEAK_GBS,
+                                  "note": "compute_global_error on the device: u_h, grad u_h and the weighted L2 / H1 sums in one kernel "
+                                          "(incl. the 16 B per polytope copied back and the stream synchronisation)"}}
 
 
 def strong_proxy(pa, args, steps):

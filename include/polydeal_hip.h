@@ -175,6 +175,19 @@ int pdh_evaluate_device(pdh_ctx *ctx, const double *d_solution, const int64_t *d
 int pdh_shape_values_device(pdh_ctx *ctx, int dim, int degree, int basis, int n_boxes, const double *d_bbox,
                             const int64_t *d_pt_ptr, const double *d_pts, int64_t n_points, double *d_values);
 
+/* PolyUtils::compute_global_error (reference include/poly_utils.h:1647-1750) with the weighted sums formed ON THE DEVICE:
+ *   sums[0] = sum_q JxW_q (u(x_q) - u_h(x_q))^2,   sums[1] = sum_q JxW_q |grad u(x_q) - grad u_h(x_q)|^2
+ * over the points of the polytopes owned by the context (the SQUARES: ranks add them before the root, like the reference's
+ * Utilities::MPI::sum, :1736-1745).  pt_ptr / pts as for pdh_evaluate; w [N] the JxW of the points; exact_u [N] and
+ * exact_grad [dim][N] the analytical solution and its gradient sampled by the caller at the same points (the library has no
+ * callbacks into host code).  One kernel evaluates u_h, grad u_h and the two sums per polytope (fixed summation order:
+ * the result is reproducible); 16 bytes per polytope cross PCIe instead of 8 (dim + 1) per point.  sums is HOST memory in
+ * both variants; the _device variant takes every array in device memory and synchronises the stream before it returns. */
+int pdh_global_error(pdh_ctx *ctx, const double *solution, const int64_t *pt_ptr, const double *pts, const double *w,
+                     const double *exact_u, const double *exact_grad, double *sums /* [2] */);
+int pdh_global_error_device(pdh_ctx *ctx, const double *d_solution, const int64_t *d_pt_ptr, const double *d_pts, int64_t n_points,
+                            const double *d_w, const double *d_exact_u, const double *d_exact_grad, double *sums /* [2], host */);
+
 /* Access to device-resident results and synchronisation. */
 int pdh_device_values(pdh_ctx *ctx, double **device_ptr, int64_t *n_values);
 int pdh_synchronize(pdh_ctx *ctx);

@@ -50,6 +50,7 @@ EXPORTS = [
     "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
     "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows", "pdh_values_checksum",
     "pdh_assemble_rhs_device", "pdh_evaluate_device", "pdh_shape_values_device",
+    "pdh_global_error", "pdh_global_error_device",
 ]
 
 _lib = None
@@ -256,6 +257,29 @@ class Context:
         self._chk(self.lib.pdh_evaluate(self.h, sol.ctypes.data, ptr.ctypes.data, p.ctypes.data, u.ctypes.data,
                                         None if g is None else g.ctypes.data))
         return (u, g) if want_grad else u
+
+    def global_error_sums(self, solution, pt_ptr, pts, w, exact_u, exact_grad):
+        """(sum w (u - u_h)^2, sum w |grad u - grad u_h|^2) over the owned polytopes, formed on the device
+        (pdh_global_error); exact_u [N], exact_grad [dim][N] sampled at pts [dim][N]."""
+        sol = np.ascontiguousarray(solution, dtype=np.float64)
+        ptr = np.ascontiguousarray(pt_ptr, dtype=np.int64)
+        p = np.ascontiguousarray(pts, dtype=np.float64)
+        ww = np.ascontiguousarray(w, dtype=np.float64)
+        eu = np.ascontiguousarray(exact_u, dtype=np.float64)
+        eg = np.ascontiguousarray(exact_grad, dtype=np.float64)
+        n = int(ptr[-1])
+        if ww.shape != (n,) or eu.shape != (n,) or eg.shape != (p.shape[0], n) or p.shape[1] != n:
+            raise ValueError("w / exact_u [N], exact_grad / pts [dim][N] with N = pt_ptr[-1]")
+        out = (C.c_double * 2)()
+        self._chk(self.lib.pdh_global_error(self.h, sol.ctypes.data, ptr.ctypes.data, p.ctypes.data, ww.ctypes.data,
+                                            eu.ctypes.data, eg.ctypes.data, out))
+        return float(out[0]), float(out[1])
+
+    def global_error_sums_device(self, d_solution, d_pt_ptr, d_pts, n_points, d_w, d_exact_u, d_exact_grad):
+        out = (C.c_double * 2)()
+        self._chk(self.lib.pdh_global_error_device(self.h, C.c_void_p(d_solution), C.c_void_p(d_pt_ptr), C.c_void_p(d_pts), n_points,
+                                                   C.c_void_p(d_w), C.c_void_p(d_exact_u), C.c_void_p(d_exact_grad), out))
+        return float(out[0]), float(out[1])
 
     def shape_values(self, dim, degree, basis, bbox, pt_ptr, pts):
         """phi_j(x_q) of the box basis (dim, degree, basis) for every box's points: [N][n]."""

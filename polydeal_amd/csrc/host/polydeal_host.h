@@ -1551,8 +1551,8 @@ inline void assemble_dg_matrix(std::vector<double> &values, const FiniteElement 
 }
 
 // PolyUtils::compute_global_error (reference include/poly_utils.h:1647-1750) on a problem resident in `ctx`
-// (set from the same FlatProblem): u_h and grad u_h come from pdh_evaluate at the polytopes' quadrature points,
-// the weighted sums are formed here.  exact(const double *x) -> double; exact_grad(const double *x, double *g).
+// (set from the same FlatProblem): u_h, grad u_h at the polytopes' quadrature points and the weighted sums come from the
+// device (pdh_global_error).  exact(const double *x) -> double; exact_grad(const double *x, double *g).
 // Returns {L2 error, H1-seminorm error}; pass want_h1 = false to skip the gradient part (second entry 0).
 template <class Exact, class ExactGrad>
 inline std::array<double, 2> compute_global_error(pdh_ctx *ctx, const FlatProblem &F, const std::vector<double> &solution,
@@ -1560,27 +1560,26 @@ inline std::array<double, 2> compute_global_error(pdh_ctx *ctx, const FlatProble
 {
   const int dim = F.c.dim;
   const int64_t N = F.vq_ptr.back();
-  std::vector<double> uh((size_t)N), gh(want_h1 ? (size_t)N * dim : 0);
-  if (pdh_evaluate(ctx, solution.data(), F.vq_ptr.data(), F.vq_x.data(), uh.data(), want_h1 ? gh.data() : nullptr) != PDH_OK)
-    throw std::runtime_error(std::string("pdh_evaluate: ") + pdh_last_error(ctx));
-  double l2 = 0.0, h1 = 0.0;
+  // the analytical solution is sampled here (the C ABI has no callbacks); u_h, grad u_h and the JxW-weighted sums of the squared
+  // differences are formed by ONE kernel on the device (pdh_global_error)
+  std::vector<double> eu((size_t)N), eg((size_t)N * dim, 0.0);
   for (int64_t q = 0; q < N; ++q)
     {
       double x[3] = {0, 0, 0}, g[3] = {0, 0, 0};
       for (int c = 0; c < dim; ++c)
         x[c] = F.vq_x[(size_t)c * N + q];
-      const double d = exact(x) - uh[q];
-      l2 += d * d * F.vq_w[q];
+      eu[q] = exact(x);
       if (want_h1)
         {
           exact_grad(x, g);
-          double s = 0.0;
           for (int c = 0; c < dim; ++c)
-            s += (g[c] - gh[(size_t)c * N + q]) * (g[c] - gh[(size_t)c * N + q]);
-          h1 += s * F.vq_w[q];
+            eg[(size_t)c * N + q] = g[c];
         }
     }
-  return {std::sqrt(l2), std::sqrt(h1)};
+  double sums[2] = {0.0, 0.0};
+  if (pdh_global_error(ctx, solution.data(), F.vq_ptr.data(), F.vq_x.data(), F.vq_w.data(), eu.data(), eg.data(), sums) != PDH_OK)
+    throw std::runtime_error(std::string("pdh_global_error: ") + pdh_last_error(ctx));
+  return {std::sqrt(sums[0]), want_h1 ? std::sqrt(sums[1]) : 0.0};
 }
 } // namespace PolyUtilsHIP
 

@@ -2146,6 +2146,77 @@ extern "C" int pdh_evaluate(pdh_ctx *ctx, const double *solution, const int64_t 
   return PDH_OK;
 }
 
+// ---- PolyUtils::compute_global_error fused on the device (reference include/poly_utils.h:1647-1750) -----------------------
+extern "C" hipError_t pdh_launch_eval_err(int dim, int n1d, const PdhDev *P, int count, const double *coef, const int64_t *pt_ptr,
+                                          const double *pts, int64_t pts_stride, const double *w, const double *exact_u,
+                                          const double *exact_g, double *err, hipStream_t stream);
+extern "C" int pdh_global_error_device(pdh_ctx *ctx, const double *d_solution, const int64_t *d_pt_ptr, const double *d_pts,
+                                       int64_t n_points, const double *d_w, const double *d_exact_u, const double *d_exact_grad,
+                                       double *sums)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (!ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "pdh_global_error called before pdh_set_problem");
+  if (!d_solution || !d_pt_ptr || !d_pts || !d_w || !d_exact_u || !d_exact_grad || !sums || n_points < 0)
+    return fail(ctx, PDH_EINVAL, "solution, pt_ptr, pts, w, exact_u, exact_grad and sums are required");
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  sums[0] = sums[1] = 0.0;
+  if (ctx->n_owned == 0)
+    return PDH_OK;
+  double *d_err = static_cast<double *>(ctx->scratch_get(5, (size_t)ctx->n_owned * 2 * sizeof(double)));
+  if (!d_err)
+    return fail(ctx, PDH_EDEVICE, "pdh_global_error: out of device memory");
+  PDH_HIP(ctx, pdh_launch_eval_err(ctx->dev.dim, ctx->dev.n1d, &ctx->dev, ctx->n_owned, d_solution, d_pt_ptr, d_pts, n_points, d_w,
+                                   d_exact_u, d_exact_grad, d_err, ctx->stream));
+  // 16 bytes per polytope come back; they are added in slot order (the result does not depend on the launch)
+  std::vector<double> h((size_t)ctx->n_owned * 2);
+  PDH_HIP(ctx, hipMemcpyAsync(h.data(), d_err, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int sl = 0; sl < ctx->n_owned; ++sl)
+    {
+      sums[0] += h[2 * (size_t)sl];
+      sums[1] += h[2 * (size_t)sl + 1];
+    }
+  return PDH_OK;
+}
+
+extern "C" int pdh_global_error(pdh_ctx *ctx, const double *solution, const int64_t *pt_ptr, const double *pts, const double *w,
+                                const double *exact_u, const double *exact_grad, double *sums)
+{
+  if (!ctx)
+    return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (!ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "pdh_global_error called before pdh_set_problem");
+  if (!solution || !pt_ptr || !pts || !w || !exact_u || !exact_grad || !sums)
+    return fail(ctx, PDH_EINVAL, "solution, pt_ptr, pts, w, exact_u, exact_grad and sums are required");
+  const int nA = ctx->n_agg_total, dim = ctx->dev.dim;
+  if (pt_ptr[0] != 0)
+    return fail(ctx, PDH_EINVAL, "pt_ptr[0] must be 0");
+  for (int a = 0; a < nA; ++a)
+    if (pt_ptr[a + 1] < pt_ptr[a])
+      return fail(ctx, PDH_EINVAL, "pt_ptr must be non-decreasing");
+  const int64_t N = pt_ptr[nA];
+  sums[0] = sums[1] = 0.0;
+  if (N == 0)
+    return PDH_OK;
+  PDH_HIP(ctx, hipSetDevice(ctx->device));
+  double *d_sol = static_cast<double *>(ctx->scratch_get(0, std::max<int64_t>(ctx->n_rows_owned, 1) * sizeof(double)));
+  double *d_pts = static_cast<double *>(ctx->scratch_get(1, (size_t)N * dim * sizeof(double)));
+  int64_t *d_ptr = static_cast<int64_t *>(ctx->scratch_get(2, ((size_t)nA + 1) * sizeof(int64_t)));
+  double *d_eu = static_cast<double *>(ctx->scratch_get(3, (size_t)N * 2 * sizeof(double))); // exact_u | w
+  double *d_eg = static_cast<double *>(ctx->scratch_get(4, (size_t)N * dim * sizeof(double)));
+  if (!d_sol || !d_pts || !d_ptr || !d_eu || !d_eg)
+    return fail(ctx, PDH_EDEVICE, "pdh_global_error: out of device memory");
+  PDH_HIP(ctx, hipMemcpyAsync(d_sol, solution, ctx->n_rows_owned * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_pts, pts, (size_t)N * dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_ptr, pt_ptr, ((size_t)nA + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_eu, exact_u, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_eu + N, w, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  PDH_HIP(ctx, hipMemcpyAsync(d_eg, exact_grad, (size_t)N * dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return pdh_global_error_device(ctx, d_sol, d_ptr, d_pts, N, d_eu + N, d_eu, d_eg, sums);
+}
+
 // ---- basis values on boxes (injection matrices) -----------------------------------------------------------------------
 extern "C" int pdh_shape_values_device(pdh_ctx *ctx, int dim, int degree, int basis, int n_boxes, const double *d_bbox,
                                        const int64_t *d_pt_ptr, const double *d_pts, int64_t n_points, double *d_values)

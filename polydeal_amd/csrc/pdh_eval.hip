@@ -44,11 +44,19 @@ __host__ __device__ constexpr int function_index(int k0, int k1, int k2)
   return -1;
 }
 
-template <int DIM, int N1D, bool GRAD, int BASIS>
+// ERR: instead of writing u_h / grad u_h, form the squared error sums of PolyUtils::compute_global_error (reference
+// include/poly_utils.h:1699-1745) per polytope:  err[slot] = { sum_q w (u - u_h)^2, sum_q w |grad u - grad u_h|^2 }  with the
+// exact values sampled by the caller at the same points - nothing per point leaves the device.
+struct EvalErr
+{
+  const double *w, *exact_u, *exact_g; // [N], [N], [dim][N]
+  double *err;                         // [n_owned][2]
+};
+template <int DIM, int N1D, bool GRAD, int BASIS, bool ERR = false>
 __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_owned, const double *__restrict__ coef,
                                                    const int64_t *__restrict__ pt_ptr, const double *__restrict__ pts,
                                                    const int64_t pts_stride, double *__restrict__ out_u,
-                                                   double *__restrict__ out_g, const int by_agg)
+                                                   double *__restrict__ out_g, const int by_agg, const EvalErr E = EvalErr{})
 {
   // by_agg: pt_ptr / pts / out are the CALLER's arrays, indexed by the polytope numbers of the description ([n_agg+1]);
   // otherwise they are compacted over the owned slots
@@ -69,6 +77,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_o
     lds[lane] = coef[P.own_row[slot] + lane];
   PDH_WAVE_SYNC();
   const int64_t qb = pt_ptr[by_agg ? agg : slot], qe = pt_ptr[(by_agg ? agg : slot) + 1];
+  double e_l2 = 0.0, e_h1 = 0.0;
   for (int64_t base = qb; base < qe; base += PDH_WAVE)
     {
       const int64_t q = base + lane;
@@ -76,6 +85,19 @@ __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_o
       double x[DIM];
       for (int c = 0; c < DIM; ++c)
         x[c] = on ? pts[c * pts_stride + q] : lo[c];
+      // (error mode: the exact values of this point are requested before the evaluation, consumed after it)
+      double ew = 0.0, eu = 0.0, eg[DIM];
+      for (int c = 0; c < DIM; ++c)
+        eg[c] = 0.0;
+      if constexpr (ERR)
+        if (on)
+          {
+            ew = E.w[q];
+            eu = E.exact_u[q];
+            if constexpr (GRAD)
+              for (int c = 0; c < DIM; ++c)
+                eg[c] = E.exact_g[c * pts_stride + q];
+          }
       double r[RC::LEN]; // (value, derivative / h) of every 1-D function, in registers (static indices only)
       eval_point_record<DIM, N1D, false>(P.tab, lo, h, x, 1.0, nullptr, r);
       // (the coefficient reads stay inside the loop: hoisted, the n coefficients would occupy 2 n VGPRs for the whole kernel -
@@ -127,12 +149,37 @@ __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_o
               }
           }
       });
-      if (on)
+      if constexpr (ERR)
+        {
+          e_l2 += ew * (eu - u) * (eu - u); // ew = 0 on lanes without a point
+          if constexpr (GRAD)
+            {
+              double s = 0.0;
+              for (int c = 0; c < DIM; ++c)
+                s += (eg[c] - g[c]) * (eg[c] - g[c]);
+              e_h1 += ew * s;
+            }
+        }
+      else if (on)
         {
           out_u[q] = u;
           if constexpr (GRAD)
             for (int c = 0; c < DIM; ++c)
               out_g[c * pts_stride + q] = g[c];
+        }
+    }
+  if constexpr (ERR)
+    {
+      // fixed-order butterfly over the wave: the sums of a polytope do not depend on anything but its points
+      for (int off = 32; off > 0; off >>= 1)
+        {
+          e_l2 += __shfl_xor(e_l2, off);
+          e_h1 += __shfl_xor(e_h1, off);
+        }
+      if (lane == 0)
+        {
+          E.err[2 * (int64_t)slot] = e_l2;
+          E.err[2 * (int64_t)slot + 1] = e_h1;
         }
     }
 }
@@ -209,6 +256,38 @@ extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_
   PDH_SHAPE_CASE(3, 1) PDH_SHAPE_CASE(3, 2) PDH_SHAPE_CASE(3, 3) PDH_SHAPE_CASE(3, 4)
   PDH_SHAPE_CASE(3, 5) PDH_SHAPE_CASE(3, 6)
 #undef PDH_SHAPE_CASE
+  return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t pdh_launch_eval_err(int dim, int n1d, const PdhDev *P, int count, const double *coef, const int64_t *pt_ptr,
+                                          const double *pts, int64_t pts_stride, const double *w, const double *exact_u,
+                                          const double *exact_g, double *err, hipStream_t stream)
+{
+  if (count <= 0)
+    return hipSuccess;
+  const dim3 grid((unsigned)count), block(PDH_WAVE);
+  int full = 1;
+  for (int c = 0; c < dim; ++c)
+    full *= n1d;
+  const bool dgq = P->n == full;
+  const pdh::EvalErr E{w, exact_u, exact_g, err};
+  const size_t lds = (size_t)PDH_WAVE * sizeof(double);
+#define PDH_ERR_CASE(D, N)                                                                                           \
+  if (dim == D && n1d == N)                                                                                          \
+    {                                                                                                                \
+      if (dgq)                                                                                                       \
+        hipLaunchKernelGGL((pdh::k_eval<D, N, true, 0, true>), grid, block, lds, stream, *P, count, coef, pt_ptr, pts, \
+                           pts_stride, nullptr, nullptr, 1, E);                                                      \
+      else                                                                                                           \
+        hipLaunchKernelGGL((pdh::k_eval<D, N, true, 1, true>), grid, block, lds, stream, *P, count, coef, pt_ptr, pts, \
+                           pts_stride, nullptr, nullptr, 1, E);                                                      \
+      return hipGetLastError();                                                                                      \
+    }
+  PDH_ERR_CASE(2, 1) PDH_ERR_CASE(2, 2) PDH_ERR_CASE(2, 3) PDH_ERR_CASE(2, 4)
+  PDH_ERR_CASE(2, 5) PDH_ERR_CASE(2, 6) PDH_ERR_CASE(2, 7) PDH_ERR_CASE(2, 8)
+  PDH_ERR_CASE(3, 1) PDH_ERR_CASE(3, 2) PDH_ERR_CASE(3, 3) PDH_ERR_CASE(3, 4)
+  PDH_ERR_CASE(3, 5) PDH_ERR_CASE(3, 6)
+#undef PDH_ERR_CASE
   return hipErrorInvalidValue;
 }
 

@@ -1,5 +1,5 @@
-"""Post-processing on the HIP path: evaluation of the polytopal solution on the device,
-weighted sums on the host.
+"""Post-processing on the HIP path: evaluation of the polytopal solution AND the weighted error sums on
+the device (pdh_global_error: one kernel, 16 bytes per polytope come back).
 
 Mirrors PolyUtils::compute_global_error (reference include/poly_utils.h:1647-1750) and the evaluation step of
 PolyUtils::interpolate_to_fine_grid (:1145-1274).  The evaluation itself is ``Context.evaluate`` ->
@@ -20,15 +20,11 @@ def compute_global_error(ctx: Context, vq_ptr, vq_x, vq_w, solution, exact, exac
     partitioned problem, as the reference does with Utilities::MPI::sum, poly_utils.h:1736-1745)."""
     vq_x = np.asarray(vq_x, dtype=np.float64)
     vq_w = np.asarray(vq_w, dtype=np.float64)
-    res = ctx.evaluate(solution, vq_ptr, vq_x, want_grad=exact_grad is not None)
-    uh, gh = res if exact_grad is not None else (res, None)
-    owned = ctx.owned_point_mask(vq_ptr)
     xs = vq_x.T
-    l2 = float(np.sum(((exact(xs) - uh) ** 2 * vq_w)[owned]))
-    if exact_grad is None:
-        return np.sqrt(l2), None
-    h1 = float(np.sum((np.sum((exact_grad(xs).T - gh) ** 2, axis=0) * vq_w)[owned]))
-    return np.sqrt(l2), np.sqrt(h1)
+    eu = np.asarray(exact(xs), dtype=np.float64)
+    eg = np.zeros_like(vq_x) if exact_grad is None else np.ascontiguousarray(np.asarray(exact_grad(xs), dtype=np.float64).T)
+    l2, h1 = ctx.global_error_sums(solution, vq_ptr, vq_x, vq_w, eu, eg)
+    return np.sqrt(l2), (None if exact_grad is None else np.sqrt(h1))
 
 
 def interpolate_to_points(ctx: Context, solution, pt_ptr, pts):

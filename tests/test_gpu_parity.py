@@ -158,7 +158,22 @@ def test_cpp_examples_run():
             assert g.startswith("Test with 1: ") and abs(float(g.split(":")[1])) < 1e-12
         else:
             assert g == w
-    out = subprocess.run([os.path.join(root, "examples", "poisson")], capture_output=True, text=True, timeout=300)
+    # examples/poisson.cc: p-convergence on t3.msh refined twice, 364 agglomerates, FE_AggloDGP(1..4), product_sine solution -
+    # matrix, right-hand side, evaluation (interpolate_to_fine_grid) and error norms through the HIP path, CG on the host
+    mesh = os.path.join(root, "tests", "golden", "t3.msh")
+    out = subprocess.run([os.path.join(root, "examples", "poisson"), mesh], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.split("\n")
+    assert lines[0] == "Testing p-convergence" and [l for l in lines if l.startswith("Fe degree: ")] == ["Fe degree: %d" % p for p in (1, 2, 3, 4)]
+    assert sum(l.startswith("Time taken by assemble_system(): ") for l in lines) == 4
+    l2 = [float(l.split(":")[1]) for l in lines if l.startswith("Error (L2):")]
+    h1 = [float(l.split(":")[1]) for l in lines if l.startswith("Error (H1):")]
+    nodal = [float(l.split()[-1]) for l in lines if l.startswith("interpolate_to_fine_grid:")]
+    assert len(l2) == len(h1) == len(nodal) == 4
+    # 364 polytopes of diameter ~0.1: sin(pi x) sin(pi y) is resolved better by a factor >= 4 (L2) / 2.5 (H1) per degree
+    assert all(l2[k + 1] < 0.25 * l2[k] and h1[k + 1] < 0.4 * h1[k] for k in range(3)), (l2, h1)
+    assert l2[0] < 5e-2 and l2[3] < 5e-7 and h1[3] < 5e-5 and nodal[3] < 5e-6, (l2, h1, nodal)
+    out = subprocess.run([os.path.join(root, "examples", "poisson"), "--bench"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Assembled DoF/s" in out.stdout
     line = [l for l in out.stdout.split("\n") if l.startswith("compute_global_error")][0].replace("(", " ").replace(")", " ")
@@ -400,6 +415,14 @@ def test_evaluate_and_global_error_parity(dim, lg, b, fe_cls, p, dist):
     assert np.max(np.abs(gh - ref_g)) <= TOL * np.max(np.abs(ref_g))
     rl2, rh1 = po.compute_global_error(ah, u, exact, exact_grad)
     assert abs(l2 - rl2) <= TOL * rl2 and abs(h1 - rh1) <= TOL * rh1
+    # the sums are formed on the device (pdh_global_error: 16 bytes per polytope come back): same numbers as summing the
+    # evaluated values here, and reproducible bit for bit
+    xs = np.asarray(kw["vq_x"]).T
+    eu, eg = exact(xs), exact_grad(xs).T
+    s_dev = ctx.global_error_sums(u, kw["vq_ptr"], kw["vq_x"], kw["vq_w"], eu, eg)
+    s_host = (float(np.sum(kw["vq_w"] * (eu - uh) ** 2)), float(np.sum(kw["vq_w"] * np.sum((eg - gh) ** 2, axis=0))))
+    assert abs(s_dev[0] - s_host[0]) <= 1e-13 * s_host[0] and abs(s_dev[1] - s_host[1]) <= 1e-13 * s_host[1]
+    assert s_dev == ctx.global_error_sums(u, kw["vq_ptr"], kw["vq_x"], kw["vq_w"], eu, eg)
 
     # two "ranks": squares of the partial errors add up (poly_utils.h:1736-1745)
     s2 = np.zeros(2)
