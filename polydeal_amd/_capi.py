@@ -105,6 +105,8 @@ def _bind(lib):
     lib.pdh_shape_values_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_void_p]
     lib.pdh_shape_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+    lib.pdh_global_error.argtypes = [C.c_void_p] * 7 + [P(C.c_double)]
+    lib.pdh_global_error_device.argtypes = [C.c_void_p] * 4 + [C.c_int64] + [C.c_void_p] * 3 + [P(C.c_double)]
     lib.pdh_device_values.argtypes = [C.c_void_p, P(C.c_void_p), P(C.c_int64)]
     lib.pdh_synchronize.argtypes = [C.c_void_p]
     lib.pdh_stream.argtypes = [C.c_void_p]

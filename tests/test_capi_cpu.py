@@ -159,3 +159,13 @@ def test_row_kernel_eligibility_is_decided_on_the_quadrature_data(basis, p):
     ah, fe = handler(2, 3)
     rc, why = _rows_applies(ah.flatten(pa.SipVariant.poisson_example(fe), True, False))
     assert rc == 0 and "3-D" in why, why
+
+
+def test_every_entry_point_has_declared_argument_types():
+    """ctypes passes an undeclared Python int as a C int: a 64-bit pointer survives that only by accident (found as a segfault
+    of a new entry point on the GPU box).  Every exported function that takes arguments must have its argtypes declared."""
+    from polydeal_amd import _capi
+
+    lib = pa.load_library()
+    missing = [s for s in _capi.EXPORTS if s != "pdh_version" and getattr(lib, s).argtypes is None]
+    assert not missing, missing
