@@ -821,6 +821,41 @@ __device__ __forceinline__ void mstage3(const ASet &X, const double *T2B, int la
   });
 }
 
+// Stage 3 with the operand ROLES SWAPPED (row kernel, pdh_rows.h): the T2 fragment is the A operand, the table the B operand.
+//   D lane (i, blk, j) = sum_a0 T2[a0][(s1; o1 = blk, o2 = i)] X[s0][o0 = j][a0]   ->   column O = o0 + 4 o1 + 16 o2 = lane
+// - a result register is still one complete row, and now in the NATURAL column order: lane l holds column l, so the
+// epilogue stores it as it stands (no transposition through LDS).  The table registers are the same (an ASet holds
+// X[s][idx][k] with idx = lane & 3 in all four lane blocks - A and B fragments are addressed alike); the T2 fragment wants
+// (o1, o2) = (blk, idx) where the B-operand order had (idx, blk), so the producer scatters accordingly.  Rotation inside
+// aligned blocks of 16 doubles: 2 kq + 8 ks (conflict-free for the writer's 16-lane groups: banks h + 2 j + 8 (blk & 1)).
+__device__ __forceinline__ void mstage2_scatter_t(const double (&D2)[2][4], double *T2B, int lane)
+{
+  const int i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+  static_for<0, 2>([&](auto bf_) {
+    constexpr int bf = bf_;
+    static_for<0, 4>([&](auto r_) {
+      constexpr int r = r_;
+      // D2[bf][s1 = r] lane (i, blk, j) = T2[a0 = 4 (blk & 1) + j][(s1, o1 = i, o2 = 2 bf + (blk >> 1))]
+      // reader lane (kq = j, blk_r = o1 = i, idx_r = o2) of fragment (ks = blk & 1, cf = s1)
+      T2B[((blk & 1) * 4 + r) * 64 + j * 16 + ((4 * i + 2 * bf + (blk >> 1) + 2 * j + 8 * (blk & 1)) & 15)] = D2[bf][r];
+    });
+  });
+}
+__device__ __forceinline__ void mstage3_t(const ASet &X, const double *T2B, int lane, double (&D3)[4][4])
+{
+  static_for<0, 2>([&](auto ks_) {
+    constexpr int ks = ks_;
+    static_for<0, 4>([&](auto cf_) {
+      constexpr int cf = cf_;
+      const double a = T2B[(ks * 4 + cf) * 64 + ((lane & 48) | ((lane + 2 * (lane >> 4) + 8 * ks) & 15))];
+      static_for<0, 4>([&](auto r_) {
+        constexpr int r = r_;
+        D3[cf][r] = pdh::mfma4(a, X.a[r][ks], D3[cf][r]);
+      });
+    });
+  });
+}
+
 template <int N1D>
 constexpr int lds_doubles_diag()
 {

@@ -1392,9 +1392,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   {
     double *T1B = W;                  // [4 arrays][2 bf][2 ks][64]
     double *T2B = W + 4 * 2 * 2 * 64; // [2 ks][4 cf][64]
-    double *rowst = W;                // [16 rows][64 columns] (after stage 3)
-    const int di = lane >> 4, dblk = (lane >> 2) & 3, dj = lane & 3;
-    const int O = di + 4 * dj + 16 * dblk; // this lane's column in the D layout of stage 3
+    // (stage 3 runs with the operand roles swapped, pdh_moment.h: mstage3_t - a result register D3[cf][s0] is row
+    // s0 + 4 cf + 16 k2 of the block with lane l holding column l, stored as it stands)
+    double dg = 0.0; // lane R: the diagonal entry A[R,R] (diagonal-first rows: kept for piece 0 of the row, P5)
     pdhm::T1Off t1o;
     t1o.init(a0, a1);
 #ifdef PDHR_STAMP
@@ -1449,9 +1449,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           PDH_WAVE_SYNC();
           double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = D
           pdhm::mstage2_term(AE, 0, ih0 * ih0, T1B, lane, D2);
-          pdhm::mstage2_scatter(D2, T2B, lane);
+          pdhm::mstage2_scatter_t(D2, T2B, lane);
           PDH_WAVE_SYNC();
-          pdhm::mstage3(AD, T2B, lane, D3);
+          pdhm::mstage3_t(AD, T2B, lane, D3);
         }
         {
           PDH_WAVE_SYNC();
@@ -1459,24 +1459,25 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           pdhm::mstage2_term(AD, 0, ih1 * ih1, T1B, lane, D2);
           pdhm::mstage2_term(AE, 1, 1.0, T1B, lane, D2);
           pdhm::mstage2_term(AF, 3, ih1, T1B, lane, D2);
-          pdhm::mstage2_scatter(D2, T2B, lane);
+          pdhm::mstage2_scatter_t(D2, T2B, lane);
           PDH_WAVE_SYNC();
-          pdhm::mstage3(AE, T2B, lane, D3);
+          pdhm::mstage3_t(AE, T2B, lane, D3);
         }
         {
           PDH_WAVE_SYNC();
           double D2[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}; // X = Fs
           pdhm::mstage2_term(AE, 2, ih0, T1B, lane, D2);
-          pdhm::mstage2_scatter(D2, T2B, lane);
+          pdhm::mstage2_scatter_t(D2, T2B, lane);
           PDH_WAVE_SYNC();
-          pdhm::mstage3(AF, T2B, lane, D3);
+          pdhm::mstage3_t(AF, T2B, lane, D3);
         }
 #ifdef PDHR_STAMP
         const long long ts2_ = (long long)__builtin_readcyclecounter();
         tq2 += ts2_ - ts1_;
 #endif
         if (!shifted)
-          { // ascending layout: the own block is aligned, a register is a complete row
+          { // ascending layout: the own block is aligned, a register is a complete row in column order
+            const uint32_t loff4 = (uint32_t)lane * 8u;
             static_for<0, 4>([&](auto cf_) {
               constexpr int cf = cf_;
               static_for<0, 4>([&](auto s0_) {
@@ -1484,61 +1485,39 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 const int R = s0 + 4 * cf + 16 * k2;
                 // (D3 comes straight out of the MFMA: the hazard between an MFMA result and the store that reads it is the
                 // compiler's to resolve)
-                row_store(D3[cf][s0], (uint32_t)O * 8u, (uint32_t)(R * rlen + L) * 8u);
+                row_store(D3[cf][s0], loff4, (uint32_t)(R * rlen + L) * 8u);
               });
             });
           }
         else
           {
-            // diagonal-first layout: piece m0 of row R = [carry | own columns without the diagonal]; the diagonal entry is
-            // position 0 of the row (lane 0 of piece 0: written here if the own block is the first one, else kept for P5)
-            PDH_WAVE_SYNC();
-            // (columns rotated inside blocks of 16 by the block number: a write group's 16 lanes hold O = i + 4 j + 16 blk,
-            // i fixed - four banks without the rotation)
-            const int Osw = (O & 48) | ((O + (O >> 4)) & 15);
-            static_for<0, 4>([&](auto cf_) {
-              constexpr int cf = cf_;
-              static_for<0, 4>([&](auto s0_) {
-                constexpr int s0 = s0_;
-                rowst[(s0 + 4 * cf) * 64 + Osw] = D3[cf][s0];
-              });
-            });
-            PDH_WAVE_SYNC();
-            // row R: lane 0 takes column R (the diagonal entry), lane l >= 1 column l - 1 or l (the diagonal is skipped).
-            // Both candidate tile addresses of a lane do not depend on the row; the carry of row R comes out of lane R of
-            // carry_own by v_readlane and goes into lane 0 by v_writelane; scalar row pointer + 32-bit lane offset.
-            auto sw = [](int c_) { return (c_ & 48) | ((c_ + (c_ >> 4)) & 15); };
-            const int swA = sw(lane > 0 ? lane - 1 : 0), swB = sw(lane), lm1 = lane - 1;
-            const int co_lo = __double2loint(carry_own), co_hi = __double2hiint(carry_own);
-            const uint32_t loff4 = (uint32_t)lane * 8u;
+            // diagonal-first layout: piece m0 of row R = [carry | own columns without the diagonal]: column c sits at position
+            // c + 1 (c < R) or c (c > R) of the piece; the diagonal entry belongs to position 0 of the ROW (= of this piece if
+            // the own block is the first one, m0 = 0; else piece 0 takes it in P5 from diagv), and position 0 of this piece
+            // takes the carry (last column of the block before).  Lane R - the one holding the diagonal entry - is the lane
+            // whose slot is free: it stores the carry of row R, which carry_own holds in exactly that lane.  So a row is ONE
+            // store of 512 contiguous bytes with the lanes 0 .. R rotated by one position: no transposition, no LDS.
+            const uint32_t offA = (uint32_t)(lane + 1) * 8u, offB = (uint32_t)lane * 8u;
             uint32_t rowrun = (uint32_t)(16 * k2 * rlen + L) * 8u; // uniform: byte offset of the row's piece
             auto own_rows = [&](auto carry_) {
               constexpr bool CARRY = carry_;
-              // all 16 tile reads first (one LDS round trip for the slab, not one per row)
-              double vr[16];
-              static_for<0, 16>([&](auto r_) {
-                constexpr int r = r_;
-                const int R = r + 16 * k2;
-                int a = lm1 >= R ? swB : swA;
-                a = lane == 0 ? sw(R) : a;
-                vr[r] = rowst[r * 64 + a];
-              });
-              static_for<0, 16>([&](auto r_) {
-                constexpr int r = r_;
-                const int R = r + 16 * k2;
-                double v = vr[r];
-                if constexpr (CARRY)
-                  {
-                    if (lane == 0)
-                      diagv[R] = v; // kept for piece 0 (P5)
-                    int lo_ = __double2loint(v), hi_ = __double2hiint(v);
-                    const int slo = __builtin_amdgcn_readlane(co_lo, R), shi = __builtin_amdgcn_readlane(co_hi, R);
-                    asm("v_writelane_b32 %0, %1, 0" : "+v"(lo_) : "s"(slo));
-                    asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
-                    v = __hiloint2double(hi_, lo_);
-                  }
-                row_store(v, loff4, rowrun);
-                rowrun += (uint32_t)rlen * 8u;
+              static_for<0, 4>([&](auto cf_) {
+                constexpr int cf = cf_;
+                static_for<0, 4>([&](auto s0_) {
+                  constexpr int s0 = s0_;
+                  const int R = s0 + 4 * cf + 16 * k2; // uniform
+                  const bool below = lane < R, diag = lane == R;
+                  double v = D3[cf][s0];
+                  uint32_t off = below ? offA : offB;
+                  off = diag ? 0u : off;
+                  if constexpr (CARRY)
+                    {
+                      dg = diag ? v : dg;
+                      v = diag ? carry_own : v;
+                    }
+                  row_store(v, off, rowrun);
+                  rowrun += (uint32_t)rlen * 8u;
+                });
               });
             };
             if (m0 > 0)
@@ -1550,6 +1529,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         tq3 += (long long)__builtin_readcyclecounter() - ts2_;
 #endif
       }
+    if (shifted && m0 > 0)
+      diagv[lane] = dg; // (read by P5 for piece 0, after its wave-level synchronisation)
 #ifdef PDHR_STAMP
     if (lane == 0 && Rw.stamps)
       {
