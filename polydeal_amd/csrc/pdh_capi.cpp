@@ -1641,6 +1641,17 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
               return rc;
             }
           {
+            void *dq = nullptr;
+            if (hipMalloc(&dq, 64) != hipSuccess)
+              {
+                free_problem(ctx);
+                return fail(ctx, PDH_EDEVICE, "row kernel: out of device memory");
+              }
+            ctx->allocs.push_back(dq);
+            (void)hipMemset(dq, 0, 64);
+            R.sched = static_cast<unsigned int *>(dq);
+          }
+          {
             void *ds = nullptr;
             const size_t nb = (size_t)std::max(K.n_owned, 1) * 16 * sizeof(long long);
             if (hipMalloc(&ds, nb) == hipSuccess)

@@ -53,9 +53,18 @@
 #include "pdh_rows_tables.h"
 
 // experiment switches (tools/ab_bench.py; never defined in the shipped build): -DPDHR_EXP=1 no coupling blocks (P5),
-// 2 no diagonal block (P4), 3 no faces (P2), 4 no volume (P1), 5 P5 without its global stores
+// 2 no diagonal block (P4), 3 no faces (P2), 4 no volume (P1), 5 P5 without its global stores, 6 no row stores at all
 #ifndef PDHR_EXP
 #define PDHR_EXP 0
+#endif
+// 1: the blocks RIGHT of the diagonal (aligned pieces, no carries) are written before the diagonal block, the blocks left of it
+// after: the row stores of a polytope come in three bursts (192 | 64 | 192 for a block-shaped polytope) instead of one of
+// 448 at the end - the kernel is bound by how well its stores overlap with the arithmetic of the other waves of the CU
+#ifndef PDHR_SPLIT
+#define PDHR_SPLIT 1
+#endif
+#ifndef PDHR_STORE_AUX
+#define PDHR_STORE_AUX 18 // gfx940+ cache-policy bits of the row stores: 1 = sc0, 2 = nt, 16 = sc1
 #endif
 
 // -DPDHR_CHECK (diagnostic builds only): every data-dependent point index of a global load is checked against the size of
@@ -268,14 +277,34 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       m.e[0] = r[lane - maxe];
     return m;
   };
+  // Work distribution: the first polytope of a wave is its block number, every further one comes from a device-wide counter
+  // (PdhRows::sched[0], one returning atomic add per polytope, requested a whole polytope ahead of its use).  A static stride
+  // (slot += gridDim.x) left the waves of the faster CUs / XCDs idle while the slowest finished: per-wave spans of 0.81 .. 1.15
+  // of the mean (in-kernel stamps, 2048 waves x 16 polytopes), i.e. a tail of 13 % of the kernel.  The wave that leaves last
+  // (sched[1] counts leavers) puts both words back to zero for the next launch - launches of one context are stream-ordered.
+  auto leave = [&]() {
+    // (every wave has made its last request to sched[0] before it counts itself out: the last one out may reset both)
+    if (threadIdx.x == 0)
+      if (__hip_atomic_fetch_add(Rw.sched + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+        {
+          __hip_atomic_store(Rw.sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(Rw.sched + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+  };
   int slot = blockIdx.x;
   if (slot >= n_owned)
-    return;
+    { // (the launcher never starts more waves than polytopes; counted out all the same, or the counters would not be reset)
+      leave();
+      return;
+    }
   Meta cur = load_meta(slot);
   const int lane_outer = lane;
 #pragma unroll 1
-  for (; slot < n_owned; slot += (int)gridDim.x)
+  for (;;)
   {
+  int nslot_v = 0;
+  if (lane_outer == 0)
+    nslot_v = (int)gridDim.x + (int)__hip_atomic_fetch_add(Rw.sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // Everything derived from the lane number below is loop-invariant; hoisted out of this loop it would sit in ~60 VGPRs for
   // the whole kernel (the compiler did exactly that: 256 VGPRs + spills).  An opaque copy ties it to the iteration.
   int lane = lane_outer;
@@ -296,7 +325,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   // the polytope's rows as a buffer: n rows of rlen values from rbase on (see "Row stores" at the top of this file)
   const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(P.values + rbase, 0, NF * rlen * 8, 0x00020000);
   auto row_store = [&](double v, uint32_t lane_bytes, uint32_t row_bytes) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v), vrs, (int)lane_bytes, (int)row_bytes, 0);
+#if PDHR_EXP == 6
+    if (P.n < 0) // (experiment: everything computed, nothing stored)
+#endif
+    // cache policy sc1 | nt: the values are written once and not read again by this kernel; written through (the line is not kept in
+    // the XCD's L2) the same stores run 5 % faster in the store-only twin of this kernel (tools/probes/rows_store_probe.hip:
+    // 1.37 -> 1.30 ms at 8 waves per CU)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v), vrs, (int)lane_bytes, (int)row_bytes, PDHR_STORE_AUX);
   };
   // the face table of the polytope lives in the lanes (lane t = face t); a face's entries are read with v_readlane
   const long long pb_ = __double_as_longlong(cur.e[0]);
@@ -1225,6 +1260,135 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           carry_own = (MULTI ? carry_own : 0.0) + last_column(rl_i(t_axis, t));
         }
 
+  // ================= coupling blocks (FE_DGQ(3), one plane per neighbour): P5 of the phase list ===========================
+  // LEFT_PASS = false: the blocks right of the diagonal (every block in the ascending layout) - plain aligned pieces, no
+  // dependence on anything but their own face: written HERE, before the diagonal block (PDHR_SPLIT).  LEFT_PASS = true: the
+  // blocks left of the diagonal, whose pieces start with the last column of the block before (the first one with the
+  // diagonal entry, which P4 leaves in diagv): after P4.
+  auto coupling_blocks = [&](auto left_pass_) {
+    constexpr bool LEFT_PASS = left_pass_;
+    // (the ascending layout has aligned pieces only: one pass, after the diagonal block - before it the moment accumulators
+    // are still live and the pass would spill)
+    constexpr bool SPLIT = PDHR_SPLIT && SHIFTED;
+    double carry = 0.0; // lane R: the value that lane 0 stores in row R of the next piece
+    bool first_left = true;
+#if PDHR_EXP == 1
+    for (int t = n_bdry; t < nfaces && P.n < 0; ++t)
+#else
+    for (int t = n_bdry; t < nfaces; ++t)
+#endif
+      {
+        const int b = rl_i(t_blk, t);
+        const int c = rl_i(t_axis, t);
+        const bool left = shifted && b < m0;
+        if (SPLIT && left != LEFT_PASS)
+          continue;
+        PDH_WAVE_SYNC();
+        const bool first_piece = left && first_left; // piece 0 starts with the diagonal entry (diagv, written in P4)
+        if (left)
+          first_left = false;
+        build_S(t);
+        // this lane's column of the block: shifted pieces hold columns -1 .. 62 (lane 0: the carry)
+        const int jcol = left ? (lane > 0 ? lane - 1 : 0) : lane;
+        const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
+        double Cl[4], sc[16];
+        for (int k = 0; k < 4; ++k)
+          Cl[k] = Cbuf[k * 4 + lc];
+        for (int u = 0; u < 16; ++u)
+          sc[u] = Sbuf[u * 16 + vt];
+        const double next_carry = left ? last_column(c) : 0.0;
+        // rows: value = Cl[k_c(R)] * sc[u(R)].  Shifted pieces: lane 0 stores the carry of row R instead.  The carries of all
+        // rows (lane R = row R: `carry` of the block before, or the diagonal entries P4 left in diagv for piece 0) stand in
+        // LDS; eight rows at a time, lane 0 ALONE reads its eight carries straight into the product registers (EXEC = 1 around
+        // the eight ds_read: the other lanes keep their products), one wait, eight stores.  No VALU instruction per row but
+        // the multiply - the carries used to travel by v_readlane + v_writelane pairs, four VALU instructions per row, 768 per
+        // block-shaped polytope (an eighth of all the kernel's VALU work).  The row address is a scalar offset + lane.
+        double *ctab = W + 1536; // [64] (behind the scratch of build_S)
+        if (left && !first_piece)
+          ctab[lane] = carry;
+        const double *csrc = first_piece ? diagv : ctab; // uniform
+        typedef __attribute__((address_space(3))) const char lds_cchar;
+        const unsigned caddr = (unsigned)(uintptr_t)(lds_cchar *)reinterpret_cast<const char *>(csrc);
+        if (left)
+          PDH_WAVE_SYNC();
+        const uint32_t rowp = 64u * 8u * (uint32_t)b; // uniform: byte offset of the piece in row 0
+        const uint32_t lane_off = (uint32_t)lane * 8u;
+        auto rows = [&, lane_off](auto c_, auto left_) {
+          constexpr int cc = c_;
+          constexpr bool LEFT = left_;
+          const uint32_t loff = lane_off;
+          uint32_t rowrun = rowp;
+          static_for<0, 8>([&](auto g_) {
+            constexpr int g = g_;
+            double v[8];
+            static_for<0, 8>([&](auto r_) {
+              constexpr int R = 8 * g + r_;
+              constexpr int kc = (R >> (2 * cc)) & 3;
+              constexpr int k0 = R & 3, k1 = (R >> 2) & 3, k2 = (R >> 4) & 3;
+              constexpr int u = cc == 0 ? (k1 + 4 * k2) : (cc == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
+              v[r_] = Cl[kc] * sc[u];
+            });
+            if constexpr (LEFT)
+              {
+                // (one self-contained statement: EXEC is all ones before - uniform code of a one-wave workgroup - and after;
+                // the LDS reads are waited for inside, so nothing is outstanding that the compiler does not know of)
+                asm volatile("s_mov_b64 exec, 1\n\t"
+                             "ds_read_b64 %0, %8 offset:%9\n\t"
+                             "ds_read_b64 %1, %8 offset:%10\n\t"
+                             "ds_read_b64 %2, %8 offset:%11\n\t"
+                             "ds_read_b64 %3, %8 offset:%12\n\t"
+                             "ds_read_b64 %4, %8 offset:%13\n\t"
+                             "ds_read_b64 %5, %8 offset:%14\n\t"
+                             "ds_read_b64 %6, %8 offset:%15\n\t"
+                             "ds_read_b64 %7, %8 offset:%16\n\t"
+                             "s_mov_b64 exec, -1\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                             : "v"(caddr), "n"(64 * g + 0), "n"(64 * g + 8), "n"(64 * g + 16), "n"(64 * g + 24), "n"(64 * g + 32),
+                               "n"(64 * g + 40), "n"(64 * g + 48), "n"(64 * g + 56));
+              }
+            static_for<0, 8>([&](auto r_) {
+#if PDHR_EXP == 5
+              if (P.n < 0)
+#endif
+                row_store(v[r_], loff, rowrun); // (a running offset: 64 precomputed row offsets would be spilled scalars)
+              rowrun += (uint32_t)rlen * 8u;
+            });
+          });
+        };
+        using std::integral_constant;
+        // (with PDHR_SPLIT a pass meets one kind of piece only: the other kind's code is not instantiated for it)
+        if (left)
+          {
+            if constexpr (LEFT_PASS || !SPLIT)
+              {
+                if (c == 0)
+                  rows(integral_constant<int, 0>{}, std::true_type{});
+                else if (c == 1)
+                  rows(integral_constant<int, 1>{}, std::true_type{});
+                else
+                  rows(integral_constant<int, 2>{}, std::true_type{});
+              }
+          }
+        else
+          {
+            if constexpr (!LEFT_PASS || !SPLIT)
+              {
+                if (c == 0)
+                  rows(integral_constant<int, 0>{}, std::false_type{});
+                else if (c == 1)
+                  rows(integral_constant<int, 1>{}, std::false_type{});
+                else
+                  rows(integral_constant<int, 2>{}, std::false_type{});
+              }
+          }
+        PDH_WAVE_SYNC();
+        carry = next_carry;
+      }
+  };
+  if constexpr (!SMALL && !MULTI && PDHR_SPLIT && SHIFTED)
+    coupling_blocks(std::false_type{});
+
   PDHR_MARK(4);
   // ================= P4: diagonal block ============================================================================
   PDH_WAVE_SYNC();
@@ -1397,6 +1561,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     double dg = 0.0; // lane R: the diagonal entry A[R,R] (diagonal-first rows: kept for piece 0 of the row, P5)
     pdhm::T1Off t1o;
     t1o.init(a0, a1);
+    // The K = 8 fragments of stage 2 read an eighth Legendre mode and an eighth (a0) row that do not exist: zero pads (row 7,
+    // column 7 of every [a0][a1] plane of T1B).  Nothing but stage 1 writes T1B between here and the end of P4, and stage 1
+    // writes the 49 values only: the pads are set ONCE per polytope - all 1024 doubles are cleared, 16 stores per lane, where
+    // the version that re-wrote its pads with every value spent three exec-masked stores per value (64 values per lane).
+    PDH_WAVE_SYNC();
+    for (int k = 0; k < 16; ++k)
+      T1B[k * 64 + lane] = 0.0;
 #ifdef PDHR_STAMP
     long long tq1 = 0, tq2 = 0, tq3 = 0;
 #endif
@@ -1426,10 +1597,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               n0 += e * accN[0][a];
               n1 += e * accN[1][a];
             });
-            pdhm::t1b_store<0, ll>(T1B, t1o, g1);
-            pdhm::t1b_store<1, ll>(T1B, t1o, ee);
-            pdhm::t1b_store<2, ll>(T1B, t1o, n0);
-            pdhm::t1b_store<3, ll>(T1B, t1o, n1);
+            // (values only: the zero pads of T1B were written once for this polytope, below)
+            T1B[(0 * 256 + (ll >> 1) * 128) + t1o.val[ll & 1]] = g1;
+            T1B[(1 * 256 + (ll >> 1) * 128) + t1o.val[ll & 1]] = ee;
+            T1B[(2 * 256 + (ll >> 1) * 128) + t1o.val[ll & 1]] = n0;
+            T1B[(3 * 256 + (ll >> 1) * 128) + t1o.val[ll & 1]] = n1;
           });
 #ifdef PDHR_STAMP
         const long long ts1_ = (long long)__builtin_readcyclecounter();
@@ -1545,8 +1717,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   // the next polytope's record is requested here: the store phase is long enough to hide the loads (~7k cycles), and
   // before it the 24 registers of the record would sit through the phases with the highest register pressure
   Meta nxt = cur;
-  if (slot + (int)gridDim.x < n_owned)
-    nxt = load_meta(slot + (int)gridDim.x);
+  const int nslot = __builtin_amdgcn_readfirstlane(nslot_v); // (requested at the top of this polytope)
+  if (nslot < n_owned)
+    nxt = load_meta(nslot);
   if constexpr (SMALL)
     {
       // ================= P5 (streamed kinds): the polytope's n rows are ONE contiguous range of n rlen values ==============
@@ -1755,93 +1928,16 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       }
   }
   else
-  // ================= P5: coupling blocks in ascending column order ====================================================
+  // ================= P5: coupling blocks left of the diagonal, in ascending column order ================================
   {
-    double carry = 0.0; // lane R: the value that lane 0 stores in row R of the next piece
-    bool first_left = true;
-#if PDHR_EXP == 1
-    for (int t = n_bdry; t < nfaces && P.n < 0; ++t)
-#else
-    for (int t = n_bdry; t < nfaces; ++t)
-#endif
-      {
-        const int b = rl_i(t_blk, t);
-        const int c = rl_i(t_axis, t);
-        const bool left = shifted && b < m0;
-        PDH_WAVE_SYNC();
-        const bool first_piece = left && first_left; // piece 0 starts with the diagonal entry (diagv, written in P4)
-        if (left)
-          first_left = false;
-        build_S(t);
-        // this lane's column of the block: shifted pieces hold columns -1 .. 62 (lane 0: the carry)
-        const int jcol = left ? (lane > 0 ? lane - 1 : 0) : lane;
-        const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
-        double Cl[4], sc[16];
-        for (int k = 0; k < 4; ++k)
-          Cl[k] = Cbuf[k * 4 + lc];
-        for (int u = 0; u < 16; ++u)
-          sc[u] = Sbuf[u * 16 + vt];
-        const double next_carry = left ? last_column(c) : 0.0;
-        // rows: value = Cl[k_c(R)] * sc[u(R)].  Shifted pieces: lane 0 stores the carry of row R instead.  The carries of all
-        // rows sit in ONE register (lane R = row R: `carry` of the block before, or the diagonal entries P4 left in diagv
-        // for piece 0) and reach lane 0 through v_readlane / v_writelane - an LDS broadcast per row made every row wait for
-        // its own LDS round trip (a quarter of this phase).  The row address is a scalar base + lane.
-        const double cvec = first_piece ? diagv[lane] : carry;
-        const int cvec_lo = __double2loint(cvec), cvec_hi = __double2hiint(cvec);
-        const uint32_t rowp = 64u * 8u * (uint32_t)b; // uniform: byte offset of the piece in row 0
-        const uint32_t lane_off = (uint32_t)lane * 8u;
-        auto rows = [&, lane_off](auto c_, auto left_) {
-          constexpr int cc = c_;
-          constexpr bool LEFT = left_;
-          const uint32_t loff = lane_off;
-          uint32_t rowrun = rowp;
-          static_for<0, 64>([&](auto R_) {
-            constexpr int R = R_;
-            constexpr int kc = (R >> (2 * cc)) & 3;
-            constexpr int k0 = R & 3, k1 = (R >> 2) & 3, k2 = (R >> 4) & 3;
-            constexpr int u = cc == 0 ? (k1 + 4 * k2) : (cc == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
-            double v = Cl[kc] * sc[u];
-            if constexpr (LEFT)
-              {
-                // (this compiler has no writelane builtin)
-                int lo_ = __double2loint(v), hi_ = __double2hiint(v);
-                const int slo = __builtin_amdgcn_readlane(cvec_lo, R), shi = __builtin_amdgcn_readlane(cvec_hi, R);
-                asm("v_writelane_b32 %0, %1, 0" : "+v"(lo_) : "s"(slo));
-                asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
-                v = __hiloint2double(hi_, lo_);
-              }
-#if PDHR_EXP == 5
-            if (P.n < 0)
-#endif
-              row_store(v, loff, rowrun); // (a running offset: 64 precomputed row offsets would be spilled scalars)
-            rowrun += (uint32_t)rlen * 8u;
-          });
-        };
-        using std::integral_constant;
-        if (left)
-          {
-            if (c == 0)
-              rows(integral_constant<int, 0>{}, std::true_type{});
-            else if (c == 1)
-              rows(integral_constant<int, 1>{}, std::true_type{});
-            else
-              rows(integral_constant<int, 2>{}, std::true_type{});
-          }
-        else
-          {
-            if (c == 0)
-              rows(integral_constant<int, 0>{}, std::false_type{});
-            else if (c == 1)
-              rows(integral_constant<int, 1>{}, std::false_type{});
-            else
-              rows(integral_constant<int, 2>{}, std::false_type{});
-          }
-        PDH_WAVE_SYNC();
-        carry = next_carry;
-      }
+    coupling_blocks(std::true_type{});
   }
   PDHR_MARK(6);
+  if (nslot >= n_owned)
+    break;
+  slot = nslot;
   cur = nxt;
   } // persistent loop over the wave's slots
+  leave();
 }
 } // namespace pdhr

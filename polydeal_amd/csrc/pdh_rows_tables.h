@@ -23,5 +23,7 @@ struct PdhRows
   int32_t multi;           // 1: take the MULTI instantiation
   int32_t maxe;            // face entries a record provides for (16 unless multi): record = 12 + 12 maxe doubles
   int32_t maxf;            // interior entries (coupling-moment slots in LDS) a polytope may have (6 unless multi)
+  unsigned int *sched;     // [2] work counter of the persistent waves and count of the waves that have left (both zero
+                           // between launches: the last wave out resets them)
   long long *stamps;       // [n_owned][16] s_memtime at the phase boundaries; written by -DPDHR_STAMP builds only
 };

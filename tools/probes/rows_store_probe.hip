@@ -1,0 +1,116 @@
+// rows_store_probe.hip — what the STORES of the row kernel (pdh_rows.h) cost on their own: the same persistent structure
+// (W single-wave workgroups per CU with L bytes of LDS each, polytopes handed out by a device-wide counter), the same store
+// instructions (buffer_store_dwordx2, scalar row offset + 8 * lane, 64 rows of one 512-byte piece after another, 7 pieces per
+// polytope, row length 7 * 64 doubles), no arithmetic.  Answers: is 1.2 ms (6.1 TB/s, store_pattern.hip: one wave per piece,
+// 229 376 waves) also what 2048 persistent waves reach, and how does it move with the number of waves per CU?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); std::exit(1); } } while (0)
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+
+// spin: busy VALU work per polytope between the store bursts (0: none), in units of 64 dependent FMAs
+// order 0: piece-major (all 64 rows of piece 0, then piece 1, ... - the row kernel's P5); 1: row-major (the nb pieces of row 0,
+// then row 1, ...: 3584 contiguous bytes at a time)
+// AUX: cache-policy bits of the store (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX>
+__global__ void __launch_bounds__(64, 2) k_rows_like(double *v, unsigned *sched, int n_poly, int nb, int spin, int order)
+{
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  int slot = blockIdx.x;
+  if (lane == 0)
+    lds[0] = 1.0;
+  double acc = lane;
+  for (;;)
+    {
+      int nslot_v = 0;
+      if (lane == 0)
+        nslot_v = (int)gridDim.x + (int)__hip_atomic_fetch_add(sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int rlen = nb * 64;
+      for (int s = 0; s < spin; ++s)
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+          acc = acc * 1.0000001 + 1e-9;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(v + (size_t)slot * 64 * rlen, 0, 64 * rlen * 8, 0x00020000);
+      if (order == 0)
+        for (int b = 0; b < nb; ++b)
+          {
+            unsigned off = 64u * 8u * (unsigned)b;
+#pragma unroll
+            for (int r = 0; r < 64; ++r)
+              {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, acc + r), rs, lane * 8, off, AUX);
+                off += (unsigned)rlen * 8u;
+              }
+          }
+      else
+        {
+          unsigned off = 0;
+          for (int r = 0; r < 64; ++r)
+#pragma unroll
+            for (int b = 0; b < 7; ++b)
+              {
+                if (b < nb)
+                  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, acc + r), rs, lane * 8, off, AUX);
+                off += 512u;
+              }
+        }
+      const int nslot = __builtin_amdgcn_readfirstlane(nslot_v);
+      if (nslot >= n_poly)
+        break;
+      slot = nslot;
+    }
+  if (lane == 0)
+    if (__hip_atomic_fetch_add(sched + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+      {
+        __hip_atomic_store(sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sched + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+}
+
+int main()
+{
+  const int NP = 32768, NB = 7;
+  const size_t n = (size_t)NP * 64 * NB * 64;
+  double *v;
+  unsigned *sched;
+  CHECK(hipMalloc(&v, (n + 64) * sizeof(double)));
+  CHECK(hipMalloc(&sched, 64));
+  CHECK(hipMemset(sched, 0, 64));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  auto run = [&](auto aux_, int order, int spin, int per_cu) {
+    constexpr int AUX = decltype(aux_)::value;
+    const size_t lds = per_cu <= 8 ? 20 * 1024 : (160 * 1024 / per_cu) / 1280 * 1280;
+    const int grid = 256 * per_cu;
+    auto launch = [&] { hipLaunchKernelGGL(k_rows_like<AUX>, dim3(grid), dim3(64), lds, 0, v, sched, NP, NB, spin, order); };
+    launch();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < 5; ++i)
+      launch();
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 5;
+    std::printf("aux %2d  %s  spin %2d (x64 dependent FMA per polytope)  %2d waves/CU (LDS %6zu B): %.3f ms  %.2f TB/s\n", AUX,
+                order ? "row-major  " : "piece-major", spin, per_cu, lds, ms, n * 8.0 / ms / 1e9);
+  };
+  for (int order : {0, 1})
+    for (int per_cu : {2, 4, 8, 16})
+      run(std::integral_constant<int, 0>{}, order, 16, per_cu);
+  for (int per_cu : {4, 8})
+    {
+      run(std::integral_constant<int, 1>{}, 0, 16, per_cu);
+      run(std::integral_constant<int, 2>{}, 0, 16, per_cu);
+      run(std::integral_constant<int, 3>{}, 0, 16, per_cu);
+      run(std::integral_constant<int, 16>{}, 0, 16, per_cu);
+      run(std::integral_constant<int, 17>{}, 0, 16, per_cu);
+      run(std::integral_constant<int, 18>{}, 0, 16, per_cu);
+    }
+  return 0;
+}

@@ -49,5 +49,16 @@ if basis == "dgq" and degree == 3:
 else:
     for k, nm in ((7, "P4 (streamed kinds): stage 1"), (14, "P4 (streamed kinds): stage 2"), (15, "P4 (streamed kinds): stage 3")):
         print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
-span = out[:, 6].max() - out[:, 0].min()
-print("first start -> last end: %d ticks" % span)
+# Balance between the persistent waves: wave g works through slots g, g + G, g + 2 G, ... (G = grid size); the stamps of one
+# wave come from one counter, so its own span (first start -> last end) is meaningful, absolute times of different waves are not
+G = int(os.environ.get("PDH_ROWS_GRID", "0")) or min(n, 8 * 256)
+per_wave = []
+for g in range(min(G, n)):
+    sl = np.arange(g, n, G)
+    per_wave.append((out[sl[-1], 6] - out[sl[0], 0], len(sl), float(tot[sl].sum())))
+pw = np.array(per_wave, dtype=np.float64)
+print("per wave (%d waves, %d-%d polytopes each): span min %.0f  mean %.0f  median %.0f  p95 %.0f  max %.0f ticks; busy (sum of polytope lifetimes) / span: mean %.3f"
+      % (len(pw), pw[:, 1].min(), pw[:, 1].max(), pw[:, 0].min(), pw[:, 0].mean(), np.median(pw[:, 0]), np.percentile(pw[:, 0], 95), pw[:, 0].max(),
+         float((pw[:, 2] / pw[:, 0]).mean())))
+by_xcd = [pw[x::8, 0].mean() for x in range(8)]
+print("mean span by blockIdx %% 8 (XCD under round-robin placement): " + " ".join("%.0f" % v for v in by_xcd))
