@@ -480,8 +480,10 @@ def main():
                          "(roofline.overlapped_ms_per_step); off by default so that a rocprofv3 trace of the default command "
                          "contains serialised launches only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-strong-proxy", dest="strong_proxy", action="store_false",
-                    help="N = 1: skip extra.strong_proxy (rank 0's share of 2-, 4-, 8-rank strong-scaling splits timed on this device)")
+    ap.add_argument("--strong-proxy", action="store_true",
+                    help="N = 1: add extra.strong_proxy (rank 0's share of 2-, 4-, 8-rank strong-scaling splits timed on this device); off "
+                         "by default: it launches the headline kernel on smaller row ranges, which would blur that kernel's average in a "
+                         "rocprofv3 --stats summary of the default command")
     ap.add_argument("--no-aux-kernels", dest="aux_kernels", action="store_false",
                     help="skip the timing of the right-hand-side and evaluation kernels (extra.aux_kernels)")
     ap.add_argument("--no-exchange-extra", dest="exchange_extra", action="store_false",
@@ -557,6 +559,10 @@ def main():
                 "n_dofs": r3["n_dofs"], "nnz": r3["nnz"], "algorithm": r3["alg"], "ms_per_step": 1e3 * t3, "value": r3["n_dofs"] / t3,
                 "kernel_ms": r3["kms"], "algorithmic_bytes_per_step": by3, "hbm_GBs": by3 / t3 * 1e-9,
                 "frac_of_hbm_peak": by3 / t3 * 1e-9 / HBM_PEAK_GBS, "setup_s": r3["t_setup"], "checksum": r3["checksum"]}
+            if r3["alg"] == "rows":  # what the same problem costs through the two-kernel moment form (round 2's path for such meshes)
+                r4 = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, 3, 1, alg="moment", grown=True)
+                extra["irregular_agglomerates"]["moment_form_ms_per_step"] = 1e3 * r4["dt"] / 3
+                extra["irregular_agglomerates"]["moment_form_kernel_ms"] = r4["kms"]
         except Exception as exc:
             extra["irregular_agglomerates"] = {"error": repr(exc)}
     if world == 1 and args.strong_proxy and not args.no_extra:

@@ -17,7 +17,8 @@ lib_path = os.path.abspath(sys.argv[1])
 cells = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 basis = sys.argv[3] if len(sys.argv) > 3 else "dgq"
 degree = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-grid, ah, fe = bench.build_handler(pa, 3, cells, 2, basis, degree, degree + 1)
+grown = len(sys.argv) > 5 and sys.argv[5] == "grown"  # irregular agglomerates (MULTI instantiation of the kernel)
+grid, ah, fe = bench.build_handler(pa, 3, cells, 2, basis, degree, degree + 1, grown=grown)
 flat = ah.flatten(pa.SipVariant.poisson_example(fe), True, False)
 ctx = pa.Context(0, lib_path=lib_path)
 ctx.set_problem(flat)
