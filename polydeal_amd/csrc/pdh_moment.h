@@ -1058,6 +1058,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
         const int O = di + 4 * dj + 16 * dblk; // this lane's column
         T1Off t1o;
         t1o.init(a0, a1);
+        // zero pads of the K = 8 fragments (row 7 / column 7 of every [a0][a1] plane): T1B is cleared once, stage 1 then writes
+        // its 49 values only - nothing else touches T1B inside the slab loop of this kernel (see pdh_rows.h, P4)
+        PDH_WAVE_SYNC();
+        for (int k = 0; k < 16; ++k)
+          T1B[k * 64 + lane] = 0.0;
 #pragma unroll 1
         for (int k2 = 0; k2 < PDHM_SLABS; ++k2)
           {
@@ -1075,10 +1080,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
                   n0 += e * accN[0][a];
                   n1 += e * accN[1][a];
                 });
-                t1b_store<0, ll>(T1B, t1o, g1);
-                t1b_store<1, ll>(T1B, t1o, ee);
-                t1b_store<2, ll>(T1B, t1o, n0);
-                t1b_store<3, ll>(T1B, t1o, n1);
+                T1B[(0 * 256 + (ll >> 1) * 128) + t1o.val[ll & 1]] = g1;
+                T1B[(1 * 256 + (ll >> 1) * 128) + t1o.val[ll & 1]] = ee;
+                T1B[(2 * 256 + (ll >> 1) * 128) + t1o.val[ll & 1]] = n0;
+                T1B[(3 * 256 + (ll >> 1) * 128) + t1o.val[ll & 1]] = n1;
               });
             // the A operands (24 doubles) are re-read per slab instead of living through stage 1 (register pressure);
             // the opaque zero keeps the compiler from hoisting the loads out of the loop again

@@ -1022,6 +1022,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double *tabQ = W;               // [2][PAIRS][RS]
   double *Tst = W + 2 * M::LTAB;  // [16 pairs (k_j,l_j)][8]
   double *Sbuf = Tst + 128;       // [16 u][16 v]
+  double *Sdst = Sbuf, *Cdst = Cbuf; // where build_S leaves S and C (MULTI keeps the planes of a neighbour side by side)
   auto build_S = [&](int t) { // t = local face index
     const int fl = t - n_bdry;
     const int c = rl_i(t_axis, t);
@@ -1112,7 +1113,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         for (int a = 0; a < NA; ++a)
           s += ei[a] * Tst[pairJ * 8 + a];
         if constexpr (!SMALL)
-          Sbuf[(ki + 4 * kj) * 16 + li + 4 * lj] = s;
+          Sdst[(ki + 4 * kj) * 16 + li + 4 * lj] = s;
         else
           { // compact S over the face's moment slot (read for the last time in the T stage)
             const bool okk = ki < N1D && kj < N1D && (BASIS == 0 || ki + kj < N1D);
@@ -1141,14 +1142,14 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         const double sg = rl_d(t_nsign, t), sig = rl_d(t_sigma, t);
         const double cv = (0.5 * sg * dk * ih_c - sig * vk) * vl - 0.5 * sg * vk * dl * ihq_c;
         if constexpr (!SMALL)
-          Cbuf[lane] = cv;
+          Cdst[lane] = cv;
         else
           Call[fl * 16 + lane] = cv;
       }
     PDH_WAVE_SYNC();
   };
   // last column (63: l = (3,3,3)) of the block just built, row R = lane
-  auto last_column = [&](int c) { return Cbuf[digit_c(lane, c) * 4 + 3] * Sbuf[digits_t(lane, c) * 16 + 15]; };
+  auto last_column = [&](int c) { return Cdst[digit_c(lane, c) * 4 + 3] * Sdst[digits_t(lane, c) * 16 + 15]; };
 
   // ================= P3: carry into the own block's piece ==========================================================
   constexpr bool shifted = SHIFTED;
@@ -1840,38 +1841,25 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           first_left = false;
         // this lane's column of the block: shifted pieces hold columns -1 .. 62 (lane 0: the carry)
         const int jcol = left ? (lane > 0 ? lane - 1 : 0) : lane;
-        // carries of all rows in ONE register (lane R = row R), see the single-plane kernel below
-        const double cvec = first_piece ? diagv[lane] : carry;
-        const int cvec_lo = __double2loint(cvec), cvec_hi = __double2hiint(cvec);
         const uint32_t rowp = 64u * 8u * (uint32_t)b; // uniform: byte offset of the piece in row 0
         const uint32_t lane_off = (uint32_t)lane * 8u;
-        // one row out: lane 0 of a shifted piece takes the carry of the row; scalar row / piece offset + 32-bit lane offset
-        auto put_row = [&, lane_off](auto left_, auto R_, double v, uint32_t rp) {
-          constexpr bool LEFT = left_;
-          constexpr int R = R_;
-          if constexpr (LEFT)
-            {
-              int lo_ = __double2loint(v), hi_ = __double2hiint(v);
-              const int slo = __builtin_amdgcn_readlane(cvec_lo, R), shi = __builtin_amdgcn_readlane(cvec_hi, R);
-              asm("v_writelane_b32 %0, %1, 0" : "+v"(lo_) : "s"(slo));
-              asm("v_writelane_b32 %0, %1, 0" : "+v"(hi_) : "s"(shi));
-              v = __hiloint2double(hi_, lo_);
-            }
-#if PDHR_EXP == 5
-          if (P.n < 0)
-#endif
-            row_store(v, lane_off, rp);
-        };
+        // carries of the shifted pieces: in LDS, read by lane 0 alone (EXEC = 1) straight into the value registers, eight rows
+        // at a time - as in the single-plane kernel (coupling_blocks)
+        double *ctab = W + 1536; // [64]
+        if (left && !first_piece)
+          ctab[lane] = carry;
+        const double *csrc = first_piece ? diagv : ctab; // uniform
+        typedef __attribute__((address_space(3))) const char lds_cchar;
+        const unsigned caddr = (unsigned)(uintptr_t)(lds_cchar *)reinterpret_cast<const char *>(csrc);
         double next_carry = 0.0;
         using std::integral_constant;
         {
           // acc[r] = sum_e C_e[k_c(R), l_c(j)] S_e[u(R), v(j)], in two halves of 32 rows (64 accumulators do not fit the
-          // register file next to what lives across this phase).  S_e / C_e of a neighbour met along SEVERAL planes are
-          // rebuilt for the second half; a single plane's stay in LDS.  (A variant that multiplied and stored the rows of
-          // single-plane neighbours directly, like the block-shaped kernel does, faulted on the device in all its four
-          // instantiations - stores through a corrupted base - while this form is correct; the cause was not found in the
-          // generated code, see profiles/README.md, r03.)
-          const bool single = te == t + 1;
+          // register file next to what lives across this phase).  S_e / C_e of the first three planes of a neighbour stay in
+          // LDS side by side (W + 704 ..., behind the scratch of build_S) for the second half; further planes are rebuilt.
+          // (A variant that multiplied and stored the rows of single-plane neighbours directly, like the block-shaped
+          // kernel does, faulted on the device in all its four instantiations - stores through a corrupted base - while this
+          // form is correct; the cause was not found in the generated code, see profiles/README.md, r03.)
           uint32_t rowrun = rowp;
           static_for<0, 2>([&](auto half_) {
             constexpr int half = half_;
@@ -1879,7 +1867,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             static_for<0, 32>([&](auto r_) { acc[r_] = 0.0; });
             for (int e = t; e < te; ++e)
               {
-                if (!(single && half == 1))
+                const int kslot = e - t;
+                Sdst = kslot < 3 ? W + 704 + 272 * kslot : Sbuf;
+                Cdst = kslot < 3 ? W + 704 + 272 * kslot + 256 : Cbuf;
+                if (half == 0 || kslot >= 3)
                   {
                     PDH_WAVE_SYNC();
                     build_S(e);
@@ -1888,9 +1879,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
                 double Cl[4], sc[16];
                 for (int k = 0; k < 4; ++k)
-                  Cl[k] = Cbuf[k * 4 + lc];
+                  Cl[k] = Cdst[k * 4 + lc];
                 for (int u = 0; u < 16; ++u)
-                  sc[u] = Sbuf[u * 16 + vt];
+                  sc[u] = Sdst[u * 16 + vt];
                 if (half == 0 && left)
                   next_carry += last_column(c);
                 auto add = [&](auto c_) {
@@ -1910,10 +1901,35 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 else
                   add(integral_constant<int, 2>{});
               }
+            if (half == 0 && left)
+              PDH_WAVE_SYNC(); // (ctab written above is read below)
             auto out = [&](auto left_) {
-              static_for<0, 32>([&](auto r_) {
-                put_row(left_, integral_constant<int, 32 * half + r_>{}, acc[r_], rowrun);
-                rowrun += (uint32_t)rlen * 8u;
+              constexpr bool LEFT = left_;
+              static_for<0, 4>([&](auto g_) {
+                constexpr int g = 4 * half + g_;
+                if constexpr (LEFT)
+                  asm volatile("s_mov_b64 exec, 1\n\t"
+                               "ds_read_b64 %0, %8 offset:%9\n\t"
+                               "ds_read_b64 %1, %8 offset:%10\n\t"
+                               "ds_read_b64 %2, %8 offset:%11\n\t"
+                               "ds_read_b64 %3, %8 offset:%12\n\t"
+                               "ds_read_b64 %4, %8 offset:%13\n\t"
+                               "ds_read_b64 %5, %8 offset:%14\n\t"
+                               "ds_read_b64 %6, %8 offset:%15\n\t"
+                               "ds_read_b64 %7, %8 offset:%16\n\t"
+                               "s_mov_b64 exec, -1\n\t"
+                               "s_waitcnt lgkmcnt(0)"
+                               : "+v"(acc[8 * g_ + 0]), "+v"(acc[8 * g_ + 1]), "+v"(acc[8 * g_ + 2]), "+v"(acc[8 * g_ + 3]),
+                                 "+v"(acc[8 * g_ + 4]), "+v"(acc[8 * g_ + 5]), "+v"(acc[8 * g_ + 6]), "+v"(acc[8 * g_ + 7])
+                               : "v"(caddr), "n"(64 * g + 0), "n"(64 * g + 8), "n"(64 * g + 16), "n"(64 * g + 24), "n"(64 * g + 32),
+                                 "n"(64 * g + 40), "n"(64 * g + 48), "n"(64 * g + 56));
+                static_for<0, 8>([&](auto r_) {
+#if PDHR_EXP == 5
+                  if (P.n < 0)
+#endif
+                    row_store(acc[8 * g_ + r_], lane_off, rowrun);
+                  rowrun += (uint32_t)rlen * 8u;
+                });
               });
             };
             if (left)
@@ -1921,6 +1937,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             else
               out(std::false_type{});
           });
+          Sdst = Sbuf, Cdst = Cbuf;
         }
         PDH_WAVE_SYNC();
         carry = next_carry;
