@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   // (sched[1] counts leavers) puts both words back to zero for the next launch - launches of one context are stream-ordered.
   auto leave = [&]() {
     // (every wave has made its last request to sched[0] before it counts itself out: the last one out may reset both)
+    if constexpr (!RowsKind<N1D, BASIS>::SMALL)
     if (threadIdx.x == 0)
       if (__hip_atomic_fetch_add(Rw.sched + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
         {
@@ -302,9 +303,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
 #pragma unroll 1
   for (;;)
   {
-  int nslot_v = 0;
-  if (lane_outer == 0)
-    nslot_v = (int)gridDim.x + (int)__hip_atomic_fetch_add(Rw.sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (streamed kinds: static stride - their polytopes are short, 45 .. 80 requests per microsecond would sit at the ~88 per
+  // microsecond one counter word sustains: measured 0.41 -> 0.52 ms for FE_AggloDGP(2) with the counter)
+  constexpr bool DYNAMIC = !SMALL;
+  int nslot_v = slot + (int)gridDim.x;
+  if constexpr (DYNAMIC)
+    if (lane_outer == 0)
+      nslot_v = (int)gridDim.x + (int)__hip_atomic_fetch_add(Rw.sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // Everything derived from the lane number below is loop-invariant; hoisted out of this loop it would sit in ~60 VGPRs for
   // the whole kernel (the compiler did exactly that: 256 VGPRs + spills).  An opaque copy ties it to the iteration.
   int lane = lane_outer;
@@ -331,7 +336,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     // cache policy sc1 | nt: the values are written once and not read again by this kernel; written through (the line is not kept in
     // the XCD's L2) the same stores run 5 % faster in the store-only twin of this kernel (tools/probes/rows_store_probe.hip:
     // 1.37 -> 1.30 ms at 8 waves per CU)
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v), vrs, (int)lane_bytes, (int)row_bytes, PDHR_STORE_AUX);
+    // (the streamed kinds keep the default policy: their rows are not multiples of 128 bytes, neighbouring pieces share lines, and
+    // written through the halves of a shared line no longer merge in L2 - FE_DGQ(2) 0.74 -> 0.79 ms with sc1)
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v), vrs, (int)lane_bytes, (int)row_bytes, SMALL ? 0 : PDHR_STORE_AUX);
   };
   // the face table of the polytope lives in the lanes (lane t = face t); a face's entries are read with v_readlane
   const long long pb_ = __double_as_longlong(cur.e[0]);
@@ -1718,7 +1725,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   // the next polytope's record is requested here: the store phase is long enough to hide the loads (~7k cycles), and
   // before it the 24 registers of the record would sit through the phases with the highest register pressure
   Meta nxt = cur;
-  const int nslot = __builtin_amdgcn_readfirstlane(nslot_v); // (requested at the top of this polytope)
+  const int nslot = DYNAMIC ? __builtin_amdgcn_readfirstlane(nslot_v) : nslot_v; // (requested at the top of this polytope)
   if (nslot < n_owned)
     nxt = load_meta(nslot);
   if constexpr (SMALL)
