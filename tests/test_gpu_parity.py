@@ -1416,3 +1416,53 @@ def test_t3_mesh_parity_with_the_oracle(n_refine, n_sub, basis, p, vname):
         orp, oci, ref = po.assemble_csr(oah, ovar, diag_first=diag_first)
         assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
         assert_parity(vals, ref, orp, oci, fe.n_dofs_per_cell)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_kernel_staircase_rank_local_descriptions(world):
+    """Irregular (grown) agglomerates of Cartesian cells from the PRODUCT mirror, partitioned into `world` row ranges, every rank
+    with its own rank-local description (pdh_problem.local = 1: own polytopes + ghost neighbours): the MULTI row kernel must
+    reproduce the rows of the global assembly (faces cut by the partition are seen from the owned side only), and the global
+    assembly the oracle's."""
+    import polydeal_amd as pa
+    from polydeal_amd.partition import row_range
+
+    grid = pa.BackgroundGrid.subdivided_hyper_cube(3, 6, 0.0, 1.0)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_grown_agglomerates(6, seed=7)
+    fe = pa.FE_DGQ(3, 3)
+    ah.initialize_fe_values(4, 4)
+    ah.distribute_agglomerated_dofs(fe)
+    var = pa.SipVariant.poisson_example(fe)
+    n, nA, N = fe.n_dofs_per_cell, ah.n_agglomerates, ah.n_dofs
+    gflat = ah.flatten(var, True, True)
+    ctx = pa.Context(0)
+    ctx.set_problem(gflat)
+    assert ctx.algorithm_in_use() == "rows"
+    gvals = ctx.assemble()
+    ctx.close()
+    # oracle on the same agglomerates
+    og = po.subdivided_hyper_cube(3, 6, 0.0, 1.0)
+    oah = po.AgglomerationHandler(og)
+    for P in range(nA):
+        cells = ah.get_agglomerate(P)
+        oah.define_agglomerate([cells[-1]] + cells[:-1])
+    ofe = po.FE_DGQ(3, 3)
+    oah.initialize_fe_values(4, 4)
+    oah.distribute_agglomerated_dofs(ofe)
+    orp, oci, ref = po.assemble_csr(oah, po.variant_poisson_example(ofe))
+    ga = gflat.arrays()
+    assert np.array_equal(ga["rowptr"], orp) and np.array_equal(ga["colind"], oci)
+    assert_parity(gvals, ref, orp, oci, n)
+    splits = [row_range(nA, n, r, world)[0] for r in range(world)] + [N]
+    for r in range(world):
+        r0, r1 = splits[r], splits[r + 1]
+        loc = ah.flatten_local(var, r0, r1, True, False, row_splits=splits)
+        ctx = pa.Context(0)
+        ctx.set_problem(loc, r0, r1)
+        assert ctx.algorithm_in_use() == "rows"
+        v = ctx.assemble()
+        ctx.close()
+        want = gvals[orp[r0]:orp[r1]]
+        assert v.shape == want.shape
+        assert np.max(np.abs(v - want)) <= 1e-13 * np.max(np.abs(gvals))
