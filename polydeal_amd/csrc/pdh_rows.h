@@ -60,6 +60,9 @@
 // 1: the blocks RIGHT of the diagonal (aligned pieces, no carries) are written before the diagonal block, the blocks left of it
 // after: the row stores of a polytope come in three bursts (192 | 64 | 192 for a block-shaped polytope) instead of one of
 // 448 at the end - the kernel is bound by how well its stores overlap with the arithmetic of the other waves of the CU
+#ifndef PDHR_TOUCH
+#define PDHR_TOUCH 1 // 0: no early touch of the face-point data (A/B)
+#endif
 #ifndef PDHR_SPLIT
 #define PDHR_SPLIT 1
 #endif
@@ -359,6 +362,86 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         ma.init(lane);
         ma.init_addr(W, lane);
       }
+
+  // ---- lane tasks of the face phase (P2, tensor sub-face rules): (face entry, sub-face, direction), up to 64 at a time.
+  // The point data of the FIRST batch is touched here, before the volume phase (loads whose result nobody reads: they bring
+  // the lines into this XCD's L2): behind this kernel's own store traffic a load that misses takes thousands of cycles (the
+  // lane-task part of P2 was 18 k cycles with the stores and 7 k without), and P1 has work to put in front of that.  Keeping
+  // the loaded values themselves across P1 costs ~50 VGPRs and spills (measured: 416 B of scratch per lane), and a load
+  // into a register nobody waits for lands in whatever the allocator has put there since - so these are loads to LDS
+  // (global_load_lds_dword: no destination register), into 256 bytes nobody reads between the end of the previous
+  // polytope's P5 and the first wait of this polytope's P1 for its own (later) loads - loads return in order, so that wait
+  // covers them, and the compiler's counts, which ignore them, only make it stricter: the first half of diagv (written next
+  // in P4).  Measured (A/B in one process): FE_DGQ(3) 1.570 -> 1.527 ms.  The streamed kinds do without: the same touches
+  // (into W[512 ...)) made them 2-5 % SLOWER (FE_AggloDGP(3) 0.927 -> 0.946, FE_DGQ(2) 0.738 -> 0.750, FE_AggloDGP(2)
+  // 0.402 -> 0.424 ms) - their phases are short, the task map computed twice costs more than the head start brings.
+  if (PDHR_TOUCH && !SMALL && Rw.fq_tensor_n > 0 && nfaces > 0)
+    {
+      // (the same task map as P2 below, recomputed there: nothing of this block stays live across P1)
+      const int fn = Rw.fq_tensor_n, nf2 = fn * fn;
+      const int my_nsub = lane < nfaces ? t_pcnt / nf2 : 0;
+      typedef __attribute__((address_space(3))) const char lds_cchar;
+      const unsigned dump = (unsigned)(uintptr_t)(lds_cchar *)reinterpret_cast<const char *>(diagv); // [64] dwords
+      auto touch = [&](const double *p) {
+        // (M0 = LDS byte address of the dump, each lane's dword goes to M0 + 4 lane; M0 is saved and restored - the compiler
+        // does not track it across an asm - and SALU-writes-M0 -> LDS-DMA needs one wait state)
+        unsigned m0_saved;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dword %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(m0_saved)
+                     : "v"(p), "s"(dump)
+                     : "memory");
+      };
+      int te = 0, ntask = 0;
+      while (te < nfaces)
+        {
+          const int ns2 = 2 * rl_i(my_nsub, te);
+          if (ntask + ns2 > 64)
+            break;
+          ntask += ns2;
+          ++te;
+        }
+      int mt = -1, rel = 0;
+      {
+        int s0 = 0;
+        for (int t = 0; t < te; ++t)
+          {
+            const int ns2 = 2 * rl_i(my_nsub, t);
+            if (lane >= s0 && lane < s0 + ns2)
+              {
+                mt = t;
+                rel = lane - s0;
+              }
+            s0 += ns2;
+          }
+      }
+      const int src = mt >= 0 ? mt : 0;
+      const int c = __shfl(t_axis, src), flags = __shfl(t_flags, src), nbr = __shfl(t_nbr, src);
+      const int64_t pb = ((int64_t)__shfl(t_pbhi, src) << 32) | (uint32_t)__shfl(t_pblo, src);
+      if (mt >= 0)
+        {
+          const int sb = rel >> 1, dir = rel & 1;
+          const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
+          const int ax = dir ? tj : ti;
+          const bool is_fast = (dir == 1) == ((flags & 2) != 0);
+          const int64_t stp = is_fast ? 1 : fn;
+          const int64_t base = pb + (int64_t)sb * nf2;
+          // first and last point of the task in each array (they span at most fn*fn values: one or two lines)
+          const int64_t qa = PDHR_IDX(base, P.ap_stride, 4), qb = PDHR_IDX(base + (fn - 1) * stp, P.ap_stride, 5);
+          touch(P.ap_x + (int64_t)ax * P.ap_stride + qa);
+          touch(P.ap_x + (int64_t)ax * P.ap_stride + qb);
+          touch(P.ap_wself + qa);
+          touch(P.ap_wself + qb);
+          if (nbr >= 0)
+            {
+              touch(P.ap_wcross + qa);
+              touch(P.ap_wcross + qb);
+            }
+        }
+    }
 
   PDHR_MARK(1);
   // ================= P1: volume moments ========================================================================
