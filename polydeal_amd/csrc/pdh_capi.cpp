@@ -180,7 +180,7 @@ struct pdh_ctx
   double *d_mtab = nullptr;
   // row kernel (pdh_rows.h): available when every face of every owned polytope is an axis-aligned plane (FE_DGQ(3), 3-D)
   bool rows_ok = false;
-  bool rows_auto = true; // AUTO takes the row kernel (degree >= 2; for n = 4 / 8 the direct kernels are as fast or faster)
+  bool rows_auto = true; // AUTO takes the row kernel where it applies (degree 1 since 12 waves per CU are resident: 0.21 vs 0.24-0.30 ms)
   PdhRows rows;
   bool use_rows() const
   {
@@ -1674,7 +1674,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
           R.vq_tensor_n = vq_n;
           R.fq_tensor_n = RH.fq_tensor_n;
           ctx->rows_ok = ok;
-          ctx->rows_auto = p->degree >= 2;
+          ctx->rows_auto = true;
           lap("row kernel: volume rule check");
         }
     }

@@ -82,16 +82,30 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
     const bool multi = N == 4 && B == 0 && R->multi != 0;
     const size_t lds = (pdhr::lds_doubles_rows<N, B>() + (multi ? (R->maxf - pdhr::MAXF) * pdhr::RowsKind<N, B>::SS : 0)) * sizeof(double);
     // resident single-wave workgroups per CU: by LDS (160 KB, handed out in granules of 1280 bytes - measured: 26 624 bytes
-    // fit six times, 27 136 do not), at most 8 (two waves per SIMD at 256 VGPRs)
-    const size_t granules = (lds + 1279) / 1280 * 1280;
-    const int fit = (int)(160 * 1024 / granules) < 8 ? (int)(160 * 1024 / granules) : 8;
-    const int per_cu = per_cu_env > 0 ? per_cu_env : fit;
-    const int resident = cus * per_cu;
-    const unsigned grid = (unsigned)(count < resident ? count : resident);
+    // fit six times, 27 136 do not) and by the registers of the instantiation (the runtime's occupancy query: two waves per
+    // SIMD above 168 VGPRs, three up to 168)
+    const size_t granules = (lds + pad + 1279) / 1280 * 1280;
+    const int fit_lds = (int)(160 * 1024 / granules);
     // degree 3: the instantiation without general-point paths when the host verified tensor rules everywhere
     // (PdhRows::tensor_only, pdh_capi.cpp: rows_kind_applies)
     auto go = [&](auto general_, auto shifted_, auto multi_) {
       constexpr bool G = decltype(general_)::value, S = decltype(shifted_)::value, MU = decltype(multi_)::value;
+      static thread_local size_t occ_lds = ~(size_t)0; // (per instantiation and thread)
+      static thread_local int occ_fit = 8;
+      if (occ_lds != lds + pad)
+        {
+          int nb = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pdhr::k_rows<N, B, G, S, MU>, PDH_WAVE, lds + pad) != hipSuccess || nb < 1)
+            nb = 8;
+          occ_fit = nb, occ_lds = lds + pad;
+          if (getenv("PDH_ROWS_VERBOSE"))
+            fprintf(stderr, "k_rows<%d,%d,%d,%d,%d>: lds %zu bytes, resident waves per CU: %d by LDS, %d by the occupancy query\n", N, B, (int)G,
+                    (int)S, (int)MU, lds + pad, fit_lds, nb);
+        }
+      const int fit = fit_lds < occ_fit ? fit_lds : occ_fit;
+      const int per_cu = per_cu_env > 0 ? per_cu_env : fit;
+      const int resident = cus * per_cu;
+      const unsigned grid = (unsigned)(count < resident ? count : resident);
       hipLaunchKernelGGL((pdhr::k_rows<N, B, G, S, MU>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
     };
     using std::true_type;

@@ -60,9 +60,6 @@
 // 1: the blocks RIGHT of the diagonal (aligned pieces, no carries) are written before the diagonal block, the blocks left of it
 // after: the row stores of a polytope come in three bursts (192 | 64 | 192 for a block-shaped polytope) instead of one of
 // 448 at the end - the kernel is bound by how well its stores overlap with the arithmetic of the other waves of the CU
-#ifndef PDHR_TOUCH
-#define PDHR_TOUCH 1 // 0: no early touch of the face-point data (A/B)
-#endif
 #ifndef PDHR_SPLIT
 #define PDHR_SPLIT 1
 #endif
@@ -133,6 +130,14 @@ struct RowsKind
   static constexpr int NF = BASIS == 0 ? N1D * N1D * N1D : N1D * (N1D + 1) * (N1D + 2) / 6; // functions
   static constexpr int NS = BASIS == 0 ? N1D * N1D : N1D * (N1D + 1) / 2;                   // pairs of tangential digits
   static constexpr int SS = SMALL ? ((NS * NS > 64 ? NS * NS : 64) + 7) / 8 * 8 : 64; // per-face slot: 8x8 moments, later S
+  // task vectors of P2 (tensor sub-face rules): [64 tasks][self | cross], 8 + 8 doubles per task - packed to NA + NA (odd
+  // stride) where that buys a resident wave: W, and with it the LDS of a wave, is sized by them for degree <= 2, and the
+  // streamed kinds run at the speed their occupancy allows (FE_DGQ(2): 1.14 / 0.99 / 0.86 / 0.78 ms at 4 / 5 / 6 / 7 waves
+  // per CU).  FE_DGQ(2): 21 336 -> 19 288 bytes = 8 waves per CU instead of 7 (0.76 -> 0.70 ms); degree 1: 13 480 -> 11 432
+  // bytes = the 12 waves per CU their 156 VGPRs allow (0.27 -> 0.21 ms).  FE_AggloDGP(2,3) stay at 8 / 6 waves either way
+  // (registers / the stage buffers of P4) and are 1-2 % slower with the odd stride: not packed.
+  static constexpr bool PACKED = SMALL && (N1D == 2 || (N1D == 3 && BASIS == 0));
+  static constexpr int MVC = PACKED ? NA : 8, MVS = PACKED ? 2 * NA + 1 : 16;
   static constexpr int NC = N1D * NS;                                                  // stage-2 work items per a0 (upper bound)
   static constexpr int T1 = 4 * N1D * NA * NA, T2 = 3 * NC * NA;                       // stage buffers of the diagonal block
   // index of the digit pair (ka, kb) among the pairs that occur
@@ -169,7 +174,9 @@ constexpr int w_doubles_rows()
     {
       // task vectors of P2 [64][16]; S / C scratch (two tables + T); stage buffers of the diagonal block
       constexpr int w_s = 2 * M::LTAB + 128, w_d = (K::T1 + K::T2 + 63) / 64 * 64;
-      constexpr int w0 = w_s > 1024 ? w_s : 1024;
+      // (P1: [16 cells][3][8]; S / C of all faces in lock-step: T_f at W + 128 f)
+      constexpr int w_t = 64 * K::MVS > 128 * MAXF ? 64 * K::MVS : 128 * MAXF;
+      constexpr int w0 = w_s > w_t ? w_s : w_t;
       return w0 > w_d ? w0 : w_d;
     }
 }
@@ -362,86 +369,6 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         ma.init(lane);
         ma.init_addr(W, lane);
       }
-
-  // ---- lane tasks of the face phase (P2, tensor sub-face rules): (face entry, sub-face, direction), up to 64 at a time.
-  // The point data of the FIRST batch is touched here, before the volume phase (loads whose result nobody reads: they bring
-  // the lines into this XCD's L2): behind this kernel's own store traffic a load that misses takes thousands of cycles (the
-  // lane-task part of P2 was 18 k cycles with the stores and 7 k without), and P1 has work to put in front of that.  Keeping
-  // the loaded values themselves across P1 costs ~50 VGPRs and spills (measured: 416 B of scratch per lane), and a load
-  // into a register nobody waits for lands in whatever the allocator has put there since - so these are loads to LDS
-  // (global_load_lds_dword: no destination register), into 256 bytes nobody reads between the end of the previous
-  // polytope's P5 and the first wait of this polytope's P1 for its own (later) loads - loads return in order, so that wait
-  // covers them, and the compiler's counts, which ignore them, only make it stricter: the first half of diagv (written next
-  // in P4).  Measured (A/B in one process): FE_DGQ(3) 1.570 -> 1.527 ms.  The streamed kinds do without: the same touches
-  // (into W[512 ...)) made them 2-5 % SLOWER (FE_AggloDGP(3) 0.927 -> 0.946, FE_DGQ(2) 0.738 -> 0.750, FE_AggloDGP(2)
-  // 0.402 -> 0.424 ms) - their phases are short, the task map computed twice costs more than the head start brings.
-  if (PDHR_TOUCH && !SMALL && Rw.fq_tensor_n > 0 && nfaces > 0)
-    {
-      // (the same task map as P2 below, recomputed there: nothing of this block stays live across P1)
-      const int fn = Rw.fq_tensor_n, nf2 = fn * fn;
-      const int my_nsub = lane < nfaces ? t_pcnt / nf2 : 0;
-      typedef __attribute__((address_space(3))) const char lds_cchar;
-      const unsigned dump = (unsigned)(uintptr_t)(lds_cchar *)reinterpret_cast<const char *>(diagv); // [64] dwords
-      auto touch = [&](const double *p) {
-        // (M0 = LDS byte address of the dump, each lane's dword goes to M0 + 4 lane; M0 is saved and restored - the compiler
-        // does not track it across an asm - and SALU-writes-M0 -> LDS-DMA needs one wait state)
-        unsigned m0_saved;
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %2\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dword %1, off\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(m0_saved)
-                     : "v"(p), "s"(dump)
-                     : "memory");
-      };
-      int te = 0, ntask = 0;
-      while (te < nfaces)
-        {
-          const int ns2 = 2 * rl_i(my_nsub, te);
-          if (ntask + ns2 > 64)
-            break;
-          ntask += ns2;
-          ++te;
-        }
-      int mt = -1, rel = 0;
-      {
-        int s0 = 0;
-        for (int t = 0; t < te; ++t)
-          {
-            const int ns2 = 2 * rl_i(my_nsub, t);
-            if (lane >= s0 && lane < s0 + ns2)
-              {
-                mt = t;
-                rel = lane - s0;
-              }
-            s0 += ns2;
-          }
-      }
-      const int src = mt >= 0 ? mt : 0;
-      const int c = __shfl(t_axis, src), flags = __shfl(t_flags, src), nbr = __shfl(t_nbr, src);
-      const int64_t pb = ((int64_t)__shfl(t_pbhi, src) << 32) | (uint32_t)__shfl(t_pblo, src);
-      if (mt >= 0)
-        {
-          const int sb = rel >> 1, dir = rel & 1;
-          const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
-          const int ax = dir ? tj : ti;
-          const bool is_fast = (dir == 1) == ((flags & 2) != 0);
-          const int64_t stp = is_fast ? 1 : fn;
-          const int64_t base = pb + (int64_t)sb * nf2;
-          // first and last point of the task in each array (they span at most fn*fn values: one or two lines)
-          const int64_t qa = PDHR_IDX(base, P.ap_stride, 4), qb = PDHR_IDX(base + (fn - 1) * stp, P.ap_stride, 5);
-          touch(P.ap_x + (int64_t)ax * P.ap_stride + qa);
-          touch(P.ap_x + (int64_t)ax * P.ap_stride + qb);
-          touch(P.ap_wself + qa);
-          touch(P.ap_wself + qb);
-          if (nbr >= 0)
-            {
-              touch(P.ap_wcross + qa);
-              touch(P.ap_wcross + qb);
-            }
-        }
-    }
 
   PDHR_MARK(1);
   // ================= P1: volume moments ========================================================================
@@ -795,8 +722,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   });
                   for (int a = 0; a < NA; ++a)
                     {
-                      mv[lane * 16 + a] = ms[a];
-                      mv[lane * 16 + 8 + a] = mc[a];
+                      mv[lane * RK::MVS + a] = ms[a];
+                      mv[lane * RK::MVS + RK::MVC + a] = mc[a];
                     }
                 }
               PDHR_ACC(tt_task);
@@ -820,8 +747,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                     double G = 0.0, Gc = 0.0;
                     for (int sb = 0; sb < ns; ++sb)
                       {
-                        G += mv[(s0 + 2 * sb) * 16 + a0] * mv[(s0 + 2 * sb + 1) * 16 + a1];
-                        Gc += mv[(s0 + 2 * sb) * 16 + 8 + a0] * mv[(s0 + 2 * sb + 1) * 16 + 8 + a1];
+                        G += mv[(s0 + 2 * sb) * RK::MVS + a0] * mv[(s0 + 2 * sb + 1) * RK::MVS + a1];
+                        Gc += mv[(s0 + 2 * sb) * RK::MVS + RK::MVC + a0] * mv[(s0 + 2 * sb + 1) * RK::MVS + RK::MVC + a1];
                       }
                     s0 += 2 * ns;
                     if (act)
@@ -846,12 +773,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 const double zeta = (rl_d(t_coord, t) - sel3(c, lo0, lo1, lo2)) * sel3(c, ih0, ih1, ih2);
                 double Lc[NA];
                 pdhm::legendre01<NA>(zeta, Lc);
-                const double *mvt = mv + s0 * 16;
+                const double *mvt = mv + s0 * RK::MVS;
                 if (c == 2)
                   {
                     double G = 0.0;
                     for (int sb = 0; sb < ns; ++sb)
-                      G += mvt[(2 * sb) * 16 + a0] * mvt[(2 * sb + 1) * 16 + a1];
+                      G += mvt[(2 * sb) * RK::MVS + a0] * mvt[(2 * sb + 1) * RK::MVS + a1];
                     const double gS = kS * G, gN = kN * G;
                     for (int a = 0; a < NA; ++a)
                       {
@@ -872,9 +799,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                       g[a] = 0.0;
                     for (int sb = 0; sb < ns; ++sb)
                       {
-                        const double mi = mvt[(2 * sb) * 16 + arow];
+                        const double mi = mvt[(2 * sb) * RK::MVS + arow];
                         for (int a = 0; a < NA; ++a)
-                          g[a] += mi * mvt[(2 * sb + 1) * 16 + a];
+                          g[a] += mi * mvt[(2 * sb + 1) * RK::MVS + a];
                       }
                     const double fS = lc_ * kS, fN = lc_ * kN;
                     for (int a = 0; a < NA; ++a)
@@ -891,7 +818,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   {
                     double Gc = 0.0;
                     for (int sb = 0; sb < ns; ++sb)
-                      Gc += mvt[(2 * sb) * 16 + 8 + a0] * mvt[(2 * sb + 1) * 16 + 8 + a1];
+                      Gc += mvt[(2 * sb) * RK::MVS + RK::MVC + a0] * mvt[(2 * sb + 1) * RK::MVS + RK::MVC + a1];
                     if (act)
                       M2c[fl * MS + a0 * 8 + a1] = Gc;
                   }

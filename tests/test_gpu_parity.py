@@ -669,11 +669,11 @@ def test_moment_form_parity(fe_cls, p, lg, b, dist, varname, diag_first):
     assert_parity_ah(vm, ref, ah, diag_first, what="moment")
     assert_parity_ah(vd, ref, ah, diag_first, what="direct")
     assert np.max(np.abs(vm - vd)) <= 1e-13 * sc
-    # AUTO: undistorted (every face an axis-aligned plane, tensor rules) -> row kernel from degree 2 on; else the moment
+    # AUTO: undistorted (every face an axis-aligned plane, tensor rules) -> row kernel; else the moment
     # form for both kinds of block at FE_DGQ(3), for the diagonal blocks only at FE_DGQ(2), else direct
     va, used_a = _values(kw, "auto")
     expect = "direct"
-    if dist == 0.0 and p >= 2:
+    if dist == 0.0:
         expect = "rows"
     elif fe_cls is po.FE_DGQ and p == 3:
         expect = "moment"
