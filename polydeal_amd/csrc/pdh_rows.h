@@ -138,7 +138,11 @@ struct RowsKind
   // (registers / the stage buffers of P4) and are 1-2 % slower with the odd stride: not packed.
   static constexpr bool PACKED = SMALL && (N1D == 2 || (N1D == 3 && BASIS == 0));
   static constexpr int MVC = PACKED ? NA : 8, MVS = PACKED ? 2 * NA + 1 : 16;
-  static constexpr int NC = N1D * NS;                                                  // stage-2 work items per a0 (upper bound)
+  // Stages 2 / 3 of the diagonal block run in passes over K1P values of k1 (all of them, except for FE_AggloDGP(3): there the
+  // stage buffers size the LDS of a wave, and T2 for two values of k1 at a time makes 23 032 instead of 26 616 bytes = 7
+  // resident waves per CU instead of 6 - these kinds run at the speed their occupancy allows, see MVS below)
+  static constexpr int K1P = (N1D == 4 && BASIS == 1) ? 2 : N1D;
+  static constexpr int NC = K1P * NS;                                                  // stage-2 work items per a0 and pass (upper bound)
   static constexpr int T1 = 4 * N1D * NA * NA, T2 = 3 * NC * NA;                       // stage buffers of the diagonal block
   // index of the digit pair (ka, kb) among the pairs that occur
   __host__ __device__ static constexpr int pair(int ka, int kb) { return BASIS == 0 ? ka + N1D * kb : kb * N1D - kb * (kb - 1) / 2 + ka; }
@@ -1448,7 +1452,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       constexpr int NA2 = NA * NA, NC = RK::NC;
       // stage-2 work items of this lane, one per round of 64: item q = (k1, pair (l1,l2), a0) does not depend on the slab -
       // decoded once (offsets of its T1 rows, its table row and its T2 entry)
-      constexpr int S2R = (N1D * NS * NA + 63) / 64;
+      // (item q = (k1 - first k1 of the pass, pair (l1,l2), a0): the table row of the pass adds k1b N1D RS)
+      constexpr int K1P = RK::K1P;
+      constexpr int S2R = (K1P * NS * NA + 63) / 64;
       int s2_r0[S2R], s2_tp[S2R], s2_out[S2R];
       static_for<0, S2R>([&](auto rr_) {
         constexpr int rr = rr_;
@@ -1464,7 +1470,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
             for (int w_ = N1D; l1 >= w_ && w_ > 0; --w_)
               l1 -= w_, ++l2;
           }
-        const bool ok = k1 < N1D && l1 < N1D && l2 < N1D;
+        const bool ok = k1 < K1P && l1 < N1D && l2 < N1D;
         s2_tp[rr] = ok ? (k1 * N1D + l1) * M::RS : 0;
         s2_r0[rr] = ok ? l2 * NA2 + a0_ * NA : 0;
         s2_out[rr] = ok ? cc * NA + a0_ : 0;
@@ -1507,59 +1513,70 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           PDH_WAVE_SYNC();
           PDHR_ACC(tp1);
           const int nk1 = BASIS == 0 ? N1D : N1D - k2; // values of k1 (and, below, rows (k0, k1)) of this slab
-          const long long t1_ = (long long)__builtin_readcyclecounter();
-          static_for<0, S2R>([&](auto rr_) {
-            constexpr int rr = rr_;
-            if (lane + 64 * rr < nk1 * NS * NA)
+#pragma unroll 1
+          for (int k1b = 0; k1b < nk1; k1b += K1P)
             {
-              const int tp = s2_tp[rr], cc_a = s2_out[rr];
-              const double *r0 = T1 + s2_r0[rr], *r1 = r0 + N1D * NA2, *r2 = r0 + 2 * N1D * NA2, *r3 = r0 + 3 * N1D * NA2;
-              double sD = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, sF = 0.0;
-              static_for<0, NA>([&](auto a_) {
-                constexpr int a = a_;
-                const double e = tabE[tp + a], d = tabD[tp + a], f = tabF[tp + a], g = r0[a];
-                sD += e * g;
-                s1 += d * g;
-                s2 += e * r1[a];
-                s3 += f * r3[a];
-                sF += e * r2[a];
-              });
-              T2[0 * NC * NA + cc_a] = s00 * sD;
-              T2[1 * NC * NA + cc_a] = s11 * s1 + s2 + ih1 * s3;
-              T2[2 * NC * NA + cc_a] = ih0 * sF;
-            }
-          });
-          PDH_WAVE_SYNC();
-          const long long t2_ = (long long)__builtin_readcyclecounter();
-#ifdef PDHR_STAMP
-          tp2 += t2_ - t1_;
-#endif
-          const int nrow = BASIS == 0 ? N1D * N1D : nk1 * (nk1 + 1) / 2;
-          for (int q = lane; q < nrow * NF; q += 64)
-            {
-              const int rr = q / NF, j = q - NF * rr;
-              int k1, k0;
-              if constexpr (BASIS == 0)
-                k1 = rr / N1D, k0 = rr - N1D * k1;
-              else
+              const int npk = nk1 - k1b < K1P ? nk1 - k1b : K1P; // values of k1 in this pass
+              if (k1b > 0)
+                PDH_WAVE_SYNC(); // (stage 3 of the pass before has read T2)
+              const long long t1_ = (long long)__builtin_readcyclecounter();
+              const int tpb = k1b * N1D * M::RS;
+              static_for<0, S2R>([&](auto rr_) {
+                constexpr int rr = rr_;
+                if (lane + 64 * rr < npk * NS * NA)
                 {
-                  k1 = 0, k0 = rr;
-                  for (int w_ = nk1; k0 >= w_; --w_)
-                    k0 -= w_, ++k1;
+                  const int tp = s2_tp[rr] + tpb, cc_a = s2_out[rr];
+                  const double *r0 = T1 + s2_r0[rr], *r1 = r0 + N1D * NA2, *r2 = r0 + 2 * N1D * NA2, *r3 = r0 + 3 * N1D * NA2;
+                  double sD = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, sF = 0.0;
+                  static_for<0, NA>([&](auto a_) {
+                    constexpr int a = a_;
+                    const double e = tabE[tp + a], d = tabD[tp + a], f = tabF[tp + a], g = r0[a];
+                    sD += e * g;
+                    s1 += d * g;
+                    s2 += e * r1[a];
+                    s3 += f * r3[a];
+                    sF += e * r2[a];
+                  });
+                  T2[0 * NC * NA + cc_a] = s00 * sD;
+                  T2[1 * NC * NA + cc_a] = s11 * s1 + s2 + ih1 * s3;
+                  T2[2 * NC * NA + cc_a] = ih0 * sF;
                 }
-              const int dj_ = dig[j]; // axis 0: l0 | pair(l1, l2) << 4
-              const int tp = (k0 * N1D + (dj_ & 15)) * M::RS;
-              const double *t2 = T2 + (k1 * NS + (dj_ >> 4)) * NA;
-              double sv = 0.0;
-              static_for<0, NA>([&](auto a_) {
-                constexpr int a = a_;
-                sv += tabD[tp + a] * t2[a] + tabE[tp + a] * t2[NC * NA + a] + tabF[tp + a] * t2[2 * NC * NA + a];
               });
-              Dblk[RK::findex(k0, k1, k2) * NF + j] = sv;
-            }
+              PDH_WAVE_SYNC();
+              const long long t2_ = (long long)__builtin_readcyclecounter();
 #ifdef PDHR_STAMP
-          tp3 += (long long)__builtin_readcyclecounter() - t2_;
+              tp2 += t2_ - t1_;
 #endif
+              // rows (k0, k1) of the slab with k1 in [k1b, k1b + npk): k1 outer, k0 inner (k0 < nk1 - k1 for the P_p basis)
+              const int rb = BASIS == 0 ? k1b * N1D : k1b * nk1 - k1b * (k1b - 1) / 2;
+              const int k1e = k1b + npk;
+              const int re = BASIS == 0 ? k1e * N1D : k1e * nk1 - k1e * (k1e - 1) / 2;
+              for (int q = lane + rb * NF; q < re * NF; q += 64)
+                {
+                  const int rr = q / NF, j = q - NF * rr;
+                  int k1, k0;
+                  if constexpr (BASIS == 0)
+                    k1 = rr / N1D, k0 = rr - N1D * k1;
+                  else
+                    {
+                      k1 = 0, k0 = rr;
+                      for (int w_ = nk1; k0 >= w_; --w_)
+                        k0 -= w_, ++k1;
+                    }
+                  const int dj_ = dig[j]; // axis 0: l0 | pair(l1, l2) << 4
+                  const int tp = (k0 * N1D + (dj_ & 15)) * M::RS;
+                  const double *t2 = T2 + ((k1 - k1b) * NS + (dj_ >> 4)) * NA;
+                  double sv = 0.0;
+                  static_for<0, NA>([&](auto a_) {
+                    constexpr int a = a_;
+                    sv += tabD[tp + a] * t2[a] + tabE[tp + a] * t2[NC * NA + a] + tabF[tp + a] * t2[2 * NC * NA + a];
+                  });
+                  Dblk[RK::findex(k0, k1, k2) * NF + j] = sv;
+                }
+#ifdef PDHR_STAMP
+              tp3 += (long long)__builtin_readcyclecounter() - t2_;
+#endif
+            }
         }
 #ifdef PDHR_STAMP
       if (lane == 0 && Rw.stamps)
