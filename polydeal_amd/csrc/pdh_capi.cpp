@@ -1214,19 +1214,54 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
       int nf = 0;
       for (size_t t : idx)
         for (const Plane &pl : planes[t])
+          {
+            // A run that lies in several planes (the boundary run of a corner polytope; a staircase face towards one neighbour)
+            // gives one entry per plane, and the kernel skips the sub-faces (groups of a tensor rule, else single points) whose
+            // first point is not in the entry's plane.  The entry covers only the span from the first to the last group of ITS
+            // plane - a run of s groups in k planes costs the sum of the spans, not k s, in lane tasks and moment sums - and is
+            // flagged for masking only if a foreign group lies inside that span.
+            const int64_t gsz = R.fq_tensor_n > 0 ? (int64_t)R.fq_tensor_n * R.fq_tensor_n : 1;
+            int64_t sp_b = 0, sp_e = K.run_cnt[t];
+            bool foreign_inside = false;
+            if (planes[t].size() > 1)
+              {
+                const int a = K.own_agg[K.run_slot[t]];
+                const double h = p->bbox[(size_t)a * 6 + 3 + pl.axis] - p->bbox[(size_t)a * 6 + pl.axis];
+                auto mine = [&](int64_t q) {
+                  return K.ap_n(pl.axis, t, q) * pl.sign > 0.5 && std::fabs(K.ap_x(pl.axis, t, q) - pl.coord) <= 1e-9 * h;
+                };
+                int64_t g_first = -1, g_last = -1;
+                const int64_t ng = K.run_cnt[t] / gsz;
+                for (int64_t g = 0; g < ng; ++g)
+                  if (mine(g * gsz))
+                    {
+                      if (g_first < 0)
+                        g_first = g;
+                      g_last = g;
+                    }
+                // (a plane seen only on points that are not the first of their group would be a group straddling planes: not a
+                // tensor rule on a rectangle, such runs fail face_rules_are_tensor; with gsz = 1 every point is its own group.
+                // Should it happen all the same: the whole run, masked, as before)
+                if (g_first < 0)
+                  g_first = 0, g_last = ng - 1;
+                for (int64_t g = g_first; g <= g_last; ++g)
+                  foreign_inside = foreign_inside || !mine(g * gsz);
+                sp_b = g_first * gsz, sp_e = (g_last + 1) * gsz;
+                if (sp_e > K.run_cnt[t] || K.run_cnt[t] % gsz) // (a run that is not whole groups: keep all of it)
+                  sp_b = 0, sp_e = K.run_cnt[t], foreign_inside = true;
+              }
           // A boundary run with tensor sub-face rules is cut into pieces of at most 32 sub-faces: the kernel forms the moments
           // of a piece in one batch of 64 lane tasks (2 per sub-face), and a corner polytope of 4^3 cells already has 48
           // boundary sub-faces in its run.  Boundary pieces only add to the diagonal block's face tensors, so the cut
           // changes nothing but the order of summation.  (An interior face is one entry: its coupling moments are one set.)
-          for (int64_t pc0 = 0, pcs = (K.run_nbr[t] < 0 && R.fq_tensor_n > 0) ? 32 * (int64_t)R.fq_tensor_n * R.fq_tensor_n : K.run_cnt[t];
-               pc0 < K.run_cnt[t]; pc0 += pcs)
+          for (int64_t pc0 = sp_b, pcs = (K.run_nbr[t] < 0 && R.fq_tensor_n > 0) ? 32 * gsz : sp_e - sp_b; pc0 < sp_e; pc0 += pcs)
           {
             R.fr_pbeg.push_back(K.run_ap[t] + pc0);
-            R.fr_pcnt.push_back((int32_t)std::min<int64_t>(pcs, K.run_cnt[t] - pc0));
+            R.fr_pcnt.push_back((int32_t)std::min<int64_t>(pcs, sp_e - pc0));
             R.fr_nbr.push_back(K.run_nbr[t]);
             R.fr_axis.push_back(pl.axis);
             R.fr_blk.push_back(K.run_blk[t]);
-            R.fr_flags.push_back((planes[t].size() > 1 ? 1 : 0) | ((R.fq_tensor_n > 0 && fast_j[3 * t + pl.axis] == 1) ? 2 : 0));
+            R.fr_flags.push_back((foreign_inside ? 1 : 0) | ((R.fq_tensor_n > 0 && fast_j[3 * t + pl.axis] == 1) ? 2 : 0));
             R.fr_coord.push_back(pl.coord);
             R.fr_sigma.push_back(K.run_sig[t]);
             R.fr_nsign.push_back(pl.sign);
@@ -1237,6 +1272,7 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
                   R.multi = true;
               }
           }
+          }
       const int ne = (int)R.fr_pbeg.size() - R.fr_ptr.back();
       R.maxf = std::max(R.maxf, nf);
       R.maxe = std::max(R.maxe, ne);
@@ -1244,6 +1280,16 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
     }
   if (r != nruns)
     return no("run bookkeeping");
+  if (getenv("PDH_ROWS_VERBOSE"))
+    {
+      int64_t covered = 0, points = 0, masked = 0;
+      for (size_t f = 0; f < R.fr_pcnt.size(); ++f)
+        covered += R.fr_pcnt[f], masked += (R.fr_flags[f] & 1) ? 1 : 0;
+      for (size_t t = 0; t < nruns; ++t)
+        points += K.run_cnt[t];
+      fprintf(stderr, "row kernel tables: %zu runs, %zu plane entries (%lld masked), %lld face points, %lld covered by the entries (%.2fx)\n",
+              nruns, R.fr_pcnt.size(), (long long)masked, (long long)points, (long long)covered, (double)covered / (double)points);
+    }
   if (R.maxf > maxf || R.maxe > 16)
     R.multi = true;
   if (R.multi)
@@ -1663,6 +1709,26 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
             else
               R.stamps = nullptr;
           }
+          R.m2c_scratch = nullptr;
+          R.scratch_waves = 0;
+          if (RH.multi)
+            {
+              // MULTI instantiation: the coupling moments of a polytope's interior entries (8 x 8 doubles each, up to 40 of
+              // them) are parked between P2 and P5 in a per-wave row of this buffer instead of LDS (pdh_rows.h) - 8 waves per
+              // CU at most (256 VGPRs), a few tens of MB that stay in L2 / the memory-side cache
+              int cus = 256;
+              (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+              const int waves = cus * 8;
+              void *dm = nullptr;
+              if (hipMalloc(&dm, (size_t)waves * (size_t)RH.maxf * 64 * sizeof(double)) != hipSuccess)
+                {
+                  free_problem(ctx);
+                  return fail(ctx, PDH_EDEVICE, "row kernel: out of device memory");
+                }
+              ctx->allocs.push_back(dm);
+              R.m2c_scratch = static_cast<double *>(dm);
+              R.scratch_waves = waves;
+            }
           lap("row kernel: upload");
           int vq_n = 0;
           bool tensor_only = false;

@@ -80,7 +80,9 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
     // MULTI instantiation (FE_DGQ(3), PdhRows::multi): the coupling-moment slots (one per interior plane entry) are sized for
     // the resident problem
     const bool multi = N == 4 && B == 0 && R->multi != 0;
-    const size_t lds = (pdhr::lds_doubles_rows<N, B>() + (multi ? (R->maxf - pdhr::MAXF) * pdhr::RowsKind<N, B>::SS : 0)) * sizeof(double);
+    // (MULTI: the coupling moments of the interior entries are parked in PdhRows::m2c_scratch, not in LDS - the layout of the
+    // block-shaped kernel, whose six slots serve as staging there)
+    const size_t lds = pdhr::lds_doubles_rows<N, B>() * sizeof(double);
     // resident single-wave workgroups per CU: by LDS (160 KB, handed out in granules of 1280 bytes - measured: 26 624 bytes
     // fit six times, 27 136 do not) and by the registers of the instantiation (the runtime's occupancy query: two waves per
     // SIMD above 168 VGPRs, three up to 168)
@@ -104,7 +106,9 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
         }
       const int fit = fit_lds < occ_fit ? fit_lds : occ_fit;
       const int per_cu = per_cu_env > 0 ? per_cu_env : fit;
-      const int resident = cus * per_cu;
+      int resident = cus * per_cu;
+      if (MU && resident > R->scratch_waves)
+        resident = R->scratch_waves; // (one row of the moment scratch per workgroup)
       const unsigned grid = (unsigned)(count < resident ? count : resident);
       hipLaunchKernelGGL((pdhr::k_rows<N, B, G, S, MU>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
     };

@@ -239,8 +239,16 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double *Cbuf = diagv + (!SMALL ? 64 : 0); // [4][4]  (the streamed kinds have no diagv)
   double *coefL = Cbuf + 16;        // [4][4] monomial coefficients of the 1-D basis (centred variable)
   double *W = coefL + 16;           // phase-local
-  // [maxf][8][8] coupling moments of every interior entry: in front of diagv, or (MULTI) behind everything else
+  // [maxf][8][8] coupling moments of every interior entry: in front of diagv.  MULTI (up to 40 interior entries): parked in
+  // global memory between P2 and P5 - one row of PdhRows::m2c_scratch per workgroup, 512 bytes per entry, written once and
+  // read once or twice per polytope by the same wave (it stays in L2) - and staged through ONE slot behind W when S of an
+  // entry is built.  In LDS they cost 512 bytes per entry of the polytope with the MOST entries: 36 KB per wave on the bench
+  // mesh of grown agglomerates = 4 resident waves per CU, one per SIMD, and this kernel lives on the latency the other wave
+  // of a SIMD hides.
   double *M2c = MULTI ? W + w_doubles_rows<N1D, BASIS>() : lds + 3 * M::LTAB;
+  double *M2g = nullptr;
+  if constexpr (MULTI)
+    M2g = Rw.m2c_scratch + (size_t)blockIdx.x * (size_t)Rw.maxf * 64;
   const int maxf = MULTI ? Rw.maxf : MAXF, maxe = MULTI ? Rw.maxe : ROWS_MAXE;
   // streamed kinds only: behind W
   double *Call = W + w_doubles_rows<N1D, BASIS>(); // [MAXF][4][4] C of every interior face
@@ -765,7 +773,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                     expand(fp, M2);
                     const int fl = t - n_bdry;
                     if (fp.nbr >= 0 && fl >= 0 && fl < maxf)
-                      M2c[fl * MS + lane] = M2[2 * 64 + lane];
+                      {
+                        if constexpr (MULTI)
+                          M2g[fl * 64 + lane] = M2[2 * 64 + lane];
+                        else
+                          M2c[fl * MS + lane] = M2[2 * 64 + lane];
+                      }
                     PDH_WAVE_SYNC();
                   }
               }
@@ -1007,7 +1020,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   expand(fp, M2);
                 const int fl = t - n_bdry;
                 if (fp.nbr >= 0 && (pass == 1 || !fp.sep) && fl >= 0 && fl < maxf)
-                  M2c[fl * MS + lane] = M2[2 * 64 + lane];
+                  {
+                    if constexpr (MULTI)
+                      M2g[fl * 64 + lane] = M2[2 * 64 + lane];
+                    else
+                      M2c[fl * MS + lane] = M2[2 * 64 + lane];
+                  }
                 PDH_WAVE_SYNC();
                 PDHR_ACC(tm_flush);
               }
@@ -1044,8 +1062,28 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double *Tst = W + 2 * M::LTAB;  // [16 pairs (k_j,l_j)][8]
   double *Sbuf = Tst + 128;       // [16 u][16 v]
   double *Sdst = Sbuf, *Cdst = Cbuf; // where build_S leaves S and C (MULTI keeps the planes of a neighbour side by side)
+  // MULTI: this lane's value of an entry's coupling moments from the scratch row - entries are taken in ascending order nearly
+  // always, so the value of the NEXT entry is requested whenever one is handed out (a load behind this kernel's own stores
+  // takes thousands of cycles; one double per lane is what the head start costs)
+  double m2_ahead = 0.0;
+  int m2_ahead_fl = -1;
+  auto moments_of = [&](int fl) { // (uniform)
+    double v = m2_ahead;
+    if (fl != m2_ahead_fl)
+      v = M2g[fl * 64 + lane];
+    const int nx = fl + 1;
+    m2_ahead_fl = -1;
+    if (nx < nfaces - n_bdry && nx < maxf)
+      {
+        m2_ahead = M2g[nx * 64 + lane];
+        m2_ahead_fl = nx;
+      }
+    return v;
+  };
   auto build_S = [&](int t) { // t = local face index
     const int fl = t - n_bdry;
+    if constexpr (MULTI)
+      M2c[lane] = moments_of(fl); // staging slot (read in the T stage below, behind the first hand-off)
     const int c = rl_i(t_axis, t);
     const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
     const double q0 = rl_d(t_qlo0, t), q1 = rl_d(t_qlo1, t), q2 = rl_d(t_qlo2, t);
@@ -1103,7 +1141,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       const int pair = lane & 15;
       const int kj_ = pair >> 2, lj_ = pair & 3;
       const int pairT = (kj_ < N1D && lj_ < N1D) ? kj_ * N1D + lj_ : 0;
-      const double *m2 = M2c + fl * MS;
+      const double *m2 = MULTI ? M2c : M2c + fl * MS;
       double ej[NA];
       for (int b = 0; b < NA; ++b)
         ej[b] = EQj[pairT * M::RS + b];
@@ -1411,6 +1449,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   if constexpr (!SMALL && !MULTI && PDHR_SPLIT && SHIFTED)
     coupling_blocks(std::false_type{});
 
+  m2_ahead_fl = -1; // (MULTI: a value requested ahead by P3 is not carried through the diagonal block)
   PDHR_MARK(4);
   // ================= P4: diagonal block ============================================================================
   PDH_WAVE_SYNC();

@@ -22,7 +22,9 @@ struct PdhRows
   // METIS-like agglomerates of Cartesian cells), more than 6 interior plane entries or more than 16 entries in all
   int32_t multi;           // 1: take the MULTI instantiation
   int32_t maxe;            // face entries a record provides for (16 unless multi): record = 12 + 12 maxe doubles
-  int32_t maxf;            // interior entries (coupling-moment slots in LDS) a polytope may have (6 unless multi)
+  int32_t maxf;            // interior entries (coupling-moment slots) a polytope may have (6 unless multi)
+  double *m2c_scratch;     // multi: [resident waves][maxf][64] coupling moments of a wave's current polytope (pdh_rows.h);
+  int32_t scratch_waves;   // resident waves the scratch provides for (the launcher starts no more workgroups than that)
   unsigned int *sched;     // [2] work counter of the persistent waves and count of the waves that have left (both zero
                            // between launches: the last wave out resets them)
   long long *stamps;       // [n_owned][16] s_memtime at the phase boundaries; written by -DPDHR_STAMP builds only

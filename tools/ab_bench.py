@@ -27,9 +27,10 @@ def main():
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--block", type=int, default=2)
+    ap.add_argument("--grown", action="store_true", help="irregular agglomerates grown over the cell graph (MULTI row kernel)")
     ap.add_argument("--alg", default="auto", help="auto | direct | moment | rows (pdh_set_algorithm) for both builds")
     a = ap.parse_args()
-    grid, ah, fe = bench.build_handler(pa, a.dim, a.cells, a.block, a.fe, a.degree, a.degree + 1)
+    grid, ah, fe = bench.build_handler(pa, a.dim, a.cells, a.block, a.fe, a.degree, a.degree + 1, grown=a.grown)
     flat = ah.flatten(pa.SipVariant.poisson_example(fe), True, False)
     # (several contexts per build, created alternately: the same code runs up to 3 % apart in two contexts of one process -
     # where the allocator puts the 7 GB of values matters - so one context per build cannot resolve differences of that size)
