@@ -1064,7 +1064,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double *Sdst = Sbuf, *Cdst = Cbuf; // where build_S leaves S and C (MULTI keeps the planes of a neighbour side by side)
   // MULTI: this lane's value of an entry's coupling moments from the scratch row - entries are taken in ascending order nearly
   // always, so the value of the NEXT entry is requested whenever one is handed out (a load behind this kernel's own stores
-  // takes thousands of cycles; one double per lane is what the head start costs)
+  // takes thousands of cycles; one double per lane is what the head start costs.  Two entries ahead: no faster, A/B 3.01 vs
+  // 3.05 ms - S and C of an entry cost ~6k cycles of arithmetic and hand-offs, not of waiting for this load)
   double m2_ahead = 0.0;
   int m2_ahead_fl = -1;
   auto moments_of = [&](int fl) { // (uniform)
@@ -1897,6 +1898,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     double carry = 0.0; // lane R: the value that lane 0 stores in row R of the next piece
     bool first_left = true;
     int t = n_bdry;
+#ifdef PDHR_STAMP
+    long long tb_S = 0, tb_out = 0;
+#endif
 #if PDHR_EXP == 1
     while (t < nfaces && P.n < 0)
 #else
@@ -1945,8 +1949,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 Cdst = kslot < 3 ? W + 704 + 272 * kslot + 256 : Cbuf;
                 if (half == 0 || kslot >= 3)
                   {
+                    PDHR_T0();
                     PDH_WAVE_SYNC();
                     build_S(e);
+                    PDHR_ACC(tb_S);
                   }
                 const int c = rl_i(t_axis, e);
                 const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
@@ -2005,10 +2011,14 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                 });
               });
             };
-            if (left)
-              out(std::true_type{});
-            else
-              out(std::false_type{});
+            {
+              PDHR_T0();
+              if (left)
+                out(std::true_type{});
+              else
+                out(std::false_type{});
+              PDHR_ACC(tb_out);
+            }
           });
           Sdst = Sbuf, Cdst = Cbuf;
         }
@@ -2016,6 +2026,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         carry = next_carry;
         t = te;
       }
+#ifdef PDHR_STAMP
+    if (lane == 0 && Rw.stamps)
+      {
+        Rw.stamps[(int64_t)slot * 16 + 8] = tb_S; // (MULTI: slots 8, 9 are free - the tensor path of P2 uses 12, 13)
+        Rw.stamps[(int64_t)slot * 16 + 9] = tb_out;
+      }
+#endif
   }
   else
   // ================= P5: coupling blocks left of the diagonal, in ascending column order ================================

@@ -41,6 +41,9 @@ tensor = out[:, 12].any() or out[:, 13].any()
 if tensor:  # P2 ran on verified tensor sub-face rules (slots 12, 13); slots 8 .. 11 belong to the general-point path
     for k, nm in ((12, "P2 (tensor rules): lane tasks"), (13, "P2 (tensor rules): per-face sums + expansion")):
         print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
+    if grown:  # MULTI instantiation: slots 8, 9 time the two parts of P5
+        for k, nm in ((8, "P5 (MULTI): S and C of the plane entries"), (9, "P5 (MULTI): carries + row stores")):
+            print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
 else:
     for k, nm in ((8, "P2: issue of the next chunk's loads"), (9, "P2: record phase"), (10, "P2: MFMA steps"), (11, "P2: flush + expansion")):
         print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
