@@ -211,6 +211,51 @@ def test_config4_diffusion_reaction_128cubed_dgq2_one_gpu():
     assert interior.sum() == (nb - 2) ** 3, interior.sum()
 
 
+def test_multi_row_kernel_beyond_the_resident_waves():
+    """MULTI row kernel (irregular agglomerates, staircase faces) on MORE polytopes than the device holds resident waves
+    (32^3 cells in 4096 grown agglomerates; 2048 waves on 256 CUs): every wave works through several polytopes and re-uses its
+    row of the coupling-moment scratch (PdhRows::m2c_scratch) - the small parity cases against the oracle give every wave
+    one polytope.  Checked against the moment form (no scratch, no persistent waves; itself parity-tested against the oracle
+    on the small cases) entry by entry, and through the size-independent identities  A 1 = 0 on interior rows,
+    1^T A 1 = sigma |dOmega| with the polytope-wise penalty the caller variant sets."""
+    grid = pa.BackgroundGrid.subdivided_hyper_cube(3, 32, 0.0, 1.0)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_grown_agglomerates(8, seed=3)
+    fe = pa.FE_DGQ(3, 3)
+    ah.initialize_fe_values(4, 4)
+    ah.distribute_agglomerated_dofs(fe)
+    assert ah.n_agglomerates > 2048 + 1024
+    var = pa.SipVariant.poisson_example(fe)
+    flat = ah.flatten(var, True, True)
+    out = {}
+    for alg in ("rows", "moment"):
+        ctx = pa.Context(0)
+        ctx.set_algorithm(alg)
+        ctx.set_problem(flat)
+        assert ctx.algorithm_in_use() == alg
+        ctx.poison_values()
+        ctx.assemble_device()
+        ctx.assemble_device()  # (a second pass over the same scratch rows)
+        out[alg] = ctx.assemble()
+        ctx.close()
+    assert np.all(np.isfinite(out["rows"]))
+    scale = float(np.max(np.abs(out["moment"])))
+    assert float(np.max(np.abs(out["rows"] - out["moment"]))) <= 1e-12 * scale
+    arr = flat.arrays()
+    A = sp.csr_matrix((out["rows"], arr["colind"].copy(), arr["rowptr"].copy()), shape=(ah.n_dofs, ah.n_dofs))
+    v1 = np.ones(ah.n_dofs)  # FE_DGQ: nodal basis, the constant has all coefficients one
+    y1 = A @ v1
+    n = fe.n_dofs_per_cell
+    for P in range(0, ah.n_agglomerates, 7):
+        l, h = ah.bbox(P)
+        if np.min(l) > 1e-12 and np.max(h) < 1 - 1e-12:
+            d0 = ah.dof_indices(P)[0]
+            assert np.max(np.abs(y1[d0:d0 + n])) <= 1e-12 * scale * n
+    sample = np.unique(np.linspace(0, ah.n_dofs - 1, 400).astype(np.int64))
+    S = A[sample][:, sample]
+    assert abs(S - S.T).max() <= 1e-12 * scale
+
+
 def test_bench_strong_scaling_rehearsal_on_one_gpu():
     """`bench.py --gpus 4 --scaling strong` (the default scaling, BASELINE.json north_star: strong scaling to 8 GPUs) rehearsed on
     this box's ONE GPU: four ranks (gloo, all on device 0 - the box admits at most six processes on the card, so the 8-rank
