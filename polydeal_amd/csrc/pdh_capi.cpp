@@ -1118,6 +1118,7 @@ struct RowsHost
   // entries / entries than the block-shaped kernel provides for (6 / 16)
   bool multi = false;
   int maxe = 16, maxf = 6;
+  int maxs = 0; // most sub-faces (groups of a tensor rule) of the interior entries of one polytope
 };
 static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R, std::string *why = nullptr)
 {
@@ -1274,6 +1275,14 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
           }
           }
       const int ne = (int)R.fr_pbeg.size() - R.fr_ptr.back();
+      if (R.fq_tensor_n > 0)
+        {
+          int64_t nsub = 0;
+          for (size_t f = (size_t)R.fr_ptr.back(); f < R.fr_pbeg.size(); ++f)
+            if (R.fr_nbr[f] >= 0)
+              nsub += R.fr_pcnt[f] / ((int64_t)R.fq_tensor_n * R.fq_tensor_n);
+          R.maxs = std::max<int>(R.maxs, (int)nsub);
+        }
       R.maxf = std::max(R.maxf, nf);
       R.maxe = std::max(R.maxe, ne);
       R.fr_ptr.push_back((int32_t)R.fr_pbeg.size());
@@ -1711,6 +1720,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
           }
           R.m2c_scratch = nullptr;
           R.scratch_waves = 0;
+          R.scratch_stride = 0;
           if (RH.multi)
             {
               // MULTI instantiation: the coupling moments of a polytope's interior entries (8 x 8 doubles each, up to 40 of
@@ -1720,7 +1730,10 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
               (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
               const int waves = cus * 8;
               void *dm = nullptr;
-              if (hipMalloc(&dm, (size_t)waves * (size_t)RH.maxf * 64 * sizeof(double)) != hipSuccess)
+              // (with tensor sub-face rules the row holds 16 + 16 factors per interior sub-face instead, pdh_rows.h: FACT)
+              const size_t stride = std::max<size_t>((size_t)RH.maxf * 64, (size_t)RH.maxs * 32 + 64);
+              R.scratch_stride = (int64_t)stride;
+              if (hipMalloc(&dm, (size_t)waves * stride * sizeof(double)) != hipSuccess)
                 {
                   free_problem(ctx);
                   return fail(ctx, PDH_EDEVICE, "row kernel: out of device memory");

@@ -225,6 +225,12 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   static_assert(!MULTI || (N1D == 4 && BASIS == 0), "several planes per neighbour: FE_DGQ(3) only");
   using RK = RowsKind<N1D, BASIS>;
   constexpr bool SMALL = RK::SMALL;
+  // MULTI with verified tensor rules: the coupling data of an interior entry are kept per SUB-FACE in factorised form - on an
+  // axis-aligned rectangle with a tensor rule  S_sub[(k_i,k_j),(l_i,l_j)] = X[k_i,l_i] Y[k_j,l_j],  X[k,l] = sum_alpha a_alpha
+  // B^P_k(x_alpha) B^Q_l(x_alpha) (16 + 16 numbers from 4 + 4 points, both bases evaluated in their own boxes) - instead of
+  // as 49 two-dimensional moments in a common frame that need direction tables and two contraction stages per entry (6 k
+  // cycles each, a third of this instantiation's time; its entries are small: 1.4 sub-faces on average)
+  constexpr bool FACT = MULTI && !GENERAL;
   constexpr int MS = RK::SS; // doubles per interior-face slot
   constexpr int NF = RK::NF, NS = RK::NS;
   using M = pdhm::MT<N1D>;
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
   double *M2c = MULTI ? W + w_doubles_rows<N1D, BASIS>() : lds + 3 * M::LTAB;
   double *M2g = nullptr;
   if constexpr (MULTI)
-    M2g = Rw.m2c_scratch + (size_t)blockIdx.x * (size_t)Rw.maxf * 64;
+    M2g = Rw.m2c_scratch + (size_t)blockIdx.x * (size_t)Rw.scratch_stride; // (FACT: [sub-face][X 16 | Y 16])
   const int maxf = MULTI ? Rw.maxf : MAXF, maxe = MULTI ? Rw.maxe : ROWS_MAXE;
   // streamed kinds only: behind W
   double *Call = W + w_doubles_rows<N1D, BASIS>(); // [MAXF][4][4] C of every interior face
@@ -499,6 +505,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
 
   PDHR_MARK(2);
   // ================= P2: faces ==================================================================================
+  int t_nsub = 0, t_soff = 0; // FACT: lane t = entry t: its sub-faces and how many the interior entries before it have
   double accS[NAP], accN[DIM][NAP];
   for (int a = 0; a < NAP; ++a)
     {
@@ -626,6 +633,16 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     const int my_nsub = (fn > 0 && lane < nfaces) ? t_pcnt / nf2 : 0;
     // (an entry with more than 32 sub-faces does not fit the 64 lane tasks of a batch: such polytopes take the MFMA path)
     const bool face_tensor = fn > 0 && __ballot(my_nsub > 32) == 0ull;
+    if constexpr (FACT)
+      {
+        t_nsub = my_nsub;
+        int run = 0;
+        for (int t = n_bdry; t < nfaces; ++t)
+          {
+            t_soff = lane == t ? run : t_soff;
+            run += rl_i(my_nsub, t);
+          }
+      }
     if (face_tensor)
       {
         // Verified tensor rules on the sub-faces (pdh_problem::fq_tensor_n): every group of fn^2 points is a rule
@@ -679,6 +696,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               const int64_t pb = ((int64_t)__shfl(t_pbhi, src) << 32) | (uint32_t)__shfl(t_pblo, src);
               const double q0 = __shfl(t_qlo0, src), q1 = __shfl(t_qlo1, src), q2 = __shfl(t_qlo2, src);
               const double i0 = __shfl(t_qih0, src), i1 = __shfl(t_qih1, src), i2 = __shfl(t_qih2, src);
+              const int soff_src = FACT ? __shfl(t_soff, src) : 0; // (cross-lane reads stay outside the divergent part)
               if (mt >= 0)
                 {
                   const int sb = rel >> 1, dir = rel & 1;
@@ -706,6 +724,10 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                   double ms[NA], mc[NA];
                   for (int a = 0; a < NA; ++a)
                     ms[a] = mc[a] = 0.0;
+                  double Fd[FACT ? 16 : 1]; // FACT: X (dir 0) or Y (dir 1) of this sub-face, [k][l]
+                  for (int i = 0; i < (FACT ? 16 : 1); ++i)
+                    Fd[i] = 0.0;
+                  const double loq_d = sel3(ax, q0, q1, q2), ihq_d = sel3(ax, i0, i1, i2);
                   // (all loads of the task first, like the volume tasks; fn <= 8)
                   double xr[8], wsr[8], wcr[8];
                   static_for<0, 8>([&](auto i_) {
@@ -726,17 +748,48 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                         pdhm::legendre01<NA>((x - lo_d) * ih_d, Lx);
                         for (int a = 0; a < NA; ++a)
                           ms[a] += wS * Lx[a];
-                        if (ihF_d != ih_d || loF_d != lo_d)
-                          pdhm::legendre01<NA>((x - loF_d) * ihF_d, Lx);
-                        for (int a = 0; a < NA; ++a)
-                          mc[a] += wC * Lx[a];
+                        if constexpr (FACT)
+                          {
+                            // both bases in the centred variable of their own box (pdh_basis.h: monomial coefficients,
+                            // uniform: scalar operands)
+                            const double zp = (x - lo_d) * ih_d - 0.5, zq = (x - loq_d) * ihq_d - 0.5;
+                            double bp[4], bq[4];
+                            for (int k = 0; k < 4; ++k)
+                              {
+                                double vp = P.tab.coef[k][3], vq = P.tab.coef[k][3];
+                                for (int m = 2; m >= 0; --m)
+                                  {
+                                    vp = vp * zp + P.tab.coef[k][m];
+                                    vq = vq * zq + P.tab.coef[k][m];
+                                  }
+                                bp[k] = wC * vp, bq[k] = vq;
+                              }
+                            for (int k = 0; k < 4; ++k)
+                              for (int l = 0; l < 4; ++l)
+                                Fd[k * 4 + l] += bp[k] * bq[l];
+                          }
+                        else
+                          {
+                            if (ihF_d != ih_d || loF_d != lo_d)
+                              pdhm::legendre01<NA>((x - loF_d) * ihF_d, Lx);
+                            for (int a = 0; a < NA; ++a)
+                              mc[a] += wC * Lx[a];
+                          }
                       }
                   });
                   for (int a = 0; a < NA; ++a)
                     {
                       mv[lane * RK::MVS + a] = ms[a];
-                      mv[lane * RK::MVS + RK::MVC + a] = mc[a];
+                      if constexpr (!FACT)
+                        mv[lane * RK::MVS + RK::MVC + a] = mc[a];
                     }
+                  if constexpr (FACT)
+                    if (nbr >= 0)
+                      {
+                        double *row = M2g + (size_t)(soff_src + sb) * 32 + dir * 16;
+                        for (int i = 0; i < 16; ++i)
+                          row[i] = Fd[i];
+                      }
                 }
               PDHR_ACC(tt_task);
             }
@@ -760,18 +813,21 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
                     for (int sb = 0; sb < ns; ++sb)
                       {
                         G += mv[(s0 + 2 * sb) * RK::MVS + a0] * mv[(s0 + 2 * sb + 1) * RK::MVS + a1];
-                        Gc += mv[(s0 + 2 * sb) * RK::MVS + RK::MVC + a0] * mv[(s0 + 2 * sb + 1) * RK::MVS + RK::MVC + a1];
+                        if constexpr (!FACT)
+                          Gc += mv[(s0 + 2 * sb) * RK::MVS + RK::MVC + a0] * mv[(s0 + 2 * sb + 1) * RK::MVS + RK::MVC + a1];
                       }
                     s0 += 2 * ns;
                     if (act)
                       {
                         M2[0 * 64 + a0 * 8 + a1] = fp.sig * G;
                         M2[1 * 64 + a0 * 8 + a1] = -0.5 * fp.nsg * G;
-                        M2[2 * 64 + a0 * 8 + a1] = Gc;
+                        if constexpr (!FACT)
+                          M2[2 * 64 + a0 * 8 + a1] = Gc;
                       }
                     PDH_WAVE_SYNC();
                     expand(fp, M2);
                     const int fl = t - n_bdry;
+                    if constexpr (!FACT)
                     if (fp.nbr >= 0 && fl >= 0 && fl < maxf)
                       {
                         if constexpr (MULTI)
@@ -1056,6 +1112,14 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       }
   }
 
+  if constexpr (FACT)
+    {
+      // The factors were written by the task lanes of P2 and are read by OTHER lanes of this wave from here on (P3 follows at
+      // once): global memory orders a work-item's own accesses only, so the wave releases its stores before it goes on
+      // (vmcnt(0): they have reached L2).  [The moment form parks a value in the lane that reads it back: no fence needed.]
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
   PDHR_MARK(3);
   // ---- S and C of one face into W (tables for the tangential directions, T, S) ----------------------------------------
   double *tabQ = W;               // [2][PAIRS][RS]
@@ -1081,14 +1145,62 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
       }
     return v;
   };
+  // FACT: the first 64 doubles (two sub-faces) of the NEXT entry's factors are requested when an entry is built
+  double fa_v = 0.0;
+  int fa_t = -1;
   auto build_S = [&](int t) { // t = local face index
     const int fl = t - n_bdry;
-    if constexpr (MULTI)
-      M2c[lane] = moments_of(fl); // staging slot (read in the T stage below, behind the first hand-off)
     const int c = rl_i(t_axis, t);
     const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
     const double q0 = rl_d(t_qlo0, t), q1 = rl_d(t_qlo1, t), q2 = rl_d(t_qlo2, t);
     const double i0 = rl_d(t_qih0, t), i1 = rl_d(t_qih1, t), i2 = rl_d(t_qih2, t);
+    if constexpr (FACT)
+      {
+        // S[(k_i,k_j),(l_i,l_j)] = sum over the entry's sub-faces of X[k_i,l_i] Y[k_j,l_j]: the factors (P2) are staged from the
+        // scratch row through W[0, 448) (14 sub-faces at a time), every lane forms its four entries of S
+        const int ns = rl_i(t_nsub, t), sf0 = rl_i(t_soff, t);
+        double v0 = fa_v;
+        if (t != fa_t)
+          v0 = M2g[(size_t)sf0 * 32 + lane];
+        fa_t = -1;
+        if (t + 1 < nfaces)
+          {
+            fa_v = M2g[(size_t)rl_i(t_soff, t + 1) * 32 + lane];
+            fa_t = t + 1;
+          }
+        double *F = W;
+        const int pairI = lane & 15, ki = pairI >> 2, li = pairI & 3;
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int sb0 = 0; sb0 < ns; sb0 += 14)
+          {
+            const int nsc = ns - sb0 < 14 ? ns - sb0 : 14;
+            if (sb0 > 0)
+              PDH_WAVE_SYNC(); // (the chunk before has been read)
+            if (lane < nsc * 32)
+              F[lane] = sb0 == 0 ? v0 : M2g[(size_t)(sf0 + sb0) * 32 + lane];
+            for (int r = lane + 64; r < nsc * 32; r += 64)
+              F[r] = M2g[(size_t)(sf0 + sb0) * 32 + r];
+            PDH_WAVE_SYNC();
+            for (int sb = 0; sb < nsc; ++sb)
+              {
+                const double x = F[sb * 32 + ki * 4 + li];
+                static_for<0, 4>([&](auto r_) {
+                  constexpr int r = r_;
+                  const int pairJ = (lane >> 4) + 4 * r, kj = pairJ >> 2, lj = pairJ & 3;
+                  sacc[r] += x * F[sb * 32 + 16 + kj * 4 + lj];
+                });
+              }
+          }
+        static_for<0, 4>([&](auto r_) {
+          constexpr int r = r_;
+          const int pairJ = (lane >> 4) + 4 * r, kj = pairJ >> 2, lj = pairJ & 3;
+          Sdst[(ki + 4 * kj) * 16 + li + 4 * lj] = sacc[r];
+        });
+      }
+    else
+    {
+    if constexpr (MULTI)
+      M2c[lane] = moments_of(fl); // staging slot (read in the T stage below, behind the first hand-off)
     bool same[2];
     {
       const int dd = (lane >> 4) & 1;
@@ -1183,6 +1295,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
           }
       });
     }
+    } // (moment form of S)
     if (lane < 16)
       {
         // C[k][l] = (1/2 s B'_k(zP)/hP - sigma B_k(zP)) B_l(zQ) - 1/2 s B_k(zP) B'_l(zQ)/hQ    (centred variable)
@@ -1451,6 +1564,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
     coupling_blocks(std::false_type{});
 
   m2_ahead_fl = -1; // (MULTI: a value requested ahead by P3 is not carried through the diagonal block)
+  fa_t = -1;
   PDHR_MARK(4);
   // ================= P4: diagonal block ============================================================================
   PDH_WAVE_SYNC();

@@ -25,6 +25,7 @@ struct PdhRows
   int32_t maxf;            // interior entries (coupling-moment slots) a polytope may have (6 unless multi)
   double *m2c_scratch;     // multi: [resident waves][maxf][64] coupling moments of a wave's current polytope (pdh_rows.h);
   int32_t scratch_waves;   // resident waves the scratch provides for (the launcher starts no more workgroups than that)
+  int64_t scratch_stride;  // doubles per resident wave: max(maxf 64, 32 x most interior sub-faces of a polytope + 64)
   unsigned int *sched;     // [2] work counter of the persistent waves and count of the waves that have left (both zero
                            // between launches: the last wave out resets them)
   long long *stamps;       // [n_owned][16] s_memtime at the phase boundaries; written by -DPDHR_STAMP builds only
