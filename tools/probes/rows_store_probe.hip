@@ -88,6 +88,52 @@ __global__ void __launch_bounds__(64, 2) k_rows_like(double *v, unsigned *sched,
       }
 }
 
+// SHARE waves of one workgroup write ONE polytope together (wave w the rows [64 w / SHARE, 64 (w + 1) / SHARE), piece after piece):
+// the same number of waves per CU, 1 / SHARE as many concurrent store streams (regions written at a time).
+template <int AUX, int SHARE>
+__global__ void __launch_bounds__(64 * SHARE) k_rows_shared(double *v, unsigned *sched, int n_poly, int nb, int spin)
+{
+  extern __shared__ double lds[];
+  __shared__ int next_slot;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int slot = blockIdx.x;
+  double acc = lane;
+  for (;;)
+    {
+      if (threadIdx.x == 0)
+        next_slot = (int)gridDim.x + (int)__hip_atomic_fetch_add(sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int rlen = nb * 64;
+      for (int s = 0; s < spin; ++s)
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+          acc = acc * 1.0000001 + 1e-9;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(v + (size_t)slot * 64 * rlen, 0, 64 * rlen * 8, 0x00020000);
+      constexpr int RW = 64 / SHARE;
+      for (int b = 0; b < nb; ++b)
+        {
+          unsigned off = 64u * 8u * (unsigned)b + (unsigned)(w * RW) * (unsigned)rlen * 8u;
+#pragma unroll
+          for (int r = 0; r < RW; ++r)
+            {
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, acc + r), rs, lane * 8, off, AUX);
+              off += (unsigned)rlen * 8u;
+            }
+        }
+      __syncthreads();
+      const int nslot = next_slot;
+      __syncthreads();
+      if (nslot >= n_poly)
+        break;
+      slot = nslot;
+    }
+  if (threadIdx.x == 0)
+    if (__hip_atomic_fetch_add(sched + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+      {
+        __hip_atomic_store(sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sched + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+}
+
 int main()
 {
   const int NP = 32768, NB = 7;
@@ -118,8 +164,35 @@ int main()
     std::printf("aux %2d  %s  spin %2d (x64 dependent FMA per polytope)  %2d waves/CU (LDS %6zu B): %.3f ms  %.2f TB/s\n", AUX,
                 order == 2 ? "piece-major, dwordx4 (2 rows)" : (order ? "row-major  " : "piece-major"), spin, per_cu, lds, ms, n * 8.0 / ms / 1e9);
   };
-  for (int order : {0, 2})
-    for (int per_cu : {2, 4, 8, 16})
+  auto run_shared = [&](auto share_, int spin, int waves_per_cu) {
+    constexpr int SHARE = decltype(share_)::value;
+    const int wg_per_cu = waves_per_cu / SHARE;
+    const size_t lds = (size_t)20 * 1024 * SHARE <= 64 * 1024 ? (size_t)20 * 1024 * SHARE : 64 * 1024 - 64; // (<= 64 KB per workgroup)
+    const int grid = 256 * wg_per_cu;
+    auto launch = [&] { hipLaunchKernelGGL((k_rows_shared<18, SHARE>), dim3(grid), dim3(64 * SHARE), lds, 0, v, sched, NP, NB, spin); };
+    launch();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < 5; ++i)
+      launch();
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 5;
+    std::printf("aux 18  %d waves share a polytope  spin %2d  %2d waves/CU = %d workgroups/CU = %d concurrent regions: %.3f ms  %.2f TB/s\n", SHARE,
+                spin, waves_per_cu, wg_per_cu, grid, ms, n * 8.0 / ms / 1e9);
+  };
+  for (int per_cu : {8, 16})
+    {
+      run_shared(std::integral_constant<int, 1>{}, 16, per_cu);
+      run_shared(std::integral_constant<int, 2>{}, 16, per_cu);
+      run_shared(std::integral_constant<int, 4>{}, 16, per_cu);
+      if (per_cu >= 8)
+        run_shared(std::integral_constant<int, 8>{}, 16, per_cu);
+    }
+  for (int order : {0})
+    for (int per_cu : {2, 8})
       {
         run(std::integral_constant<int, 0>{}, order, 16, per_cu);
         run(std::integral_constant<int, 18>{}, order, 16, per_cu);
