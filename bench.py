@@ -544,6 +544,22 @@ def main():
             extra.update(algorithmic_bytes_per_step=by2, hbm_GBs=by2 / (r2["dt"] / args.steps) * 1e-9,
                          frac_of_hbm_peak=by2 / (r2["dt"] / args.steps) * 1e-9 / HBM_PEAK_GBS,
                          fp64_bound_ms=1e3 * sum(r2["work"]["flops"]) / (FP64_PEAK_TFLOPS * 1e12))
+    if not args.no_extra and world == 1 and args.dim == 3 and args.degree == 3:
+        # the lower degrees of the same mesh (streamed kinds of the row kernel; degree 2 is the element of BASELINE configs[1] / [3])
+        import copy
+        extra["lower_degrees"] = []
+        for p_low in (2, 1):
+            try:
+                a2 = copy.copy(args)
+                a2.degree = p_low
+                r5 = run_gpu(pa, torch, dist, a2, args.fe, rank, world, local_rank, max(3, args.steps // 2), 1)
+                t5 = r5["dt"] / max(3, args.steps // 2)
+                by5 = r5["work"]["bytes_total"] if r5["alg"] == "rows" else sum(r5["work"]["bytes"])
+                extra["lower_degrees"].append({"fe": ("FE_DGQ" if args.fe == "dgq" else "FE_AggloDGP") + "(%d)" % p_low, "n_dofs": r5["n_dofs"],
+                                               "algorithm": r5["alg"], "ms_per_step": 1e3 * t5, "value": r5["n_dofs"] / t5,
+                                               "algorithmic_bytes_per_step": by5, "frac_of_hbm_peak": by5 / t5 * 1e-9 / HBM_PEAK_GBS})
+            except Exception as exc:  # a secondary measurement must not cost the main line
+                extra["lower_degrees"].append({"degree": p_low, "error": repr(exc)})
     if main_res.get("aux") is not None:
         extra["aux_kernels"] = main_res["aux"]
     if not args.no_extra and world == 1 and args.dim == 3:
