@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(64, 2) k_rows_like(double *v, unsigned *sched,
 
 // SHARE waves of one workgroup write ONE polytope together (wave w the rows [64 w / SHARE, 64 (w + 1) / SHARE), piece after piece):
 // the same number of waves per CU, 1 / SHARE as many concurrent store streams (regions written at a time).
-template <int AUX, int SHARE>
+// (APART = true: the control - the same workgroups and barriers, but every wave writes a polytope of its own, all 64 rows)
+template <int AUX, int SHARE, bool APART = false>
 __global__ void __launch_bounds__(64 * SHARE) k_rows_shared(double *v, unsigned *sched, int n_poly, int nb, int spin)
 {
   extern __shared__ double lds[];
@@ -107,11 +108,12 @@ __global__ void __launch_bounds__(64 * SHARE) k_rows_shared(double *v, unsigned 
 #pragma unroll
         for (int k = 0; k < 64; ++k)
           acc = acc * 1.0000001 + 1e-9;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(v + (size_t)slot * 64 * rlen, 0, 64 * rlen * 8, 0x00020000);
-      constexpr int RW = 64 / SHARE;
+      // (APART: slot counts groups of SHARE polytopes)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(v + (size_t)(APART ? slot * SHARE + w : slot) * 64 * rlen, 0, 64 * rlen * 8, 0x00020000);
+      constexpr int RW = APART ? 64 : 64 / SHARE;
       for (int b = 0; b < nb; ++b)
         {
-          unsigned off = 64u * 8u * (unsigned)b + (unsigned)(w * RW) * (unsigned)rlen * 8u;
+          unsigned off = 64u * 8u * (unsigned)b + (APART ? 0u : (unsigned)(w * RW) * (unsigned)rlen * 8u);
 #pragma unroll
           for (int r = 0; r < RW; ++r)
             {
@@ -140,7 +142,15 @@ int main()
   const size_t n = (size_t)NP * 64 * NB * 64;
   double *v;
   unsigned *sched;
-  CHECK(hipMalloc(&v, (n + 64) * sizeof(double)));
+  // ROWS_PROBE_ALLOC=uncached | finegrained: the values in device memory of another kind (hipExtMallocWithFlags)
+  const char *kind = getenv("ROWS_PROBE_ALLOC");
+  if (kind && kind[0] == 'u')
+    CHECK(hipExtMallocWithFlags((void **)&v, (n + 64) * sizeof(double), hipDeviceMallocUncached));
+  else if (kind && kind[0] == 'f')
+    CHECK(hipExtMallocWithFlags((void **)&v, (n + 64) * sizeof(double), hipDeviceMallocFinegrained));
+  else
+    CHECK(hipMalloc(&v, (n + 64) * sizeof(double)));
+  std::printf("allocation: %s\n", kind ? kind : "hipMalloc");
   CHECK(hipMalloc(&sched, 64));
   CHECK(hipMemset(sched, 0, 64));
   hipEvent_t e0, e1;
@@ -163,6 +173,25 @@ int main()
     ms /= 5;
     std::printf("aux %2d  %s  spin %2d (x64 dependent FMA per polytope)  %2d waves/CU (LDS %6zu B): %.3f ms  %.2f TB/s\n", AUX,
                 order == 2 ? "piece-major, dwordx4 (2 rows)" : (order ? "row-major  " : "piece-major"), spin, per_cu, lds, ms, n * 8.0 / ms / 1e9);
+  };
+  auto run_apart = [&](auto share_, int spin, int waves_per_cu) {
+    constexpr int SHARE = decltype(share_)::value;
+    const int wg_per_cu = waves_per_cu / SHARE;
+    const size_t lds = 64 * 1024 - 64;
+    const int grid = 256 * wg_per_cu;
+    auto launch = [&] { hipLaunchKernelGGL((k_rows_shared<18, SHARE, true>), dim3(grid), dim3(64 * SHARE), lds, 0, v, sched, NP / SHARE, NB, spin); };
+    launch();
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < 5; ++i)
+      launch();
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= 5;
+    std::printf("aux 18  control: workgroups of %d waves in step, every wave a polytope of its own  %2d waves/CU: %.3f ms  %.2f TB/s\n", SHARE,
+                waves_per_cu, ms, n * 8.0 / ms / 1e9);
   };
   auto run_shared = [&](auto share_, int spin, int waves_per_cu) {
     constexpr int SHARE = decltype(share_)::value;
@@ -191,6 +220,8 @@ int main()
       if (per_cu >= 8)
         run_shared(std::integral_constant<int, 8>{}, 16, per_cu);
     }
+  run_apart(std::integral_constant<int, 8>{}, 16, 8);
+  run_apart(std::integral_constant<int, 4>{}, 16, 8);
   for (int order : {0})
     for (int per_cu : {2, 8})
       {
