@@ -239,8 +239,9 @@ int pdh_values_checksum(pdh_ctx *ctx, double *out4);
  * FE_DGQ / FE_AggloDGP of degree 1 .. 3 when every face of every owned polytope lies in an axis-aligned plane (agglomerates
  * of Cartesian cells): the face moments are then rank one and a coupling block is a Kronecker product C (4x4) x S.  Every
  * element but FE_DGQ(3) additionally needs tensor-product rules on the sub-cells and sub-faces (vq_tensor_n / fq_tensor_n).
- * AUTO takes it from degree 2 on when the resident problem qualifies (tested on the quadrature points at pdh_set_problem,
- * no mesh flag needed).                                                                                              */
+ * FE_DGQ(3) also takes polytopes that meet a neighbour along several planes (METIS-like agglomerates of Cartesian cells).
+ * AUTO takes it whenever the resident problem qualifies (tested on the quadrature points at pdh_set_problem, no mesh flag
+ * needed).                                                                                                           */
 #define PDH_ALG_ROWS 4
 /* Host-only: 1 if PDH_ALG_ROWS applies to this description / row range, 0 if not (pdh_last_error(NULL) says why). */
 int pdh_check_rows(const pdh_problem *problem, int32_t row_begin, int32_t row_end);
