@@ -33,9 +33,14 @@
 //   P3 carry into the own block's piece: last column of the block left of it
 //   P4 diagonal block: three-stage contraction on the MFMA (pdh_moment.h), rows written slab by slab
 //   P5 coupling blocks in ascending column order: tables -> S, C -> 64 products per lane -> stores
-// Instantiations: <N1D, BASIS, GENERAL, SHIFTED> - GENERAL = false drops the general-point paths (the host verified tensor
+// Instantiations: <N1D, BASIS, GENERAL, SHIFTED, MULTI> - GENERAL = false drops the general-point paths (the host verified tensor
 // rules everywhere), SHIFTED = diagonal-first rows; both are facts of a resident problem, and keeping the other variant's
-// code out of the kernel is worth 5-10 % (register allocation).
+// code out of the kernel is worth 5-10 % (register allocation).  MULTI (FE_DGQ(3) only): polytopes that meet a neighbour along
+// several planes or have more than 6 interior / 16 plane entries (METIS-like agglomerates of Cartesian cells) - a coupling
+// block is then the SUM over the neighbour's plane entries of C_e (x) S_e, accumulated in registers 32 rows at a time; the
+// coupling data of the entries are parked in a per-workgroup row of global memory between P2 and P5 (PdhRows::m2c_scratch:
+// LDS stays at the block kernel's 20 KB whatever the number of entries), as 2-D moments (GENERAL) or, with tensor rules, as
+// the two 4 x 4 factors of every sub-face (FACT below).
 //
 // Row stores (P4 epilogue, P5): BUFFER stores through one resource per polytope - address = base of the polytope's rows (four
 // SGPRs) + scalar offset (row and piece, advanced by SALU adds) + 32-bit lane offset; with a plain pointer the compiler forms a
