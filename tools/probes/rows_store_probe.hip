@@ -14,6 +14,9 @@ typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 // order 0: piece-major (all 64 rows of piece 0, then piece 1, ... - the row kernel's P5); 1: row-major (the nb pieces of row 0,
 // then row 1, ...: 3584 contiguous bytes at a time)
 // AUX: cache-policy bits of the store (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+// g_pad: extra doubles between the regions of consecutive polytopes (the CSR layout has none: 64 rows x 448 values = 7 x 64 KB);
+// g_rot: polytope k starts its pieces with row (g_rot k) mod 64 instead of row 0
+__constant__ int g_pad, g_rot;
 template <int AUX>
 __global__ void __launch_bounds__(64, 2) k_rows_like(double *v, unsigned *sched, int n_poly, int nb, int spin, int order)
 {
@@ -33,8 +36,19 @@ __global__ void __launch_bounds__(64, 2) k_rows_like(double *v, unsigned *sched,
 #pragma unroll
         for (int k = 0; k < 64; ++k)
           acc = acc * 1.0000001 + 1e-9;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(v + (size_t)slot * 64 * rlen, 0, 64 * rlen * 8, 0x00020000);
-      if (order == 2)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(v + (size_t)slot * (64 * rlen + g_pad), 0, 64 * rlen * 8, 0x00020000);
+      if (order == 3)
+        { // piece-major, rows rotated by the polytope number
+          const unsigned r0 = (unsigned)(g_rot * slot) & 63u;
+          for (int b = 0; b < nb; ++b)
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r)
+              {
+                const unsigned rr = (r0 + (unsigned)r) & 63u;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, acc + r), rs, lane * 8, 64u * 8u * (unsigned)b + rr * (unsigned)rlen * 8u, AUX);
+              }
+        }
+      else if (order == 2)
         { // dwordx4: a store instruction writes 2 x 512 bytes - lanes 0..31 the piece of row r (16 bytes each), lanes 32..63 of row r + 32
           typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
           const unsigned lo = (unsigned)(lane & 31) * 16u + (unsigned)(lane >> 5) * 32u * (unsigned)rlen * 8u;
@@ -149,9 +163,14 @@ int main()
   else if (kind && kind[0] == 'f')
     CHECK(hipExtMallocWithFlags((void **)&v, (n + 64) * sizeof(double), hipDeviceMallocFinegrained));
   else
-    CHECK(hipMalloc(&v, (n + 64) * sizeof(double)));
+    CHECK(hipMalloc(&v, (n + 64 + (size_t)NP * 8300) * sizeof(double)));
   std::printf("allocation: %s\n", kind ? kind : "hipMalloc");
   CHECK(hipMalloc(&sched, 64));
+  auto set_pad_rot = [&](int pad, int rot) {
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_pad), &pad, sizeof(int)));
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_rot), &rot, sizeof(int)));
+  };
+  set_pad_rot(0, 0);
   CHECK(hipMemset(sched, 0, 64));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
@@ -172,7 +191,7 @@ int main()
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     ms /= 5;
     std::printf("aux %2d  %s  spin %2d (x64 dependent FMA per polytope)  %2d waves/CU (LDS %6zu B): %.3f ms  %.2f TB/s\n", AUX,
-                order == 2 ? "piece-major, dwordx4 (2 rows)" : (order ? "row-major  " : "piece-major"), spin, per_cu, lds, ms, n * 8.0 / ms / 1e9);
+                order == 3 ? "piece-major, rows rotated" : (order == 2 ? "piece-major, dwordx4 (2 rows)" : (order ? "row-major  " : "piece-major")), spin, per_cu, lds, ms, n * 8.0 / ms / 1e9);
   };
   auto run_apart = [&](auto share_, int spin, int waves_per_cu) {
     constexpr int SHARE = decltype(share_)::value;
@@ -220,6 +239,20 @@ int main()
       if (per_cu >= 8)
         run_shared(std::integral_constant<int, 8>{}, 16, per_cu);
     }
+  for (int pad : {0, 32, 512, 520, 8192 + 32})
+    {
+      set_pad_rot(pad, 0);
+      std::printf("pad %d doubles between polytopes: ", pad);
+      run(std::integral_constant<int, 18>{}, 0, 16, 8);
+    }
+  set_pad_rot(0, 0);
+  for (int rot : {0, 1, 8, 9, 23})
+    {
+      set_pad_rot(0, rot);
+      std::printf("rows rotated by %d x polytope number: ", rot);
+      run(std::integral_constant<int, 18>{}, 3, 16, 8);
+    }
+  set_pad_rot(0, 0);
   run_apart(std::integral_constant<int, 8>{}, 16, 8);
   run_apart(std::integral_constant<int, 4>{}, 16, 8);
   for (int order : {0})
