@@ -150,6 +150,67 @@ __global__ void __launch_bounds__(64 * SHARE) k_rows_shared(double *v, unsigned 
       }
 }
 
+// The store pattern a workgroup-of-eight row kernel would have: a workgroup takes EIGHT polytopes at a time (wave w computes
+// polytope 8 s + w); the six coupling blocks are written in six phases - in phase b every wave writes its eight rows
+// (8 w .. 8 w + 7) of piece b of all eight polytopes, barrier - and each wave writes the 64 rows of the own block (piece 6 here)
+// of its polytope alone.
+template <int AUX>
+__global__ void __launch_bounds__(512) k_rows_coop(double *v, unsigned *sched, int n_groups, int nb, int spin)
+{
+  extern __shared__ double lds[];
+  __shared__ int next_slot;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int slot = blockIdx.x;
+  double acc = lane;
+  for (;;)
+    {
+      if (threadIdx.x == 0)
+        next_slot = (int)gridDim.x + (int)__hip_atomic_fetch_add(sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int rlen = nb * 64;
+      for (int s = 0; s < spin; ++s)
+#pragma unroll
+        for (int k = 0; k < 64; ++k)
+          acc = acc * 1.0000001 + 1e-9;
+      for (int b = 0; b < nb - 1; ++b)
+        {
+          for (int p = 0; p < 8; ++p)
+            {
+              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(v + (size_t)(slot * 8 + p) * 64 * rlen, 0, 64 * rlen * 8, 0x00020000);
+              unsigned off = 64u * 8u * (unsigned)b + (unsigned)(w * 8) * (unsigned)rlen * 8u;
+#pragma unroll
+              for (int r = 0; r < 8; ++r)
+                {
+                  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, acc + r), rs, lane * 8, off, AUX);
+                  off += (unsigned)rlen * 8u;
+                }
+            }
+          __syncthreads();
+        }
+      {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(v + (size_t)(slot * 8 + w) * 64 * rlen, 0, 64 * rlen * 8, 0x00020000);
+        unsigned off = 64u * 8u * (unsigned)(nb - 1);
+#pragma unroll
+        for (int r = 0; r < 64; ++r)
+          {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, acc + r), rs, lane * 8, off, AUX);
+            off += (unsigned)rlen * 8u;
+          }
+      }
+      __syncthreads();
+      const int nslot = next_slot;
+      __syncthreads();
+      if (nslot >= n_groups)
+        break;
+      slot = nslot;
+    }
+  if (threadIdx.x == 0)
+    if (__hip_atomic_fetch_add(sched + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+      {
+        __hip_atomic_store(sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sched + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+}
+
 int main()
 {
   const int NP = 32768, NB = 7;
@@ -238,6 +299,22 @@ int main()
       run_shared(std::integral_constant<int, 4>{}, 16, per_cu);
       if (per_cu >= 8)
         run_shared(std::integral_constant<int, 8>{}, 16, per_cu);
+    }
+  for (int spin : {0, 16, 64})
+    {
+      auto launch = [&] { hipLaunchKernelGGL((k_rows_coop<18>), dim3(256), dim3(512), 160 * 1024 - 1024, 0, v, sched, NP / 8, NB, spin); };
+      launch();
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipEventRecord(e0));
+      for (int i = 0; i < 5; ++i)
+        launch();
+      CHECK(hipEventRecord(e1));
+      CHECK(hipDeviceSynchronize());
+      float ms;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= 5;
+      std::printf("aux 18  workgroup of eight: 8 polytopes at a time, coupling pieces by 8 rows per wave, own piece per wave  spin %2d: %.3f ms  %.2f TB/s\n", spin, ms,
+                  n * 8.0 / ms / 1e9);
     }
   for (int pad : {0, 32, 512, 520, 8192 + 32})
     {
