@@ -776,6 +776,15 @@ def test_moment_form_with_neighbours_of_very_different_size(r, lg):
     vd, _ = _values(kw, "direct")
     vm, _ = _values(kw, "moment")
     assert np.max(np.abs(vm - vd)) <= 1e-12 * np.max(np.abs(vd))
+    # AUTO: the row kernel where the big polytope's face entries fit (MULTI instantiation: every small neighbour is an entry of
+    # its own; with tensor rules both bases are evaluated in their own boxes - no common frame at all), else the forms above
+    va, used = _values(kw, "auto")
+    assert used in ("rows", "moment")
+    assert np.max(np.abs(va - vd)) <= 1e-12 * np.max(np.abs(vd))
+    if used == "rows":  # the same with the general-point paths (2-D moments in the shorter frame)
+        vg, used_g = _values(dict(kw, vq_tensor_n=-1, fq_tensor_n=-1), "rows")
+        assert used_g == "rows"
+        assert np.max(np.abs(vg - vd)) <= 1e-12 * np.max(np.abs(vd))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
