@@ -1195,6 +1195,39 @@ def test_row_kernel_staircase_agglomerates(cells, per, vname, diag_first, seed):
     assert_parity_ah(np.concatenate(parts), ref, ah, diag_first, what="row ranges")
 
 
+def test_row_kernel_staircase_with_large_plane_entries():
+    """MULTI instantiation with plane entries of MORE sub-faces than one staging round of its S takes (14): 4x4x4 blocks of an
+    8^3 grid, one corner cell moved from block A to its +x neighbour B - A and B then meet along a 15-sub-face plane, a
+    16-sub-face plane's worth of neighbours elsewhere, and the moved cell adds one-sub-face planes of three axes.  Parity with
+    the oracle per block; tensor rules and general points."""
+    fe = po.FE_DGQ(3, 3)
+    grid = po.subdivided_hyper_cube(3, 8, 0.0, 1.0)
+    c = lambda i, j, k: int(grid.ijk_to_cell[(i, j, k)])
+    blocks = {}
+    for i in range(8):
+        for j in range(8):
+            for k in range(8):
+                blocks.setdefault((i // 4, j // 4, k // 4), []).append(c(i, j, k))
+    moved = c(3, 0, 0)  # corner cell of block (0,0,0) on its +x face
+    blocks[(0, 0, 0)].remove(moved)
+    blocks[(1, 0, 0)].append(moved)
+    ah = po.AgglomerationHandler(grid)
+    for key in sorted(blocks):
+        ah.define_agglomerate(sorted(blocks[key]))
+    ah.initialize_fe_values(4, 4)
+    ah.distribute_agglomerated_dofs(fe)
+    var = po.variant_poisson_example(fe)
+    for diag_first in (True, False):
+        kw = flatten(ah, var, diag_first=diag_first)
+        ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
+        v0, used = _values(kw, "auto")
+        assert used == "rows"
+        assert_parity_ah(v0, ref, ah, diag_first, what="rows, large plane entries (tensor rules)")
+        vg, used = _values(dict(kw, vq_tensor_n=-1, fq_tensor_n=-1), "rows")
+        assert used == "rows"
+        assert_parity_ah(vg, ref, ah, diag_first, what="rows, large plane entries (general points)")
+
+
 def test_poisson_sanity_check_02_on_gpu():
     """test/polydeal/poisson_sanity_check_02.output ('Step function = 2', 'V function = 1') with the matrix assembled by the
     product chain (host mirror -> C ABI -> HIP kernels)."""
