@@ -246,6 +246,19 @@ int pdh_values_checksum(pdh_ctx *ctx, double *out4);
 /* Host-only: 1 if PDH_ALG_ROWS applies to this description / row range, 0 if not (pdh_last_error(NULL) says why). */
 int pdh_check_rows(const pdh_problem *problem, int32_t row_begin, int32_t row_end);
 int pdh_set_algorithm(pdh_ctx *ctx, int algorithm);
+/* Which row kernel serves the resident problem (PDH_ALG_ROWS has several; all write whole rows, owner computes rows):
+ *   PIECES   FE_DGQ(3), one plane per neighbour: moments + Kronecker form, rows in aligned 512-byte pieces (pdh_rows.h)
+ *   MULTI    FE_DGQ(3), several planes per neighbour (METIS-like agglomerates of Cartesian cells; pdh_rows.h)
+ *   STREAMED FE_DGQ(1,2) / FE_AggloDGP(1..3), moment form, one plane per neighbour (pdh_rows.h)
+ *   TERMS    FE_DGQ(1,2) / FE_AggloDGP(1..3) on any agglomerate of Cartesian cells with tensor-product rules: every entry a
+ *            short sum of products of three 1-D matrix entries, any number of planes per neighbour (pdh_terms.h; reference
+ *            examples/poisson.cc:413, 543-566 - FE_AggloDGP on METIS agglomerates - is this case)                       */
+#define PDH_ROWS_NONE 0
+#define PDH_ROWS_PIECES 1
+#define PDH_ROWS_MULTI 2
+#define PDH_ROWS_STREAMED 3
+#define PDH_ROWS_TERMS 4
+int pdh_rows_kernel_in_use(pdh_ctx *ctx);
 int pdh_algorithm_in_use(pdh_ctx *ctx); /* PDH_ALG_DIRECT, PDH_ALG_MOMENT, PDH_ALG_MIXED or PDH_ALG_ROWS for the resident problem, < 0 on error */
 
 /* On large problems the two kernels of a step (diagonal blocks / coupling blocks: disjoint values, complementary

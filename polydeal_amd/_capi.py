@@ -50,7 +50,7 @@ EXPORTS = [
     "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
     "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows", "pdh_values_checksum",
     "pdh_assemble_rhs_device", "pdh_evaluate_device", "pdh_shape_values_device",
-    "pdh_global_error", "pdh_global_error_device",
+    "pdh_global_error", "pdh_global_error_device", "pdh_rows_kernel_in_use",
 ]
 
 _lib = None
@@ -91,6 +91,7 @@ def _bind(lib):
     lib.pdh_set_algorithm.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_set_overlap.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_algorithm_in_use.argtypes = [C.c_void_p]
+    lib.pdh_rows_kernel_in_use.argtypes = [C.c_void_p]
     lib.pdh_set_exchange_mode.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_exchange_layout.argtypes = [C.c_void_p, C.c_int, P(C.c_int64), P(C.c_int64)]
     lib.pdh_exchange_get_send.argtypes = [C.c_void_p, C.c_void_p]
@@ -345,6 +346,13 @@ class Context:
         if rc < 0:
             self._chk(rc)
         return {1: "direct", 2: "moment", 3: "mixed", 4: "rows"}[rc]
+
+    def rows_kernel_in_use(self):
+        """Which row kernel serves the resident problem (include/polydeal_hip.h: PDH_ROWS_*)."""
+        rc = self.lib.pdh_rows_kernel_in_use(self.h)
+        if rc < 0:
+            self._chk(rc)
+        return {0: "none", 1: "pieces", 2: "multi", 3: "streamed", 4: "terms"}[rc]
 
     def set_profiling(self, on=True):
         self._chk(self.lib.pdh_set_profiling(self.h, int(on)))

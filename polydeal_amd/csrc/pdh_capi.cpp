@@ -76,8 +76,12 @@ extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_
 
 extern "C" hipError_t pdh_launch_moment(int n1d, int which, const PdhDev *P, const double *mtab, int count, hipStream_t stream);
 #include "pdh_rows_tables.h"
+#include "pdh_terms_tables.h"
 extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const double *mtab, int count, hipStream_t stream);
 extern "C" int pdh_rows_n_dofs(int n1d, int basis);
+extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int count, hipStream_t stream);
+extern "C" int pdh_terms_has_kind(int n1d, int basis);
+extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell);
 extern "C" int pdh_rows_max_faces(void);
 extern "C" int pdh_moment_table_doubles(int n1d);
 
@@ -182,9 +186,13 @@ struct pdh_ctx
   bool rows_ok = false;
   bool rows_auto = true; // AUTO takes the row kernel where it applies (degree 1 since 12 waves per CU are resident: 0.21 vs 0.24-0.30 ms)
   PdhRows rows;
+  // term kernel (pdh_terms.h): the row kernel of the small elements on agglomerates of Cartesian cells with tensor rules - any
+  // number of planes per neighbour; taken instead of the streamed kinds of pdh_rows.h wherever its tables fit the LDS budget
+  bool terms_ok = false;
+  PdhTerms terms;
   bool use_rows() const
   {
-    return rows_ok && d_mtab && ((algorithm == PDH_ALG_AUTO && rows_auto) || algorithm == PDH_ALG_ROWS);
+    return (rows_ok || terms_ok) && d_mtab && ((algorithm == PDH_ALG_AUTO && rows_auto) || algorithm == PDH_ALG_ROWS);
   }
   // which form each of the two launches uses: [0] diagonal blocks, [1] coupling blocks
   bool use_moment(int kind) const
@@ -1119,10 +1127,14 @@ struct RowsHost
   bool multi = false;
   int maxe = 16, maxf = 6;
   int maxs = 0; // most sub-faces (groups of a tensor rule) of the interior entries of one polytope
+  // every face point of every owned polytope has an axis-aligned normal and lies in the plane of its sub-face: established
+  // before the element-specific limits of the kinds of pdh_rows.h are looked at (the term kernel, pdh_terms.h, needs no more)
+  bool planar_ok = false;
+  std::vector<signed char> fast_j; // per run and normal axis: does the second tangential axis run fastest in the sub-face rules?
 };
 static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R, std::string *why = nullptr)
 {
-  std::vector<signed char> fast_j;
+  std::vector<signed char> &fast_j = R.fast_j;
   R.fq_tensor_n = resolve_tensor_hint(p->fq_tensor_n, [&](int n) { return face_rules_are_tensor(p, K, n, fast_j); });
   if (R.fq_tensor_n == 0)
     fast_j.clear();
@@ -1203,6 +1215,7 @@ static bool build_rows_tables(const pdh_problem *p, const Packed &K, RowsHost &R
   for (size_t r = 0; r < nruns; ++r)
     if (why_run[r])
       return no(why_run[r]);
+  R.planar_ok = true;
   // runs are stored slot by slot; order the faces of a slot: boundary first, then ascending block rank
   R.fr_ptr.assign(1, 0);
   size_t r = 0;
@@ -1381,6 +1394,147 @@ static bool rows_kind_applies(const pdh_problem *p, const Packed &K, const RowsH
   return ok;
 }
 
+// Tables of the term kernel (pdh_terms.h): per owned polytope one record (header + one entry per run = polytopal face, the
+// boundary run first, then ascending block rank) and the list of its sub-faces (groups of a verified tensor rule), run by run:
+// first own-side point, run, normal axis and sign, orientation of the rule.  Applies when build_rows_tables established planar
+// axis-aligned faces (RowsHost::planar_ok) and both kinds of rule are verified tensor rules; any number of planes per neighbour.
+struct TermsHost
+{
+  std::vector<double> meta;
+  std::vector<int64_t> sf_pt;
+  std::vector<int32_t> sf_info;
+  int maxruns = 0, maxsf = 0, maxsi = 0, maxcell = 0, lds_bytes = 0;
+};
+static constexpr int PDH_TERMS_LDS_CAP = 40 * 1024; // bytes per workgroup: four resident waves per CU at least
+static bool build_terms_tables(const pdh_problem *p, const Packed &K, const RowsHost &RH, int vq_n, TermsHost &T, std::string *why = nullptr)
+{
+  auto no = [&](const char *m) {
+    if (why)
+      *why = m;
+    return false;
+  };
+  const int basis = p->basis == PDH_BASIS_AGGLODGP ? 1 : 0;
+  if (p->dim != 3 || !pdh_terms_has_kind(K.n1d, basis))
+    return no("term kernel: 3-D FE_DGQ(1,2) / FE_AggloDGP(1..3) only");
+  if (!RH.planar_ok || RH.fq_tensor_n <= 0 || vq_n <= 0 || (int)K.own_agg.size() != K.n_owned)
+    return no("term kernel: needs axis-aligned planar faces and tensor-product rules on every sub-cell and sub-face");
+  const int fn = RH.fq_tensor_n;
+  const int64_t gsz = (int64_t)fn * fn, m3 = (int64_t)vq_n * vq_n * vq_n;
+  const size_t nruns = K.run_ap.size();
+  // runs of every slot in the order of the records
+  std::vector<std::vector<size_t>> order((size_t)K.n_owned);
+  {
+    size_t r = 0;
+    for (int sl = 0; sl < K.n_owned; ++sl)
+      {
+        auto &idx = order[sl];
+        for (; r < nruns && K.run_slot[r] == sl; ++r)
+          idx.push_back(r);
+        std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return K.run_blk[x] < K.run_blk[y]; });
+        int nsf = 0, nsi = 0, nb = 0;
+        for (size_t t : idx)
+          {
+            if (K.run_cnt[t] % gsz)
+              return no("term kernel: a face is not made of whole sub-face rules");
+            const int ns = (int)(K.run_cnt[t] / gsz);
+            nsf += ns;
+            if (K.run_nbr[t] >= 0)
+              nsi += ns;
+            else
+              ++nb;
+          }
+        if (nb > 1)
+          return no("term kernel: more than one boundary run on a polytope");
+        const int64_t nq = K.vq_ptr[sl + 1] - K.vq_ptr[sl];
+        if (nq % m3 || nq / m3 > 65535 || idx.size() > 250)
+          return no("term kernel: too many cells or faces on a polytope");
+        T.maxruns = std::max<int>(T.maxruns, (int)idx.size());
+        T.maxsf = std::max(T.maxsf, nsf);
+        T.maxsi = std::max(T.maxsi, nsi);
+        T.maxcell = std::max<int>(T.maxcell, (int)(nq / m3));
+      }
+    if (r != nruns)
+      return no("run bookkeeping");
+  }
+  T.maxruns = std::max(T.maxruns, 1);
+  T.lds_bytes = pdh_terms_lds_bytes(K.n1d, basis, T.maxruns, T.maxsf, T.maxsi, T.maxcell);
+  if (T.lds_bytes <= 0 || T.lds_bytes > PDH_TERMS_LDS_CAP)
+    return no("term kernel: the tables of the largest polytope do not fit its LDS budget (moment-based kinds take over)");
+  constexpr int HDR = 12, ENT = 10;
+  const int REC = HDR + T.maxruns * ENT;
+  auto as_d = [](long long v) {
+    double d;
+    std::memcpy(&d, &v, sizeof(d));
+    return d;
+  };
+  std::vector<int64_t> sf_first((size_t)K.n_owned + 1, 0);
+  for (int sl = 0; sl < K.n_owned; ++sl)
+    {
+      int64_t n = 0;
+      for (size_t t : order[sl])
+        n += K.run_cnt[t] / gsz;
+      sf_first[sl + 1] = sf_first[sl] + n;
+    }
+  T.sf_pt.resize((size_t)sf_first[K.n_owned]);
+  T.sf_info.resize((size_t)sf_first[K.n_owned]);
+  T.meta.assign((size_t)K.n_owned * REC, 0.0);
+  std::vector<char> bad((size_t)K.n_owned, 0);
+  host_parallel_for((size_t)K.n_owned, [&](size_t sl) {
+    double *rec = T.meta.data() + sl * REC;
+    const int a = K.own_agg[sl];
+    const auto &idx = order[sl];
+    int64_t at = sf_first[sl];
+    int nsfb = 0, e = 0;
+    for (size_t t : idx)
+      {
+        const int ns = (int)(K.run_cnt[t] / gsz), nb = K.run_nbr[t];
+        double *en = rec + HDR + e * ENT;
+        en[0] = as_d((long long)(uint32_t)(at - sf_first[sl]) | ((long long)ns << 32));
+        en[1] = as_d((long long)K.run_blk[t]);
+        en[2] = K.run_sig[t];
+        for (int c = 0; c < 3; ++c)
+          {
+            en[3 + c] = nb >= 0 ? p->bbox[(size_t)nb * 6 + c] : 0.0;
+            en[6 + c] = nb >= 0 ? 1.0 / (p->bbox[(size_t)nb * 6 + 3 + c] - p->bbox[(size_t)nb * 6 + c]) : 1.0;
+          }
+        if (nb < 0)
+          {
+            nsfb += ns;
+            if (e != 0)
+              bad[sl] = 1; // (the kernel takes the boundary run to be run 0)
+          }
+        for (int g = 0; g < ns; ++g, ++at)
+          {
+            int c = 0;
+            for (int d = 0; d < 3; ++d)
+              if (std::fabs(K.ap_n(d, t, g * gsz)) > 0.5)
+                c = d;
+            const int pos = K.ap_n(c, t, g * gsz) > 0 ? 1 : 0;
+            const int fj = RH.fast_j[3 * t + c] == 1 ? 1 : 0;
+            T.sf_pt[(size_t)at] = K.run_ap[t] + g * gsz;
+            T.sf_info[(size_t)at] = e | (c << 8) | (pos << 10) | (fj << 11);
+          }
+        ++e;
+      }
+    const int64_t nq = K.vq_ptr[sl + 1] - K.vq_ptr[sl];
+    rec[0] = as_d((long long)idx.size() | ((long long)(nq / m3) << 16) | ((long long)nsfb << 32));
+    for (int c = 0; c < 3; ++c)
+      {
+        rec[1 + c] = p->bbox[(size_t)a * 6 + c];
+        rec[4 + c] = 1.0 / (p->bbox[(size_t)a * 6 + 3 + c] - p->bbox[(size_t)a * 6 + c]);
+      }
+    rec[7] = as_d(K.row_base[sl]);
+    rec[8] = as_d(K.row_len[sl]);
+    rec[9] = as_d(K.diag_L[sl]);
+    rec[10] = as_d(K.vq_ptr[sl]);
+    rec[11] = as_d((long long)sf_first[sl] | ((long long)(sf_first[sl + 1] - sf_first[sl]) << 40));
+  });
+  for (char c : bad)
+    if (c)
+      return no("term kernel: run order");
+  return true;
+}
+
 // Host-only: 1 if the row kernel (PDH_ALG_ROWS) applies to this description and row range, 0 if not (pdh_last_error(NULL)
 // says why), < 0 on an invalid description.
 extern "C" int pdh_check_rows(const pdh_problem *p, int32_t row_begin, int32_t row_end)
@@ -1396,6 +1550,16 @@ extern "C" int pdh_check_rows(const pdh_problem *p, int32_t row_begin, int32_t r
   bool tensor_only = false;
   if (build_rows_tables(p, K, R, &why) && rows_kind_applies(p, K, R, vq_n, tensor_only, &why))
     return 1;
+  if (R.planar_ok && R.fq_tensor_n > 0)
+    { // the term kernel (pdh_terms.h) takes the small elements on any agglomerate of Cartesian cells with tensor rules
+      std::string why_t;
+      TermsHost TH;
+      const int vn = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
+      if (vn > 0 && build_terms_tables(p, K, R, vn, TH, &why_t))
+        return 1;
+      if (!why_t.empty())
+        why += "; " + why_t;
+    }
   g_err_noctx = why;
   return 0;
 }
@@ -1678,10 +1842,13 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
     }
   lap("values + tables");
   ctx->rows_ok = false;
+  ctx->terms_ok = false;
   if (ctx->d_mtab && !ctx->problem_ghost)
     {
       RowsHost RH;
-      if (build_rows_tables(p, K, RH))
+      const bool rows_built = build_rows_tables(p, K, RH);
+      int vq_n_terms = -1; // (not looked at yet)
+      if (rows_built)
         {
           lap("row kernel: planes + records");
           PdhRows &R = ctx->rows;
@@ -1754,7 +1921,34 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
           R.fq_tensor_n = RH.fq_tensor_n;
           ctx->rows_ok = ok;
           ctx->rows_auto = true;
+          vq_n_terms = vq_n;
           lap("row kernel: volume rule check");
+        }
+      // term kernel (pdh_terms.h): the small elements on agglomerates of Cartesian cells with tensor rules, any number of planes
+      // per neighbour.  PDH_TERMS=0 (diagnostics) keeps the kinds of pdh_rows.h.
+      const char *terms_e = getenv("PDH_TERMS"); // (read per call: the tests compare both kernels in one process)
+      const bool terms_env = !(terms_e && terms_e[0] == '0');
+      if (terms_env && RH.planar_ok && RH.fq_tensor_n > 0 && pdh_terms_has_kind(K.n1d, p->basis == PDH_BASIS_AGGLODGP ? 1 : 0))
+        {
+          if (vq_n_terms < 0)
+            vq_n_terms = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
+          TermsHost TH;
+          if (vq_n_terms > 0 && build_terms_tables(p, K, RH, vq_n_terms, TH))
+            {
+              PdhTerms &T = ctx->terms;
+              if ((rc = upload(ctx, TH.meta, &T.meta)) != PDH_OK || (rc = upload(ctx, TH.sf_pt, &T.sf_pt)) != PDH_OK ||
+                  (rc = upload(ctx, TH.sf_info, &T.sf_info)) != PDH_OK)
+                {
+                  free_problem(ctx);
+                  return rc;
+                }
+              T.maxruns = TH.maxruns, T.maxsf = TH.maxsf, T.maxsi = TH.maxsi, T.maxcell = TH.maxcell;
+              T.vq_tensor_n = vq_n_terms, T.fq_tensor_n = RH.fq_tensor_n;
+              T.lds_bytes = TH.lds_bytes;
+              ctx->terms_ok = true;
+              ctx->rows_auto = true;
+              lap("term kernel: tables + upload");
+            }
         }
     }
   ctx->has_problem = true;
@@ -1782,6 +1976,19 @@ extern "C" int pdh_algorithm_in_use(pdh_ctx *ctx)
     return PDH_ALG_ROWS;
   const bool d = ctx->use_moment(0), o = ctx->use_moment(1);
   return d && o ? PDH_ALG_MOMENT : (d || o ? PDH_ALG_MIXED : PDH_ALG_DIRECT);
+}
+
+extern "C" int pdh_rows_kernel_in_use(pdh_ctx *ctx)
+{
+  if (!ctx || !ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "no problem resident");
+  if (!ctx->use_rows())
+    return PDH_ROWS_NONE;
+  if (ctx->terms_ok)
+    return PDH_ROWS_TERMS;
+  if (ctx->rows.multi)
+    return PDH_ROWS_MULTI;
+  return ctx->dev.n == 64 ? PDH_ROWS_PIECES : PDH_ROWS_STREAMED;
 }
 
 extern "C" int pdh_set_problem(pdh_ctx *ctx, const pdh_problem *p)
@@ -1817,7 +2024,10 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
             return fail(ctx, PDH_EDEVICE, "hipEventCreate failed");
           PDH_HIP(ctx, hipEventRecord(r0, ctx->stream));
         }
-      PDH_HIP(ctx, pdh_launch_rows(&ctx->dev, &ctx->rows, ctx->d_mtab, ctx->n_owned, ctx->stream));
+      if (ctx->terms_ok)
+        PDH_HIP(ctx, pdh_launch_terms(&ctx->dev, &ctx->terms, ctx->n_owned, ctx->stream));
+      else
+        PDH_HIP(ctx, pdh_launch_rows(&ctx->dev, &ctx->rows, ctx->d_mtab, ctx->n_owned, ctx->stream));
       if (ctx->profiling)
         {
           PDH_HIP(ctx, hipEventRecord(r1, ctx->stream));

@@ -1,0 +1,463 @@
+// pdh_terms.h — the term kernel: the row kernel of the SMALL elements (3-D FE_DGQ(1,2), FE_AggloDGP(1..3)) on agglomerates of
+// Cartesian cells with tensor-product rules on every sub-cell and sub-face.  One wave per owned polytope computes and writes ALL
+// values of the polytope's n rows (owner computes rows, like pdh_rows.h); what is computed is unchanged (reference
+// include/poly_utils.h:2040-2084 volume + boundary, :1870-1926 interface blocks), only the order of summation differs.
+//
+// Why another form.  On an axis-aligned cell with a tensor rule every integrand of the path is a product of three 1-D sums, so
+// every entry of the polytope's rows is a short sum of products of three small-matrix entries ("terms"):
+//   A[P,P]_(k,l) = sum over cells   (K0' M1 M2 + M0 K1 M2 + M0 M1 K2)[k_d, l_d]        M_d = sum_a w_a B_k B_l,  K_d = sum_a w_a B'_k B'_l / h_d^2
+//                + sum over sub-faces D0 D1 D2 [k_d, l_d]                              (K0' = K0 + c M0 with a reaction term)
+//                  tangential d: D_d = sum_a w_a B_k B_l (own-side JxW; 2 JxW on the boundary),
+//                  normal c:     D_c = sigma B_k B_l - 1/2 s (B'_k B_l + B_k B'_l) / h_c  at the plane (sigma / 2 on the boundary)
+//   A[P,Q]_(k,l) = sum over the sub-faces shared with Q   X0 X1 X2 [k_d, l_d]
+//                  tangential d: X_d = sum_a w_a B^P_k B^Q_l (JxW of side 1, each basis in its own box),
+//                  normal c:     X_c = (1/2 s B'_k(zP)/hP - sigma B_k(zP)) B_l(zQ) - 1/2 s B_k(zP) B'_l(zQ)/hQ
+// (the same identities as pdh_rows.h uses for its Kronecker form C (x) S, written per sub-face: no Legendre moments, no contraction
+// stages, no limit on the number of planes a neighbour is met along - "staircase" faces of METIS-like agglomerates of Cartesian
+// cells, reference examples/poisson.cc:543-566, are just more terms).  The streamed kinds of pdh_rows.h spent 6 100 VALU
+// instructions and two dozen LDS hand-offs per polytope of FE_AggloDGP(3) on moments and a three-stage sum factorisation
+// (profiles/r02v4_pmc_sq_dgp.txt: 2.0e8 VALU wave-instructions per launch, time ~ 1 / resident waves); this form needs a third
+// of the instructions and three hand-offs.  Cost grows with cells + sub-faces per polytope (the moment form's does not): the
+// host takes this kernel while a polytope's tables fit the LDS budget below, else the kinds of pdh_rows.h.
+//
+// Phases (one wave per polytope; LDS: record copy, digit table, coupling tables X, diagonal tables D / M / K):
+//   A  lane tasks build the small matrices: (sub-face, tangential direction) - fn points each -, (sub-face, normal direction),
+//      (cell, direction) - tn points each; symmetric ones packed (10 of 16 entries for degree 3)
+//   B1 diagonal block: lane = (column j, subset s of the terms); per term 3 column vectors from LDS, NS + n multiply-adds;
+//      the subsets are summed across lanes (ds_bpermute) and the block is left in LDS
+//   B2 rows: a row in pieces of 64 positions, lane = position = column; a coupling column sums the terms of its neighbour's
+//      sub-faces for all n rows in registers, an own column reads the block of B1; n buffer stores of 512 contiguous bytes per piece
+#pragma once
+#include "pdh_kernels.h"
+#include "pdh_terms_tables.h"
+
+namespace pdht
+{
+using pdh::static_for;
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+
+constexpr int TERMS_HDR = 12, TERMS_ENT = 10;
+
+template <int N1D, int BASIS>
+struct Kind
+{
+  static constexpr int NF = BASIS == 0 ? N1D * N1D * N1D : N1D * (N1D + 1) * (N1D + 2) / 6; // functions
+  static constexpr int NS = BASIS == 0 ? N1D * N1D : N1D * (N1D + 1) / 2;                   // pairs (k1, k2) that occur
+  static constexpr int NSYM = N1D * (N1D + 1) / 2, FULL = N1D * N1D;
+  static constexpr int SYMS = NSYM | 1, FULLS = FULL | 1; // odd strides: the lane tasks of phase A write table after table
+  static constexpr int NSUB = 64 / NF > 0 ? 64 / NF : 1;  // subsets of the diagonal block's terms (lanes = NSUB x NF columns)
+  struct Dig
+  {
+    int k0, k1, k2;
+  };
+  // digits of function R (x fastest; BASIS 1: k0 + k1 + k2 <= p, pdh_basis.h: multi_indices)
+  __host__ __device__ static constexpr Dig dig(int R)
+  {
+    if (BASIS == 0)
+      return Dig{R % N1D, (R / N1D) % N1D, R / (N1D * N1D)};
+    int cnt = 0;
+    for (int iz = 0; iz < N1D; ++iz)
+      for (int iy = 0; iy < N1D - iz; ++iy)
+        for (int ix = 0; ix < N1D - iy - iz; ++ix)
+          {
+            if (cnt == R)
+              return Dig{ix, iy, iz};
+            ++cnt;
+          }
+    return Dig{0, 0, 0};
+  }
+  __host__ __device__ static constexpr int pair(int k1, int k2) { return BASIS == 0 ? k1 + N1D * k2 : k2 * N1D - k2 * (k2 - 1) / 2 + k1; }
+  __host__ __device__ static constexpr bool pair_ok(int k1, int k2) { return BASIS == 0 || k1 + k2 < N1D; }
+  __host__ __device__ static constexpr int sym(int k, int l) { return k <= l ? l * (l + 1) / 2 + k : k * (k + 1) / 2 + l; }
+};
+
+// LDS of a workgroup in doubles (host and device agree through this one function)
+__host__ __device__ constexpr int terms_rec_doubles(int maxruns) { return (TERMS_HDR + maxruns * TERMS_ENT + 1) & ~1; }
+template <int N1D, int BASIS>
+__host__ __device__ constexpr int terms_lds_doubles(int maxruns, int maxsf, int maxsi, int maxcell)
+{
+  using K = Kind<N1D, BASIS>;
+  const int dg = (K::NF + 1) / 2 + ((K::NF + 1) / 2 & 1);
+  const int xa = maxsi * 3 * K::FULLS + ((maxsi * 3 * K::FULLS) & 1);
+  int da = maxsf * 3 * K::SYMS + maxcell * 6 * K::SYMS;
+  da = da > K::NF * K::NF ? da : K::NF * K::NF;
+  return terms_rec_doubles(maxruns) + dg + xa + da + (da & 1);
+}
+
+template <int N1D, int BASIS, bool SHIFTED>
+__global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const PdhTerms T, const int n_owned)
+{
+  using K = Kind<N1D, BASIS>;
+  constexpr int NF = K::NF, NS = K::NS, NSYM = K::NSYM, SYMS = K::SYMS, FULL = K::FULL, FULLS = K::FULLS, NSUB = K::NSUB;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x;
+  if (slot >= n_owned)
+    return;
+  const int REC = TERMS_HDR + T.maxruns * TERMS_ENT;
+  double *rec = lds;
+  int *dig = reinterpret_cast<int *>(lds + terms_rec_doubles(T.maxruns));
+  double *Xa = lds + terms_rec_doubles(T.maxruns) + ((NF + 1) / 2 + ((NF + 1) / 2 & 1));
+  double *Da = Xa + (T.maxsi * 3 * FULLS + ((T.maxsi * 3 * FULLS) & 1));
+  auto sel3 = [](int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); };
+  auto uni = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  {
+    const double *g = T.meta + (int64_t)slot * REC;
+    for (int k = lane; k < REC; k += PDH_WAVE)
+      rec[k] = g[k];
+    if (lane < NF)
+      {
+        int k0 = 0, k1 = 0, k2 = 0, cnt = 0;
+        for (int iz = 0; iz < N1D; ++iz)
+          for (int iy = 0; iy < (BASIS == 0 ? N1D : N1D - iz); ++iy)
+            for (int ix = 0; ix < (BASIS == 0 ? N1D : N1D - iy - iz); ++ix)
+              {
+                if (cnt == lane)
+                  k0 = ix, k1 = iy, k2 = iz;
+                ++cnt;
+              }
+        dig[lane] = k0 | (k1 << 4) | (k2 << 8);
+      }
+  }
+  PDH_WAVE_SYNC();
+  const long long h0 = __double_as_longlong(uni(rec[0])), h11 = __double_as_longlong(uni(rec[11]));
+  const int ncell = (int)((h0 >> 16) & 0xffff), nsfb = (int)(h0 >> 32);
+  const int64_t sf_base = h11 & ((1ll << 40) - 1);
+  const int nsf = (int)(h11 >> 40);
+  const double lo0 = uni(rec[1]), lo1 = uni(rec[2]), lo2 = uni(rec[3]);
+  const double ih0 = uni(rec[4]), ih1 = uni(rec[5]), ih2 = uni(rec[6]);
+  const int64_t rbase = __double_as_longlong(uni(rec[7]));
+  const int rlen = (int)__double_as_longlong(uni(rec[8]));
+  const int L = (int)__double_as_longlong(uni(rec[9]));
+  const int64_t vq_b = __double_as_longlong(uni(rec[10]));
+  const int fn = T.fq_tensor_n, tn = T.vq_tensor_n;
+  double *Ca = Da + nsf * 3 * SYMS; // [cell][direction][M | K] behind the sub-faces' tables
+  // 1-D basis in the centred variable of a box (pdh_basis.h: monomial coefficients, uniform -> scalar operands)
+  auto basis = [&](double t, double *b) {
+    static_for<0, N1D>([&](auto k_) {
+      constexpr int k = k_;
+      double v = P.tab.coef[k][N1D - 1];
+      for (int m = N1D - 2; m >= 0; --m)
+        v = v * t + P.tab.coef[k][m];
+      b[k] = v;
+    });
+  };
+  auto basis_d = [&](double t, double *b, double *db) {
+    static_for<0, N1D>([&](auto k_) {
+      constexpr int k = k_;
+      double v = P.tab.coef[k][N1D - 1], d = 0.0;
+      for (int m = N1D - 2; m >= 0; --m)
+        {
+          d = d * t + v;
+          v = v * t + P.tab.coef[k][m];
+        }
+      b[k] = v, db[k] = d;
+    });
+  };
+
+  // ================= A: the small matrices =========================================================================
+  // (sub-face, tangential direction): D_d (own x own, own-side weights) and, towards a neighbour, X_d (own x neighbour, JxW of
+  // side 1).  The rule of a sub-face is a_alpha b_beta: direction 0 takes w_(alpha,0), direction 1 takes w_(0,beta) / w_(0,0)
+  for (int t0 = 0; t0 < 2 * nsf; t0 += PDH_WAVE)
+    {
+      const int tid = t0 + lane;
+      if (tid < 2 * nsf)
+        {
+          const int sf = tid >> 1, dir = tid & 1;
+          const int info = T.sf_info[sf_base + sf];
+          const int64_t pb = T.sf_pt[sf_base + sf];
+          const int run = info & 0xff, c = (info >> 8) & 3;
+          const bool fast_j = ((info >> 11) & 1) != 0;
+          const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
+          const int64_t stp = ((dir == 1) == fast_j) ? 1 : fn;
+          const double *re = rec + TERMS_HDR + run * TERMS_ENT;
+          const bool interior = (int)__double_as_longlong(re[1]) >= 0;
+          const double lo_d = sel3(ax, lo0, lo1, lo2), ih_d = sel3(ax, ih0, ih1, ih2);
+          const double loq = re[3 + ax], ihq = re[6 + ax];
+          double xr[8], wsr[8], wcr[8];
+          static_for<0, 8>([&](auto i_) { // all loads of the task first (fn <= 8, checked by the host)
+            constexpr int al = i_;
+            const int64_t q = al < fn ? pb + al * stp : pb;
+            xr[al] = al < fn ? P.ap_x[(int64_t)ax * P.ap_stride + q] : 0.0;
+            wsr[al] = al < fn ? P.ap_wself[q] : 0.0;
+            wcr[al] = (al < fn && interior) ? P.ap_wcross[q] : 0.0;
+          });
+          const double sS = dir ? 1.0 / wsr[0] : 1.0, sC = (dir && interior) ? 1.0 / wcr[0] : 1.0;
+          double Dm[NSYM], Xm[FULL];
+          for (int i = 0; i < NSYM; ++i)
+            Dm[i] = 0.0;
+          for (int i = 0; i < FULL; ++i)
+            Xm[i] = 0.0;
+          static_for<0, 8>([&](auto i_) {
+            constexpr int al = i_;
+            if (al < fn)
+              {
+                double bp[N1D], bq[N1D];
+                basis((xr[al] - lo_d) * ih_d - 0.5, bp);
+                basis((xr[al] - loq) * ihq - 0.5, bq);
+                const double wS = wsr[al] * sS, wC = wcr[al] * sC;
+                static_for<0, N1D>([&](auto k_) {
+                  constexpr int k = k_;
+                  const double ws = wS * bp[k], wc = wC * bp[k];
+                  static_for<k, N1D>([&](auto l_) { Dm[K::sym(k, l_)] += ws * bp[l_]; });
+                  static_for<0, N1D>([&](auto l_) { Xm[l_ * N1D + k] += wc * bq[l_]; });
+                });
+              }
+          });
+          double *dd = Da + (sf * 3 + ax) * SYMS;
+          for (int i = 0; i < NSYM; ++i)
+            dd[i] = Dm[i];
+          if (interior)
+            {
+              double *xd = Xa + ((sf - nsfb) * 3 + ax) * FULLS;
+              for (int i = 0; i < FULL; ++i)
+                xd[i] = Xm[i];
+            }
+        }
+    }
+  // (sub-face, normal direction) and (cell, direction)
+  {
+    const int ntask = nsf + 3 * ncell;
+    for (int t0 = 0; t0 < ntask; t0 += PDH_WAVE)
+      {
+        const int tid = t0 + lane;
+        if (tid < nsf)
+          {
+            const int sf = tid;
+            const int info = T.sf_info[sf_base + sf];
+            const int64_t pb = T.sf_pt[sf_base + sf];
+            const int run = info & 0xff, c = (info >> 8) & 3;
+            const double sg = ((info >> 10) & 1) ? 1.0 : -1.0;
+            const double *re = rec + TERMS_HDR + run * TERMS_ENT;
+            const bool interior = (int)__double_as_longlong(re[1]) >= 0;
+            const double sig = re[2];
+            const double lo_c = sel3(c, lo0, lo1, lo2), ih_c = sel3(c, ih0, ih1, ih2);
+            const double loq = re[3 + c], ihq = re[6 + c];
+            const double zeta = P.ap_x[(int64_t)c * P.ap_stride + pb];
+            double bp[N1D], dp[N1D], bq[N1D], dq[N1D];
+            basis_d((zeta - lo_c) * ih_c - 0.5, bp, dp);
+            basis_d((zeta - loq) * ihq - 0.5, bq, dq);
+            double *dd = Da + (sf * 3 + c) * SYMS;
+            double *xd = Xa + ((sf - nsfb) * 3 + c) * FULLS;
+            const double hs = 0.5 * sg * ih_c, hq = 0.5 * sg * ihq;
+            static_for<0, N1D>([&](auto k_) {
+              constexpr int k = k_;
+              static_for<k, N1D>([&](auto l_) {
+                constexpr int l = l_;
+                dd[K::sym(k, l)] = sig * bp[k] * bp[l] - hs * (dp[k] * bp[l] + bp[k] * dp[l]);
+              });
+              if (interior)
+                static_for<0, N1D>([&](auto l_) {
+                  constexpr int l = l_;
+                  xd[l * N1D + k] = (hs * dp[k] - sig * bp[k]) * bq[l] - hq * bp[k] * dq[l];
+                });
+            });
+          }
+        else if (tid < ntask)
+          {
+            const int ct = tid - nsf;
+            const int cell = ct / 3, d = ct - 3 * cell;
+            const int m3 = tn * tn * tn;
+            const int64_t base = vq_b + (int64_t)cell * m3;
+            const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
+            const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
+            double xr[8], wr[8];
+            static_for<0, 8>([&](auto i_) {
+              constexpr int i = i_;
+              xr[i] = i < tn ? P.vq_x[(int64_t)d * P.vq_stride + base + i * step] : 0.0;
+              wr[i] = i < tn ? P.vq_w[base + i * step] : 0.0;
+            });
+            const double sc = d == 0 ? 1.0 : 1.0 / wr[0];
+            double Mm[NSYM], Km[NSYM];
+            for (int i = 0; i < NSYM; ++i)
+              Mm[i] = Km[i] = 0.0;
+            static_for<0, 8>([&](auto i_) {
+              constexpr int i = i_;
+              if (i < tn)
+                {
+                  double bp[N1D], dp[N1D];
+                  basis_d((xr[i] - lo_d) * ih_d - 0.5, bp, dp);
+                  const double w = wr[i] * sc;
+                  static_for<0, N1D>([&](auto k_) {
+                    constexpr int k = k_;
+                    const double wb = w * bp[k], wd = w * (dp[k] * ih_d);
+                    static_for<k, N1D>([&](auto l_) {
+                      Mm[K::sym(k, l_)] += wb * bp[l_];
+                      Km[K::sym(k, l_)] += wd * (dp[l_] * ih_d);
+                    });
+                  });
+                }
+            });
+            if (d == 0 && P.reaction_c != 0.0) // c phi_i phi_j rides on the first term of the cell
+              for (int i = 0; i < NSYM; ++i)
+                Km[i] += P.reaction_c * Mm[i];
+            double *cd = Ca + (cell * 3 + d) * 2 * SYMS;
+            for (int i = 0; i < NSYM; ++i)
+              {
+                cd[i] = Mm[i];
+                cd[SYMS + i] = Km[i];
+              }
+          }
+      }
+  }
+  PDH_WAVE_SYNC();
+
+  // ================= B1: the diagonal block ========================================================================
+  {
+    double acc[NF];
+    for (int r = 0; r < NF; ++r)
+      acc[r] = 0.0;
+    const int s = lane / NF, j = lane - s * NF;
+    const bool on = s < NSUB;
+    const int dj = dig[j];
+    const int l0 = dj & 15, l1 = (dj >> 4) & 15, l2 = dj >> 8;
+    int o0[N1D], o1[N1D], o2[N1D]; // packed positions of column l_d of a symmetric table
+    for (int k = 0; k < N1D; ++k)
+      {
+        o0[k] = K::sym(k, l0);
+        o1[k] = K::sym(k, l1) + SYMS;
+        o2[k] = K::sym(k, l2) + 2 * SYMS;
+      }
+    // cells: (K0' M1 M2 + M0 (K1 M2 + M1 K2))[k, l]
+    for (int u = on ? s : ncell; u < ncell; u += NSUB)
+      {
+        const double *b = Ca + u * 6 * SYMS;
+        double M0[N1D], K0[N1D], M1[N1D], K1[N1D], M2[N1D], K2[N1D];
+        for (int k = 0; k < N1D; ++k)
+          {
+            M0[k] = b[o0[k]], K0[k] = b[o0[k] + SYMS];
+            M1[k] = b[o1[k] + SYMS], K1[k] = b[o1[k] + 2 * SYMS];
+            M2[k] = b[o2[k] + 2 * SYMS], K2[k] = b[o2[k] + 3 * SYMS];
+          }
+        double mm[NS], km[NS];
+        static_for<0, N1D>([&](auto k2_) {
+          static_for<0, N1D>([&](auto k1_) {
+            constexpr int k1 = k1_, k2 = k2_;
+            if constexpr (K::pair_ok(k1, k2))
+              {
+                mm[K::pair(k1, k2)] = M1[k1] * M2[k2];
+                km[K::pair(k1, k2)] = K1[k1] * M2[k2] + M1[k1] * K2[k2];
+              }
+          });
+        });
+        static_for<0, NF>([&](auto r_) {
+          constexpr typename K::Dig g = K::dig(r_);
+          acc[r_] += K0[g.k0] * mm[K::pair(g.k1, g.k2)] + M0[g.k0] * km[K::pair(g.k1, g.k2)];
+        });
+      }
+    // sub-faces: (D0 D1 D2)[k, l]
+    for (int u = on ? s : nsf; u < nsf; u += NSUB)
+      {
+        const double *b = Da + u * 3 * SYMS;
+        double f0[N1D], f1[N1D], f2[N1D];
+        for (int k = 0; k < N1D; ++k)
+          f0[k] = b[o0[k]], f1[k] = b[o1[k]], f2[k] = b[o2[k]];
+        double yz[NS];
+        static_for<0, N1D>([&](auto k2_) {
+          static_for<0, N1D>([&](auto k1_) {
+            constexpr int k1 = k1_, k2 = k2_;
+            if constexpr (K::pair_ok(k1, k2))
+              yz[K::pair(k1, k2)] = f1[k1] * f2[k2];
+          });
+        });
+        static_for<0, NF>([&](auto r_) {
+          constexpr typename K::Dig g = K::dig(r_);
+          acc[r_] += f0[g.k0] * yz[K::pair(g.k1, g.k2)];
+        });
+      }
+    // sum over the subsets (lanes j, j + n, j + 2 n, ...), then the block into LDS over the tables (dead now)
+    if constexpr (NSUB > 1)
+      static_for<0, NF>([&](auto r_) {
+        double v = acc[r_];
+        for (int q = 1; q < NSUB; ++q)
+          v += __shfl(acc[r_], lane + q * NF);
+        acc[r_] = v;
+      });
+    PDH_WAVE_SYNC();
+    if (lane < NF)
+      static_for<0, NF>([&](auto r_) { Da[r_ * NF + lane] = acc[r_]; });
+    PDH_WAVE_SYNC();
+  }
+
+  // ================= B2: the rows ===================================================================================
+  {
+    const double *Dblk = Da;
+    const int m0 = L / NF;
+    const int first_int = nsfb > 0 ? 1 : 0; // the boundary run, if any, is run 0
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(P.values + rbase, 0, NF * rlen * 8, 0x00020000);
+    const uint32_t loff = (uint32_t)lane * 8u;
+    for (int p0 = 0; p0 < rlen; p0 += PDH_WAVE)
+      {
+        const int p = p0 + lane;
+        const bool valid = p < rlen;
+        bool own;
+        int c;
+        if constexpr (SHIFTED)
+          { // diagonal-first rows: position 0 is the diagonal entry, then the columns in ascending order without it
+            own = valid && (p == 0 || (p > L && p < L + NF));
+            c = p <= L ? p - 1 : p;
+          }
+        else
+          {
+            own = valid && p >= L && p < L + NF;
+            c = p;
+          }
+        const bool cpl = valid && !own;
+        const int cc = cpl ? c : 0;
+        const int b = cc / NF, j = cc - b * NF;
+        const int run = first_int + (b < m0 ? b : b - 1);
+        const long long r0 = __double_as_longlong(rec[TERMS_HDR + (cpl ? run : 0) * TERMS_ENT]);
+        const int ns = cpl ? (int)(r0 >> 32) : 0;
+        const double *xb = Xa + ((int)(uint32_t)r0 - nsfb) * 3 * FULLS;
+        const int dj = dig[j];
+        const int q0 = (dj & 15) * N1D, q1 = ((dj >> 4) & 15) * N1D + FULLS, q2 = (dj >> 8) * N1D + 2 * FULLS;
+        double acc[NF];
+        for (int r = 0; r < NF; ++r)
+          acc[r] = 0.0;
+        for (int st = 0; __any(st < ns); ++st)
+          {
+            if (st < ns)
+              {
+                double f0[N1D], f1[N1D], f2[N1D];
+                for (int k = 0; k < N1D; ++k)
+                  f0[k] = xb[q0 + k], f1[k] = xb[q1 + k], f2[k] = xb[q2 + k];
+                double yz[NS];
+                static_for<0, N1D>([&](auto k2_) {
+                  static_for<0, N1D>([&](auto k1_) {
+                    constexpr int k1 = k1_, k2 = k2_;
+                    if constexpr (K::pair_ok(k1, k2))
+                      yz[K::pair(k1, k2)] = f1[k1] * f2[k2];
+                  });
+                });
+                static_for<0, NF>([&](auto r_) {
+                  constexpr typename K::Dig g = K::dig(r_);
+                  acc[r_] += f0[g.k0] * yz[K::pair(g.k1, g.k2)];
+                });
+              }
+            xb += 3 * FULLS;
+          }
+        if (__any(own))
+          if (own)
+            static_for<0, NF>([&](auto r_) {
+              constexpr int R = r_;
+              int col;
+              if constexpr (SHIFTED)
+                col = p == 0 ? R : (R >= p - L ? p - 1 - L : p - L);
+              else
+                col = p - L;
+              acc[R] = Dblk[R * NF + col];
+            });
+        if (valid)
+          {
+            uint32_t rowrun = (uint32_t)p0 * 8u;
+            static_for<0, NF>([&](auto r_) {
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, acc[r_]), vrs, (int)loff, (int)rowrun, 0);
+              rowrun += (uint32_t)rlen * 8u;
+            });
+          }
+      }
+  }
+}
+} // namespace pdht

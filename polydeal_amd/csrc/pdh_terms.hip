@@ -1,0 +1,62 @@
+// pdh_terms.hip — instantiations and launcher of the term kernel (pdh_terms.h): 3-D FE_DGQ(1,2), FE_AggloDGP(1..3).
+#include <cstdlib>
+#include "pdh_terms.h"
+
+namespace
+{
+template <class F>
+bool for_kind(int n1d, int basis, F &&f)
+{
+  using std::integral_constant;
+  if (n1d == 4 && basis == 1)
+    f(integral_constant<int, 4>{}, integral_constant<int, 1>{});
+  else if (n1d == 3 && basis == 0)
+    f(integral_constant<int, 3>{}, integral_constant<int, 0>{});
+  else if (n1d == 3 && basis == 1)
+    f(integral_constant<int, 3>{}, integral_constant<int, 1>{});
+  else if (n1d == 2 && basis == 0)
+    f(integral_constant<int, 2>{}, integral_constant<int, 0>{});
+  else if (n1d == 2 && basis == 1)
+    f(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+  else
+    return false;
+  return true;
+}
+} // namespace
+
+// 1 if the term kernel is instantiated for this element
+extern "C" int pdh_terms_has_kind(int n1d, int basis)
+{
+  return for_kind(n1d, basis, [](auto, auto) {}) ? 1 : 0;
+}
+
+// dynamic LDS of a workgroup for the maxima of a resident problem, bytes (0: no such kind)
+extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell)
+{
+  int bytes = 0;
+  for_kind(n1d, basis, [&](auto n_, auto b_) {
+    bytes = 8 * pdht::terms_lds_doubles<decltype(n_)::value, decltype(b_)::value>(maxruns, maxsf, maxsi, maxcell);
+  });
+  return bytes;
+}
+
+extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int count, hipStream_t stream)
+{
+  if (count <= 0)
+    return hipSuccess;
+  const int full = P->n1d * P->n1d * P->n1d;
+  const int basis = P->n == full ? 0 : 1;
+  hipError_t rc = hipErrorInvalidValue;
+  for_kind(P->n1d, basis, [&](auto n_, auto b_) {
+    constexpr int N = decltype(n_)::value, B = decltype(b_)::value;
+    if (P->n != pdht::Kind<N, B>::NF)
+      return;
+    const size_t lds = (size_t)T->lds_bytes;
+    if (P->diag_first)
+      hipLaunchKernelGGL((pdht::k_terms<N, B, true>), dim3((unsigned)count), dim3(PDH_WAVE), lds, stream, *P, *T, count);
+    else
+      hipLaunchKernelGGL((pdht::k_terms<N, B, false>), dim3((unsigned)count), dim3(PDH_WAVE), lds, stream, *P, *T, count);
+    rc = hipGetLastError();
+  });
+  return rc;
+}
