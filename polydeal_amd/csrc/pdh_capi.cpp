@@ -1467,29 +1467,24 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
     std::memcpy(&d, &v, sizeof(d));
     return d;
   };
-  std::vector<int64_t> sf_first((size_t)K.n_owned + 1, 0);
-  for (int sl = 0; sl < K.n_owned; ++sl)
-    {
-      int64_t n = 0;
-      for (size_t t : order[sl])
-        n += K.run_cnt[t] / gsz;
-      sf_first[sl + 1] = sf_first[sl] + n;
-    }
-  T.sf_pt.resize((size_t)sf_first[K.n_owned]);
-  T.sf_info.resize((size_t)sf_first[K.n_owned]);
+  // the sub-faces of a polytope stand at a fixed stride (maxsf): the kernel requests them together with the record
+  T.maxsf = std::max(T.maxsf, 1);
+  T.sf_pt.assign((size_t)K.n_owned * T.maxsf, 0);
+  T.sf_info.assign((size_t)K.n_owned * T.maxsf, 0);
   T.meta.assign((size_t)K.n_owned * REC, 0.0);
   std::vector<char> bad((size_t)K.n_owned, 0);
   host_parallel_for((size_t)K.n_owned, [&](size_t sl) {
     double *rec = T.meta.data() + sl * REC;
     const int a = K.own_agg[sl];
     const auto &idx = order[sl];
-    int64_t at = sf_first[sl];
+    int64_t at = (int64_t)sl * T.maxsf;
+    const int64_t at0 = at;
     int nsfb = 0, e = 0;
     for (size_t t : idx)
       {
         const int ns = (int)(K.run_cnt[t] / gsz), nb = K.run_nbr[t];
         double *en = rec + HDR + e * ENT;
-        en[0] = as_d((long long)(uint32_t)(at - sf_first[sl]) | ((long long)ns << 32));
+        en[0] = as_d((long long)(uint32_t)(at - at0) | ((long long)ns << 32));
         en[1] = as_d((long long)K.run_blk[t]);
         en[2] = K.run_sig[t];
         for (int c = 0; c < 3; ++c)
@@ -1527,7 +1522,7 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
     rec[8] = as_d(K.row_len[sl]);
     rec[9] = as_d(K.diag_L[sl]);
     rec[10] = as_d(K.vq_ptr[sl]);
-    rec[11] = as_d((long long)sf_first[sl] | ((long long)(sf_first[sl + 1] - sf_first[sl]) << 40));
+    rec[11] = as_d((long long)(at - at0));
   });
   for (char c : bad)
     if (c)
@@ -1945,6 +1940,17 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
               T.maxruns = TH.maxruns, T.maxsf = TH.maxsf, T.maxsi = TH.maxsi, T.maxcell = TH.maxcell;
               T.vq_tensor_n = vq_n_terms, T.fq_tensor_n = RH.fq_tensor_n;
               T.lds_bytes = TH.lds_bytes;
+              {
+                void *ds = nullptr;
+                const size_t nb = (size_t)std::max(K.n_owned, 1) * 16 * sizeof(long long);
+                T.stamps = nullptr;
+                if (hipMalloc(&ds, nb) == hipSuccess)
+                  {
+                    ctx->allocs.push_back(ds);
+                    (void)hipMemset(ds, 0, nb);
+                    T.stamps = static_cast<long long *>(ds);
+                  }
+              }
               ctx->terms_ok = true;
               ctx->rows_auto = true;
               lap("term kernel: tables + upload");
@@ -2211,11 +2217,12 @@ extern "C" int pdh_set_stream(pdh_ctx *ctx, void *stream)
 // Diagnostic (builds with -DPDHR_STAMP only): s_memtime stamps of the row kernel's phase boundaries and in-phase sums, [n_owned][16].
 extern "C" int pdh_debug_rows_stamps(pdh_ctx *ctx, long long *out)
 {
-  if (!ctx || !ctx->has_problem || !ctx->rows_ok || !ctx->rows.stamps || !out)
+  const long long *src = !ctx || !ctx->has_problem ? nullptr : (ctx->terms_ok ? ctx->terms.stamps : (ctx->rows_ok ? ctx->rows.stamps : nullptr));
+  if (!src || !out)
     return fail(ctx, PDH_ESTATE, "no row-kernel problem resident");
   PDH_HIP(ctx, hipSetDevice(ctx->device));
   PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  PDH_HIP(ctx, hipMemcpy(out, ctx->rows.stamps, (size_t)ctx->n_owned * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  PDH_HIP(ctx, hipMemcpy(out, src, (size_t)ctx->n_owned * 16 * sizeof(long long), hipMemcpyDeviceToHost));
   return PDH_OK;
 }
 

@@ -31,6 +31,19 @@
 #include "pdh_kernels.h"
 #include "pdh_terms_tables.h"
 
+#ifdef PDHT_STAMP
+#define PDHT_MARK(k)                                                                                                  \
+  do                                                                                                                  \
+    {                                                                                                                 \
+      const long long tm_ = (long long)__builtin_readcyclecounter();                                                  \
+      if (lane == 0 && T.stamps)                                                                                      \
+        T.stamps[(int64_t)slot * 16 + (k)] = tm_;                                                                      \
+    }                                                                                                                 \
+  while (0)
+#else
+#define PDHT_MARK(k)
+#endif
+
 namespace pdht
 {
 using pdh::static_for;
@@ -84,7 +97,8 @@ __host__ __device__ constexpr int terms_lds_doubles(int maxruns, int maxsf, int 
   return terms_rec_doubles(maxruns) + dg + xa + da + (da & 1);
 }
 
-template <int N1D, int BASIS, bool SHIFTED>
+// PMAX: most points per direction of a rule the instantiation takes (4 or 8): the point data of a lane task sit in registers
+template <int N1D, int BASIS, bool SHIFTED, int PMAX>
 __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const PdhTerms T, const int n_owned)
 {
   using K = Kind<N1D, BASIS>;
@@ -94,45 +108,63 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
   const int slot = blockIdx.x;
   if (slot >= n_owned)
     return;
+  PDHT_MARK(0);
   const int REC = TERMS_HDR + T.maxruns * TERMS_ENT;
   double *rec = lds;
   int *dig = reinterpret_cast<int *>(lds + terms_rec_doubles(T.maxruns));
   double *Xa = lds + terms_rec_doubles(T.maxruns) + ((NF + 1) / 2 + ((NF + 1) / 2 & 1));
   double *Da = Xa + (T.maxsi * 3 * FULLS + ((T.maxsi * 3 * FULLS) & 1));
   auto sel3 = [](int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); };
-  auto uni = [](double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-  };
-  {
-    const double *g = T.meta + (int64_t)slot * REC;
-    for (int k = lane; k < REC; k += PDH_WAVE)
-      rec[k] = g[k];
-    if (lane < NF)
-      {
-        int k0 = 0, k1 = 0, k2 = 0, cnt = 0;
-        for (int iz = 0; iz < N1D; ++iz)
-          for (int iy = 0; iy < (BASIS == 0 ? N1D : N1D - iz); ++iy)
-            for (int ix = 0; ix < (BASIS == 0 ? N1D : N1D - iy - iz); ++ix)
-              {
-                if (cnt == lane)
-                  k0 = ix, k1 = iy, k2 = iz;
-                ++cnt;
-              }
-        dig[lane] = k0 | (k1 << 4) | (k2 << 8);
-      }
-  }
-  PDH_WAVE_SYNC();
-  const long long h0 = __double_as_longlong(uni(rec[0])), h11 = __double_as_longlong(uni(rec[11]));
+  // ---- level 1 of the loads: header (uniform address: scalar loads), run entries (-> LDS), sub-face descriptors of the first
+  // round of lane tasks of either kind.  The descriptors of a polytope stand at a fixed stride (maxsf per polytope), so nothing
+  // here waits for anything else; the point data (level 2) need the descriptors only.
+  const double *g = T.meta + (int64_t)slot * REC;
+  const long long h0 = __double_as_longlong(g[0]);
   const int ncell = (int)((h0 >> 16) & 0xffff), nsfb = (int)(h0 >> 32);
-  const int64_t sf_base = h11 & ((1ll << 40) - 1);
-  const int nsf = (int)(h11 >> 40);
-  const double lo0 = uni(rec[1]), lo1 = uni(rec[2]), lo2 = uni(rec[3]);
-  const double ih0 = uni(rec[4]), ih1 = uni(rec[5]), ih2 = uni(rec[6]);
-  const int64_t rbase = __double_as_longlong(uni(rec[7]));
-  const int rlen = (int)__double_as_longlong(uni(rec[8]));
-  const int L = (int)__double_as_longlong(uni(rec[9]));
-  const int64_t vq_b = __double_as_longlong(uni(rec[10]));
+  const int nsf = (int)__double_as_longlong(g[11]);
+  const double lo0 = g[1], lo1 = g[2], lo2 = g[3];
+  const double ih0 = g[4], ih1 = g[5], ih2 = g[6];
+  const int64_t rbase = __double_as_longlong(g[7]);
+  const int rlen = (int)__double_as_longlong(g[8]);
+  const int L = (int)__double_as_longlong(g[9]);
+  const int64_t vq_b = __double_as_longlong(g[10]);
   const int fn = T.fq_tensor_n, tn = T.vq_tensor_n;
+  const int64_t sfb = (int64_t)slot * T.maxsf;
+  auto desc = [&](int sf, int &info, int64_t &pb) { // (entries behind a polytope's sub-faces are zero: harmless to load)
+    const int64_t at = sfb + (sf < T.maxsf ? sf : 0);
+    info = T.sf_info[at];
+    pb = T.sf_pt[at];
+  };
+  int infoT, infoN;
+  int64_t pbT, pbN;
+  desc(lane >> 1, infoT, pbT);
+  desc(lane, infoN, pbN);
+  for (int k0 = 0; k0 < T.maxruns * TERMS_ENT; k0 += 4 * PDH_WAVE)
+    { // (four loads in flight per lane: a rolled copy loop would wait for every single one)
+      double rv[4];
+      static_for<0, 4>([&](auto i_) {
+        const int k = k0 + lane + PDH_WAVE * i_;
+        rv[i_] = k < T.maxruns * TERMS_ENT ? g[TERMS_HDR + k] : 0.0;
+      });
+      static_for<0, 4>([&](auto i_) {
+        const int k = k0 + lane + PDH_WAVE * i_;
+        if (k < T.maxruns * TERMS_ENT)
+          rec[TERMS_HDR + k] = rv[i_];
+      });
+    }
+  if (lane < NF)
+    {
+      int k0 = 0, k1 = 0, k2 = 0, cnt = 0;
+      for (int iz = 0; iz < N1D; ++iz)
+        for (int iy = 0; iy < (BASIS == 0 ? N1D : N1D - iz); ++iy)
+          for (int ix = 0; ix < (BASIS == 0 ? N1D : N1D - iy - iz); ++ix)
+            {
+              if (cnt == lane)
+                k0 = ix, k1 = iy, k2 = iz;
+              ++cnt;
+            }
+      dig[lane] = k0 | (k1 << 4) | (k2 << 8);
+    }
   double *Ca = Da + nsf * 3 * SYMS; // [cell][direction][M | K] behind the sub-faces' tables
   // 1-D basis in the centred variable of a box (pdh_basis.h: monomial coefficients, uniform -> scalar operands)
   auto basis = [&](double t, double *b) {
@@ -160,149 +192,195 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
   // ================= A: the small matrices =========================================================================
   // (sub-face, tangential direction): D_d (own x own, own-side weights) and, towards a neighbour, X_d (own x neighbour, JxW of
   // side 1).  The rule of a sub-face is a_alpha b_beta: direction 0 takes w_(alpha,0), direction 1 takes w_(0,beta) / w_(0,0)
-  for (int t0 = 0; t0 < 2 * nsf; t0 += PDH_WAVE)
+  struct TPts
+  {
+    double x[PMAX], ws[PMAX], wc[PMAX];
+  };
+  auto tang_load = [&](int info, int64_t pb, int dir) { // all loads of a task at once (fn <= PMAX, checked by the host)
+    TPts r;
+    const int c = (info >> 8) & 3;
+    const bool fast_j = ((info >> 11) & 1) != 0;
+    const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
+    const int64_t stp = ((dir == 1) == fast_j) ? 1 : fn;
+    static_for<0, PMAX>([&](auto i_) {
+      constexpr int al = i_;
+      const int64_t q = al < fn ? pb + al * stp : pb;
+      r.x[al] = P.ap_x[(int64_t)ax * P.ap_stride + q];
+      r.ws[al] = P.ap_wself[q];
+      r.wc[al] = P.ap_wcross[q]; // (zero on the boundary)
+    });
+    return r;
+  };
+  auto tang_compute = [&](const TPts &r, int sf, int dir, int info) {
+    const int run = info & 0xff, c = (info >> 8) & 3;
+    const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
+    const double *re = rec + TERMS_HDR + run * TERMS_ENT;
+    const bool interior = (int)__double_as_longlong(re[1]) >= 0;
+    const double lo_d = sel3(ax, lo0, lo1, lo2), ih_d = sel3(ax, ih0, ih1, ih2);
+    const double loq = re[3 + ax], ihq = re[6 + ax];
+    const double sS = dir ? 1.0 / r.ws[0] : 1.0, sC = (dir && interior) ? 1.0 / r.wc[0] : 1.0;
+    double Dm[NSYM], Xm[FULL];
+    for (int i = 0; i < NSYM; ++i)
+      Dm[i] = 0.0;
+    for (int i = 0; i < FULL; ++i)
+      Xm[i] = 0.0;
+    static_for<0, PMAX>([&](auto i_) {
+      constexpr int al = i_;
+      if (al < fn)
+        {
+          double bp[N1D], bq[N1D];
+          basis((r.x[al] - lo_d) * ih_d - 0.5, bp);
+          basis((r.x[al] - loq) * ihq - 0.5, bq);
+          const double wS = r.ws[al] * sS, wC = r.wc[al] * sC;
+          static_for<0, N1D>([&](auto k_) {
+            constexpr int k = k_;
+            const double ws = wS * bp[k], wc = wC * bp[k];
+            static_for<k, N1D>([&](auto l_) { Dm[K::sym(k, l_)] += ws * bp[l_]; });
+            static_for<0, N1D>([&](auto l_) { Xm[l_ * N1D + k] += wc * bq[l_]; });
+          });
+        }
+    });
+    double *dd = Da + (sf * 3 + ax) * SYMS;
+    for (int i = 0; i < NSYM; ++i)
+      dd[i] = Dm[i];
+    if (interior)
+      {
+        double *xd = Xa + ((sf - nsfb) * 3 + ax) * FULLS;
+        for (int i = 0; i < FULL; ++i)
+          xd[i] = Xm[i];
+      }
+  };
+  // (sub-face, normal direction): D_c and X_c at the plane
+  auto norm_compute = [&](double zeta, int sf, int info) {
+    const int run = info & 0xff, c = (info >> 8) & 3;
+    const double sg = ((info >> 10) & 1) ? 1.0 : -1.0;
+    const double *re = rec + TERMS_HDR + run * TERMS_ENT;
+    const bool interior = (int)__double_as_longlong(re[1]) >= 0;
+    const double sig = re[2];
+    const double lo_c = sel3(c, lo0, lo1, lo2), ih_c = sel3(c, ih0, ih1, ih2);
+    const double loq = re[3 + c], ihq = re[6 + c];
+    double bp[N1D], dp[N1D], bq[N1D], dq[N1D];
+    basis_d((zeta - lo_c) * ih_c - 0.5, bp, dp);
+    basis_d((zeta - loq) * ihq - 0.5, bq, dq);
+    double *dd = Da + (sf * 3 + c) * SYMS;
+    double *xd = Xa + ((sf - nsfb) * 3 + c) * FULLS;
+    const double hs = 0.5 * sg * ih_c, hq = 0.5 * sg * ihq;
+    static_for<0, N1D>([&](auto k_) {
+      constexpr int k = k_;
+      static_for<k, N1D>([&](auto l_) {
+        constexpr int l = l_;
+        dd[K::sym(k, l)] = sig * bp[k] * bp[l] - hs * (dp[k] * bp[l] + bp[k] * dp[l]);
+      });
+      if (interior)
+        static_for<0, N1D>([&](auto l_) {
+          constexpr int l = l_;
+          xd[l * N1D + k] = (hs * dp[k] - sig * bp[k]) * bq[l] - hq * bp[k] * dq[l];
+        });
+    });
+  };
+  // (cell, direction): M_d and K_d.  The rule of a cell is a_i b_j c_k: direction 0 takes w_(i,0,0), the others w / w_000
+  struct CPts
+  {
+    double x[PMAX], w[PMAX];
+  };
+  auto cell_load = [&](int ct) {
+    CPts r;
+    const int cell = ct / 3, d = ct - 3 * cell;
+    const int64_t base = vq_b + (int64_t)cell * (tn * tn * tn);
+    const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
+    static_for<0, PMAX>([&](auto i_) {
+      constexpr int i = i_;
+      const int64_t q = i < tn ? base + i * step : base;
+      r.x[i] = P.vq_x[(int64_t)d * P.vq_stride + q];
+      r.w[i] = P.vq_w[q];
+    });
+    return r;
+  };
+  auto cell_compute = [&](const CPts &r, int ct) {
+    const int cell = ct / 3, d = ct - 3 * cell;
+    const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
+    const double sc = d == 0 ? 1.0 : 1.0 / r.w[0];
+    double Mm[NSYM], Km[NSYM];
+    for (int i = 0; i < NSYM; ++i)
+      Mm[i] = Km[i] = 0.0;
+    static_for<0, PMAX>([&](auto i_) {
+      constexpr int i = i_;
+      if (i < tn)
+        {
+          double bp[N1D], dp[N1D];
+          basis_d((r.x[i] - lo_d) * ih_d - 0.5, bp, dp);
+          const double w = r.w[i] * sc;
+          static_for<0, N1D>([&](auto k_) {
+            constexpr int k = k_;
+            const double wb = w * bp[k], wd = w * (dp[k] * ih_d);
+            static_for<k, N1D>([&](auto l_) {
+              Mm[K::sym(k, l_)] += wb * bp[l_];
+              Km[K::sym(k, l_)] += wd * (dp[l_] * ih_d);
+            });
+          });
+        }
+    });
+    if (d == 0 && P.reaction_c != 0.0) // c phi_i phi_j rides on the first term of the cell
+      for (int i = 0; i < NSYM; ++i)
+        Km[i] += P.reaction_c * Mm[i];
+    double *cd = Ca + (cell * 3 + d) * 2 * SYMS;
+    for (int i = 0; i < NSYM; ++i)
+      {
+        cd[i] = Mm[i];
+        cd[SYMS + i] = Km[i];
+      }
+  };
+  PDHT_MARK(1);
+  // ---- level 2: the point data of the first round of BOTH kinds of task are requested before anything is computed
+  const int ntask2 = nsf + 3 * ncell; // second kind: normal-direction tasks, then cell tasks
+  TPts tp0 = tang_load(infoT, pbT, lane & 1);
+  double zeta0 = 0.0;
+  CPts cp0;
+  for (int i = 0; i < PMAX; ++i)
+    cp0.x[i] = cp0.w[i] = 0.0;
+  if (lane < nsf)
+    zeta0 = P.ap_x[(int64_t)((infoN >> 8) & 3) * P.ap_stride + pbN];
+  else if (lane < ntask2)
+    cp0 = cell_load(lane - nsf);
+  __builtin_amdgcn_sched_barrier(0);
+  PDH_WAVE_SYNC(); // (run entries and digit table are in LDS)
+  if (lane < 2 * nsf)
+    tang_compute(tp0, lane >> 1, lane & 1, infoT);
+  for (int t0 = PDH_WAVE; t0 < 2 * nsf; t0 += PDH_WAVE)
     {
       const int tid = t0 + lane;
       if (tid < 2 * nsf)
         {
-          const int sf = tid >> 1, dir = tid & 1;
-          const int info = T.sf_info[sf_base + sf];
-          const int64_t pb = T.sf_pt[sf_base + sf];
-          const int run = info & 0xff, c = (info >> 8) & 3;
-          const bool fast_j = ((info >> 11) & 1) != 0;
-          const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
-          const int64_t stp = ((dir == 1) == fast_j) ? 1 : fn;
-          const double *re = rec + TERMS_HDR + run * TERMS_ENT;
-          const bool interior = (int)__double_as_longlong(re[1]) >= 0;
-          const double lo_d = sel3(ax, lo0, lo1, lo2), ih_d = sel3(ax, ih0, ih1, ih2);
-          const double loq = re[3 + ax], ihq = re[6 + ax];
-          double xr[8], wsr[8], wcr[8];
-          static_for<0, 8>([&](auto i_) { // all loads of the task first (fn <= 8, checked by the host)
-            constexpr int al = i_;
-            const int64_t q = al < fn ? pb + al * stp : pb;
-            xr[al] = al < fn ? P.ap_x[(int64_t)ax * P.ap_stride + q] : 0.0;
-            wsr[al] = al < fn ? P.ap_wself[q] : 0.0;
-            wcr[al] = (al < fn && interior) ? P.ap_wcross[q] : 0.0;
-          });
-          const double sS = dir ? 1.0 / wsr[0] : 1.0, sC = (dir && interior) ? 1.0 / wcr[0] : 1.0;
-          double Dm[NSYM], Xm[FULL];
-          for (int i = 0; i < NSYM; ++i)
-            Dm[i] = 0.0;
-          for (int i = 0; i < FULL; ++i)
-            Xm[i] = 0.0;
-          static_for<0, 8>([&](auto i_) {
-            constexpr int al = i_;
-            if (al < fn)
-              {
-                double bp[N1D], bq[N1D];
-                basis((xr[al] - lo_d) * ih_d - 0.5, bp);
-                basis((xr[al] - loq) * ihq - 0.5, bq);
-                const double wS = wsr[al] * sS, wC = wcr[al] * sC;
-                static_for<0, N1D>([&](auto k_) {
-                  constexpr int k = k_;
-                  const double ws = wS * bp[k], wc = wC * bp[k];
-                  static_for<k, N1D>([&](auto l_) { Dm[K::sym(k, l_)] += ws * bp[l_]; });
-                  static_for<0, N1D>([&](auto l_) { Xm[l_ * N1D + k] += wc * bq[l_]; });
-                });
-              }
-          });
-          double *dd = Da + (sf * 3 + ax) * SYMS;
-          for (int i = 0; i < NSYM; ++i)
-            dd[i] = Dm[i];
-          if (interior)
-            {
-              double *xd = Xa + ((sf - nsfb) * 3 + ax) * FULLS;
-              for (int i = 0; i < FULL; ++i)
-                xd[i] = Xm[i];
-            }
+          int info;
+          int64_t pb;
+          desc(tid >> 1, info, pb);
+          const TPts tp = tang_load(info, pb, tid & 1);
+          tang_compute(tp, tid >> 1, tid & 1, info);
         }
     }
-  // (sub-face, normal direction) and (cell, direction)
-  {
-    const int ntask = nsf + 3 * ncell;
-    for (int t0 = 0; t0 < ntask; t0 += PDH_WAVE)
-      {
-        const int tid = t0 + lane;
-        if (tid < nsf)
-          {
-            const int sf = tid;
-            const int info = T.sf_info[sf_base + sf];
-            const int64_t pb = T.sf_pt[sf_base + sf];
-            const int run = info & 0xff, c = (info >> 8) & 3;
-            const double sg = ((info >> 10) & 1) ? 1.0 : -1.0;
-            const double *re = rec + TERMS_HDR + run * TERMS_ENT;
-            const bool interior = (int)__double_as_longlong(re[1]) >= 0;
-            const double sig = re[2];
-            const double lo_c = sel3(c, lo0, lo1, lo2), ih_c = sel3(c, ih0, ih1, ih2);
-            const double loq = re[3 + c], ihq = re[6 + c];
-            const double zeta = P.ap_x[(int64_t)c * P.ap_stride + pb];
-            double bp[N1D], dp[N1D], bq[N1D], dq[N1D];
-            basis_d((zeta - lo_c) * ih_c - 0.5, bp, dp);
-            basis_d((zeta - loq) * ihq - 0.5, bq, dq);
-            double *dd = Da + (sf * 3 + c) * SYMS;
-            double *xd = Xa + ((sf - nsfb) * 3 + c) * FULLS;
-            const double hs = 0.5 * sg * ih_c, hq = 0.5 * sg * ihq;
-            static_for<0, N1D>([&](auto k_) {
-              constexpr int k = k_;
-              static_for<k, N1D>([&](auto l_) {
-                constexpr int l = l_;
-                dd[K::sym(k, l)] = sig * bp[k] * bp[l] - hs * (dp[k] * bp[l] + bp[k] * dp[l]);
-              });
-              if (interior)
-                static_for<0, N1D>([&](auto l_) {
-                  constexpr int l = l_;
-                  xd[l * N1D + k] = (hs * dp[k] - sig * bp[k]) * bq[l] - hq * bp[k] * dq[l];
-                });
-            });
-          }
-        else if (tid < ntask)
-          {
-            const int ct = tid - nsf;
-            const int cell = ct / 3, d = ct - 3 * cell;
-            const int m3 = tn * tn * tn;
-            const int64_t base = vq_b + (int64_t)cell * m3;
-            const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
-            const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
-            double xr[8], wr[8];
-            static_for<0, 8>([&](auto i_) {
-              constexpr int i = i_;
-              xr[i] = i < tn ? P.vq_x[(int64_t)d * P.vq_stride + base + i * step] : 0.0;
-              wr[i] = i < tn ? P.vq_w[base + i * step] : 0.0;
-            });
-            const double sc = d == 0 ? 1.0 : 1.0 / wr[0];
-            double Mm[NSYM], Km[NSYM];
-            for (int i = 0; i < NSYM; ++i)
-              Mm[i] = Km[i] = 0.0;
-            static_for<0, 8>([&](auto i_) {
-              constexpr int i = i_;
-              if (i < tn)
-                {
-                  double bp[N1D], dp[N1D];
-                  basis_d((xr[i] - lo_d) * ih_d - 0.5, bp, dp);
-                  const double w = wr[i] * sc;
-                  static_for<0, N1D>([&](auto k_) {
-                    constexpr int k = k_;
-                    const double wb = w * bp[k], wd = w * (dp[k] * ih_d);
-                    static_for<k, N1D>([&](auto l_) {
-                      Mm[K::sym(k, l_)] += wb * bp[l_];
-                      Km[K::sym(k, l_)] += wd * (dp[l_] * ih_d);
-                    });
-                  });
-                }
-            });
-            if (d == 0 && P.reaction_c != 0.0) // c phi_i phi_j rides on the first term of the cell
-              for (int i = 0; i < NSYM; ++i)
-                Km[i] += P.reaction_c * Mm[i];
-            double *cd = Ca + (cell * 3 + d) * 2 * SYMS;
-            for (int i = 0; i < NSYM; ++i)
-              {
-                cd[i] = Mm[i];
-                cd[SYMS + i] = Km[i];
-              }
-          }
-      }
-  }
+  PDHT_MARK(2);
+  if (lane < nsf)
+    norm_compute(zeta0, lane, infoN);
+  else if (lane < ntask2)
+    cell_compute(cp0, lane - nsf);
+  for (int t0 = PDH_WAVE; t0 < ntask2; t0 += PDH_WAVE)
+    {
+      const int tid = t0 + lane;
+      if (tid < nsf)
+        {
+          int info;
+          int64_t pb;
+          desc(tid, info, pb);
+          norm_compute(P.ap_x[(int64_t)((info >> 8) & 3) * P.ap_stride + pb], tid, info);
+        }
+      else if (tid < ntask2)
+        {
+          const CPts cp = cell_load(tid - nsf);
+          cell_compute(cp, tid - nsf);
+        }
+    }
   PDH_WAVE_SYNC();
+  PDHT_MARK(3);
 
   // ================= B1: the diagonal block ========================================================================
   {
@@ -381,6 +459,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
     PDH_WAVE_SYNC();
   }
 
+  PDHT_MARK(4);
   // ================= B2: the rows ===================================================================================
   {
     const double *Dblk = Da;
@@ -459,5 +538,6 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
           }
       }
   }
+  PDHT_MARK(5);
 }
 } // namespace pdht

@@ -52,10 +52,20 @@ extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int c
     if (P->n != pdht::Kind<N, B>::NF)
       return;
     const size_t lds = (size_t)T->lds_bytes;
-    if (P->diag_first)
-      hipLaunchKernelGGL((pdht::k_terms<N, B, true>), dim3((unsigned)count), dim3(PDH_WAVE), lds, stream, *P, *T, count);
+    const bool small = T->fq_tensor_n <= 4 && T->vq_tensor_n <= 4; // (rules of up to 4 / up to 8 points per direction)
+    auto go = [&](auto shifted_, auto pmax_) {
+      hipLaunchKernelGGL((pdht::k_terms<N, B, decltype(shifted_)::value, decltype(pmax_)::value>), dim3((unsigned)count), dim3(PDH_WAVE), lds,
+                         stream, *P, *T, count);
+    };
+    using std::integral_constant;
+    if (P->diag_first && small)
+      go(std::true_type{}, integral_constant<int, 4>{});
+    else if (P->diag_first)
+      go(std::true_type{}, integral_constant<int, 8>{});
+    else if (small)
+      go(std::false_type{}, integral_constant<int, 4>{});
     else
-      hipLaunchKernelGGL((pdht::k_terms<N, B, false>), dim3((unsigned)count), dim3(PDH_WAVE), lds, stream, *P, *T, count);
+      go(std::false_type{}, integral_constant<int, 8>{});
     rc = hipGetLastError();
   });
   return rc;
