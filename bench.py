@@ -85,7 +85,7 @@ def make_variant(pa, name, fe):
     return pa.SipVariant.poisson_example(fe)
 
 
-def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1, grown=False):
+def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1, grown=False, distort=0.0):
     lg = cells.bit_length() - 1
     if stack > 1:  # `stack` unit cubes on top of each other (last direction), lexicographic cells: slab r = rank r's rows
         grid = pa.BackgroundGrid.subdivided_hyper_rectangle(dim, (cells,) * (dim - 1) + (cells * stack,), (0.0,) * dim,
@@ -94,6 +94,8 @@ def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1, grown=False
         grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, lg)
     else:
         grid = pa.BackgroundGrid.subdivided_hyper_cube(dim, cells, 0.0, 1.0)
+    if distort:  # interior vertices moved by up to distort * h (GridTools::distort_random stand-in, exact_solutions_dgp.cc:306)
+        grid.distort(distort, 3)
     ah = pa.AgglomerationHandler(grid)
     if grown:  # METIS stand-in: connected irregular agglomerates of about block^dim cells (staircase faces, many neighbours)
         ah.define_grown_agglomerates(block ** dim, seed=1)
@@ -105,10 +107,11 @@ def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1, grown=False
     return grid, ah, fe
 
 
-def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto", look_for_tensor_rules=True, grown=False):
+def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto", look_for_tensor_rules=True, grown=False,
+            distort=0.0):
     t0 = time.time()
     stack = world if args.scaling == "weak" else 1
-    grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1, stack, grown)
+    grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1, stack, grown, distort)
     t_handler = time.time() - t0
     var = make_variant(pa, args.variant, fe)
     n = fe.n_dofs_per_cell
@@ -135,6 +138,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     ctx.set_overlap(False)
     ctx.set_problem(flat, r0, r1)
     alg_used = ctx.algorithm_in_use()
+    rows_kernel = ctx.rows_kernel_in_use()
     t_setup = time.time() - t0
     setup_parts = {"handler_s": t_handler, "flatten_s": t_flatten, "context_s": t_context,
                    "set_problem_s": t_setup - t_handler - t_flatten - t_context}
@@ -170,8 +174,20 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
         sync_all()
         dt_overlap = time.perf_counter() - t2
         ctx.set_overlap(False)
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
+        # every rank's own wall time and kernel time (HIP events): the first real multi-GPU run must show WHICH rank is slow
+        dev_t = "cpu" if args.rehearse_on_one_gpu else "cuda"
+        mine = torch.tensor([dt / steps * 1e3, kms[0] + kms[1], float(ctx.stats()["n_owned_agg"]), float(ctx.stats()["n_values"])],
+                            dtype=torch.float64, device=dev_t)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows_r = [[float(v) for v in a.cpu()] for a in allr]
+        kmax, kmin = max(r[1] for r in rows_r), min(r[1] for r in rows_r)
+        per_rank = {"wall_ms_per_step": [r[0] for r in rows_r], "kernel_ms": [r[1] for r in rows_r],
+                    "polytopes": [int(r[2]) for r in rows_r], "nnz": [int(r[3]) for r in rows_r],
+                    "kernel_ms_max_over_min": kmax / max(kmin, 1e-9)}
+        t = torch.tensor([dt], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stats = ctx.stats()
@@ -223,7 +239,7 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
             ghost = {"error": repr(exc)}
     return dict(n_dofs=ah.n_dofs, n_agg=n_agg, n=n, dt=dt, kms=kms, nl=nl, stats=stats, work=work, mfma=mfma,
                 t_setup=t_setup, nnz=nnz, checksum=chk, alg=alg_used, dt_overlap=dt_overlap,
-                ghost=ghost, local=world > 1, aux=aux, setup_parts=setup_parts)
+                ghost=ghost, local=world > 1, aux=aux, setup_parts=setup_parts, rows_kernel=rows_kernel, per_rank=per_rank)
 
 
 def time_aux_kernels(torch, ctx, flat, n, stats):
@@ -537,7 +553,8 @@ def main():
         extra = {"fe": ("FE_AggloDGP" if other == "dgp" else "FE_DGQ") + "(%d)" % args.degree,
                  "dofs_per_polytope": r2["n"], "n_dofs": r2["n_dofs"],
                  "value": r2["n_dofs"] / (r2["dt"] / args.steps), "ms_per_step": 1e3 * r2["dt"] / args.steps,
-                 "algorithm": r2["alg"], "kernel_ms": {"diagonal_blocks": r2["kms"][0], "coupling_blocks": r2["kms"][1]}}
+                 "algorithm": r2["alg"], "rows_kernel": r2["rows_kernel"],
+                 "kernel_ms": {"diagonal_blocks": r2["kms"][0], "coupling_blocks": r2["kms"][1]}}
         if r2.get("work"):
             # one launch writes everything (row kernel): SURVEY 8(d) bytes of the pass; two launches: each reads its own face data
             by2 = r2["work"]["bytes_total"] if r2["alg"] == "rows" else sum(r2["work"]["bytes"])
@@ -556,7 +573,7 @@ def main():
                 t5 = r5["dt"] / max(3, args.steps // 2)
                 by5 = r5["work"]["bytes_total"] if r5["alg"] == "rows" else sum(r5["work"]["bytes"])
                 extra["lower_degrees"].append({"fe": ("FE_DGQ" if args.fe == "dgq" else "FE_AggloDGP") + "(%d)" % p_low, "n_dofs": r5["n_dofs"],
-                                               "algorithm": r5["alg"], "ms_per_step": 1e3 * t5, "value": r5["n_dofs"] / t5,
+                                               "algorithm": r5["alg"], "rows_kernel": r5["rows_kernel"], "ms_per_step": 1e3 * t5, "value": r5["n_dofs"] / t5,
                                                "algorithmic_bytes_per_step": by5, "frac_of_hbm_peak": by5 / t5 * 1e-9 / HBM_PEAK_GBS})
             except Exception as exc:  # a secondary measurement must not cost the main line
                 extra["lower_degrees"].append({"degree": p_low, "error": repr(exc)})
@@ -579,8 +596,36 @@ def main():
                 r4 = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, 3, 1, alg="moment", grown=True)
                 extra["irregular_agglomerates"]["moment_form_ms_per_step"] = 1e3 * r4["dt"] / 3
                 extra["irregular_agglomerates"]["moment_form_kernel_ms"] = r4["kms"]
+            extra["irregular_agglomerates"]["rows_kernel"] = r3["rows_kernel"]
+            # the element the reference's callers instantiate on such agglomerates (examples/poisson.cc:413 FE_AggloDGP, :543-566
+            # METIS): term kernel (pdh_terms.h), against the two-kernel direct form it replaced there
+            r6 = run_gpu(pa, torch, dist, args, other, rank, world, local_rank, max(3, args.steps // 2), 1, grown=True)
+            t6 = r6["dt"] / max(3, args.steps // 2)
+            by6 = r6["work"]["bytes_total"] if r6["alg"] == "rows" else sum(r6["work"]["bytes"])
+            line6 = {"fe": ("FE_AggloDGP" if other == "dgp" else "FE_DGQ") + "(%d)" % args.degree, "n_dofs": r6["n_dofs"], "nnz": r6["nnz"],
+                     "algorithm": r6["alg"], "rows_kernel": r6["rows_kernel"], "ms_per_step": 1e3 * t6, "value": r6["n_dofs"] / t6,
+                     "algorithmic_bytes_per_step": by6, "frac_of_hbm_peak": by6 / t6 * 1e-9 / HBM_PEAK_GBS, "checksum": r6["checksum"]}
+            if r6["alg"] == "rows":
+                r7 = run_gpu(pa, torch, dist, args, other, rank, world, local_rank, 3, 1, alg="direct", grown=True)
+                line6["direct_form_ms_per_step"] = 1e3 * r7["dt"] / 3
+            extra["irregular_agglomerates"]["other_element"] = line6
         except Exception as exc:
             extra["irregular_agglomerates"] = {"error": repr(exc)}
+    if not args.no_extra and world == 1 and args.dim == 3:
+        # Non-Cartesian cells (the reference's own defaults: examples/3D_piston.cc:396-400, exact_solutions_dgp.cc:306): the headline
+        # mesh with every interior vertex moved by up to 0.1 h - faces are no longer planar, quadrature rules no longer tensor
+        # rules, so AUTO leaves the row kernels; what it takes instead and what that costs by the same SURVEY 8(d) byte count
+        try:
+            r8 = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, max(3, args.steps // 2), 1, distort=0.1)
+            t8 = r8["dt"] / max(3, args.steps // 2)
+            by8 = r8["work"]["bytes_total"]
+            extra["distorted"] = {
+                "what": "headline mesh, interior vertices moved by up to 0.1 h (seed 3): general hexahedra, non-planar faces",
+                "n_dofs": r8["n_dofs"], "nnz": r8["nnz"], "algorithm": r8["alg"], "rows_kernel": r8["rows_kernel"],
+                "ms_per_step": 1e3 * t8, "value": r8["n_dofs"] / t8, "kernel_ms": r8["kms"],
+                "algorithmic_bytes_per_step": by8, "frac_of_hbm_peak": by8 / t8 * 1e-9 / HBM_PEAK_GBS, "checksum": r8["checksum"]}
+        except Exception as exc:
+            extra["distorted"] = {"error": repr(exc)}
     if world == 1 and args.strong_proxy and not args.no_extra:
         try:
             extra["strong_proxy"] = strong_proxy(pa, args, max(5, args.steps))
@@ -745,11 +790,11 @@ def main():
                                       args.degree + 1, {"poisson": "examples/poisson.cc", "diffusion_reaction": "examples/diffusion_reaction.cc",
                                                         "assemble_dg_matrix": "PolyUtils::assemble_dg_matrix"}[args.variant],
                                       r["n_dofs"], r["nnz"]),
-                       "algorithm": r["alg"],
+                       "algorithm": r["alg"], "rows_kernel": r["rows_kernel"],
                        "parallelism": ("rows(polytopes) split in %d contiguous ranges" % world if args.scaling == "strong" or world == 1
                                        else "rank r owns the rows of slab r (%d polytopes per rank)" % (r["n_agg"] // world))
                                       + ", rank-local descriptions, owner-computes-rows, no data-path collective",
-                       "exchange_variant": r["ghost"]},
+                       "exchange_variant": r["ghost"], "per_rank": r["per_rank"]},
             "roofline": roof,
             "cpu_baseline": cpu,
             "extra": extra,

@@ -199,8 +199,9 @@ public:
           {
             int ft, ds;
             in >> version >> ft >> ds;
-            if (version < 4.0 || version >= 5.0 || ft != 0)
-              throw std::invalid_argument("read_msh: only the ASCII format 4.x is read");
+            // (4.1 only: 4.0 interleaves tags and coordinates in $Nodes and orders the block headers differently)
+            if (version < 4.1 - 1e-9 || version >= 4.2 - 1e-9 || ft != 0)
+              throw std::invalid_argument("read_msh: only the ASCII format 4.1 is read");
           }
         else if (line.rfind("$Nodes", 0) == 0)
           {
@@ -1497,6 +1498,7 @@ inline void partition_into_grown_agglomerates(AgglomerationHandler &ah, int n_su
   for (bool again = remaining > 0; again;)
     {
       again = false;
+      bool assigned = false;
       for (int c = 0; c < nc; ++c)
         if (owner[c] < 0)
           {
@@ -1508,7 +1510,12 @@ inline void partition_into_grown_agglomerates(AgglomerationHandler &ah, int n_su
               }
             if (owner[c] < 0)
               again = true;
+            else
+              assigned = true;
           }
+      if (again && !assigned) // a connected component of the mesh that received no seed: no sweep will ever reach it
+        throw std::invalid_argument("partition_into_grown_agglomerates: the mesh has a connected component without a seed "
+                                    "(more components than regions?)");
     }
   std::vector<std::vector<int>> groups((size_t)np);
   for (int c = 0; c < nc; ++c)

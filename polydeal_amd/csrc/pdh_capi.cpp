@@ -297,7 +297,11 @@ static int upload(pdh_ctx *ctx, const V &h, const typename V::value_type **dptr)
   return upload_n(ctx, h.data(), h.size(), dptr);
 }
 
-extern "C" const char *pdh_version(void) { return "polydeal_hip 0.3 gfx950"; }
+#ifndef PDH_SRC_HASH
+#define PDH_SRC_HASH "unhashed"
+#endif
+// "polydeal_hip <version>+<hash of the library's sources and build flags> gfx950" (Makefile: SRC_HASH)
+extern "C" const char *pdh_version(void) { return "polydeal_hip 0.4+" PDH_SRC_HASH " gfx950"; }
 
 extern "C" const char *pdh_last_error(const pdh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err_noctx.c_str(); }
 
@@ -1865,7 +1869,11 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
                 return fail(ctx, PDH_EDEVICE, "row kernel: out of device memory");
               }
             ctx->allocs.push_back(dq);
-            (void)hipMemset(dq, 0, 64);
+            if (hipMemset(dq, 0, 64) != hipSuccess)
+              {
+                free_problem(ctx);
+                return fail(ctx, PDH_EDEVICE, "row kernel: hipMemset of the work counter failed");
+              }
             R.sched = static_cast<unsigned int *>(dq);
           }
           {

@@ -110,6 +110,12 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
       if (MU && resident > R->scratch_waves)
         resident = R->scratch_waves; // (one row of the moment scratch per workgroup)
       const unsigned grid = (unsigned)(count < resident ? count : resident);
+      // the work counter and the count of leavers start every launch at zero.  The last wave out of a launch resets them, but a
+      // launch that was aborted, or two launches of one context overlapping after a change of stream, would leave them dirty -
+      // and a dirty counter silently skips or repeats polytopes.  Eight bytes, stream-ordered in front of the kernel.
+      if constexpr (!pdhr::RowsKind<N, B>::SMALL)
+        if (hipMemsetAsync(R->sched, 0, 2 * sizeof(unsigned int), stream) != hipSuccess)
+          return;
       hipLaunchKernelGGL((pdhr::k_rows<N, B, G, S, MU>), dim3(grid), dim3(PDH_WAVE), lds + pad, stream, *P, *R, mtab, count);
     };
     using std::true_type;

@@ -48,17 +48,40 @@ def coefficient_vectors(ah, fe):
     return v1, vx, off
 
 
-def run_identities(dim, cells, block, fe, nq, unstructured_rules=None):
+def run_identities(dim, cells, block, fe, nq, unstructured_rules=None, distort=0.0, expect_alg=None):
     """unstructured_rules = name of the algorithm AUTO must then take: the quadrature points are declared unstructured
-    (pdh_problem::vq_tensor_n = fq_tensor_n = -1), which keeps the kinds of the row kernel that need tensor rules out."""
+    (pdh_problem::vq_tensor_n = fq_tensor_n = -1), which keeps the kinds of the row kernel that need tensor rules out.
+    distort > 0: interior vertices moved by up to distort * h - general hexahedra / quadrilaterals, polytopes of different
+    diameters (sigma differs from face to face: the closed forms are then evaluated on the face quadrature itself)."""
     lg = cells.bit_length() - 1
     grid = pa.BackgroundGrid.hyper_cube_refined(dim, 0.0, 1.0, lg)
+    if distort:
+        grid.distort(distort, 3)
     ah = pa.AgglomerationHandler(grid)
     ah.define_block_agglomerates(block)
     ah.initialize_fe_values(nq, nq)
     ah.distribute_agglomerated_dofs(fe)
     var = pa.SipVariant.poisson_example(fe)
-    if unstructured_rules is None:
+    bdry_sigma_area = bdry_sigma_x2 = None
+    if distort:
+        flat = ah.flatten(var, True, True)
+        arr = flat.arrays()
+        bd = arr["face_out"] < 0
+        w, x0q = arr["fq_w"], arr["fq_x"][0] if arr["fq_x"].ndim == 2 else arr["fq_x"][:len(arr["fq_w"])]
+        csw = np.concatenate([[0.0], np.cumsum(w)])
+        csx = np.concatenate([[0.0], np.cumsum(w * x0q * x0q)])
+        fp = arr["fq_ptr"]
+        bdry_sigma_area = float(np.sum(arr["face_sigma"][bd] * (csw[fp[1:]] - csw[fp[:-1]])[bd]))
+        bdry_sigma_x2 = float(np.sum(arr["face_sigma"][bd] * (csx[fp[1:]] - csx[fp[:-1]])[bd]))
+        ctx = pa.Context(0)
+        ctx.set_problem(flat)
+        if expect_alg is not None:
+            assert ctx.algorithm_in_use() == expect_alg, ctx.algorithm_in_use()
+        vals = ctx.assemble()
+        ctx.close()
+        rp, ci = arr["rowptr"].copy(), arr["colind"].copy()
+        del flat, arr
+    elif unstructured_rules is None:
         rp, ci, vals = pa.assemble_dg_matrix(fe, ah, var, diag_first=True)
     else:
         flat = ah.flatten(var, True, True)
@@ -90,6 +113,16 @@ def run_identities(dim, cells, block, fe, nq, unstructured_rules=None):
     assert np.max(np.abs(y1[rows])) <= 1e-12 * scale * n
     q1 = float(v1 @ y1)
     qx = float(vx @ (A @ vx))
+    if distort:  # v = 1: sum over the boundary faces of sigma_F |F|; v = x_0: 1 - 2 + sum_F sigma_F int_F x_0^2
+        # (bound: entries good to 1e-12 of the largest entry of their block, coefficients |v| <= 1 - the quadratic forms are sums
+        # of 9e8 entries that cancel to 1e-4 of their absolute sum, so the result itself carries fewer digits than an entry)
+        tol = 1e-13 * float(np.sum(np.abs(vals)))
+        assert abs(q1 - bdry_sigma_area) <= tol, (q1, bdry_sigma_area, tol)
+        assert abs(qx - (-1.0 + bdry_sigma_x2)) <= tol, (qx, -1.0 + bdry_sigma_x2, tol)
+        sample = np.unique(np.linspace(0, ah.n_dofs - 1, 400).astype(np.int64))
+        S = A[sample][:, sample]
+        assert abs(S - S.T).max() <= 1e-12 * scale
+        return ah.n_dofs, len(vals)
     assert abs(q1 - 2 * dim * sigma) <= 1e-11 * 2 * dim * sigma
     exact_x = -1.0 + sigma * (1.0 + (2 * dim - 2) / 3.0)
     assert abs(qx - exact_x) <= 1e-11 * abs(exact_x)
@@ -282,3 +315,13 @@ def test_bench_strong_scaling_rehearsal_on_one_gpu():
     assert "split in 4 contiguous ranges" in d["config"]["parallelism"]
     assert d["checksum"]["non_finite"] == 0 and d["checksum"]["rel_err"] < 1e-9
     assert d["value"] > 0 and d["roofline"]["kernel"] == "k_rows"
+
+
+def test_config3_distorted_mesh_fullsize():
+    """The headline mesh with every interior vertex moved by up to 0.1 h (general hexahedra, non-planar faces: what the reference's
+    own defaults look like - examples/3D_piston.cc:396-400, test/polydeal/exact_solutions_dgp.cc:306): AUTO leaves the row kernels
+    (moment form for FE_DGQ(3), direct form for FE_AggloDGP(3)); the identities hold on any mesh and see every block."""
+    n_dofs, nnz = run_identities(3, 64, 2, pa.FE_DGQ(3, 3), 4, distort=0.1, expect_alg="moment")
+    assert n_dofs == 2097152 and nnz == 914358272
+    n_dofs, nnz = run_identities(3, 64, 2, pa.FE_AggloDGP(3, 3), 4, distort=0.1, expect_alg="direct")
+    assert n_dofs == 655360 and nnz == 89292800

@@ -145,8 +145,9 @@ def test_cpp_examples_run():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "examples", "minimal_SIP")
-    if not os.path.exists(exe):
-        pytest.skip("examples not built")
+    # (the binaries are git-ignored build products: this is a GPU test, so a box that runs it without them has skipped build() -
+    # that must show as a failure, not as one test fewer)
+    assert os.path.exists(exe), "examples/ not built: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C examples)"
     # examples/minimal_SIP.cc on ITS mesh (meshes/t3.msh = tests/golden/t3.msh, refined 3 times, N = 50 .. 800 agglomerates): the
     # stdout is the reference's test/polydeal/poisson_sanity_check_03.output, up to the round-off sized "Test with 1" values
     out = subprocess.run([exe, os.path.join(root, "tests", "golden", "t3.msh")], capture_output=True, text=True, timeout=300)
@@ -637,6 +638,30 @@ def _values(kw, alg, r0=0, r1=None):
     return v, used
 
 
+def _values_k(kw, alg, r0=0, r1=None, terms=True):
+    """values, algorithm in use, row kernel in use; terms=False keeps the kinds of pdh_rows.h (PDH_TERMS=0, read per set_problem)"""
+    import os
+
+    import polydeal_amd as pa
+
+    old = os.environ.get("PDH_TERMS")
+    os.environ["PDH_TERMS"] = "1" if terms else "0"
+    try:
+        prob = pa.Problem(**kw)
+        ctx = pa.Context(0)
+        ctx.set_algorithm(alg)
+        ctx.set_problem(prob, r0, r1)
+        used, kern = ctx.algorithm_in_use(), ctx.rows_kernel_in_use()
+        v = ctx.assemble()
+        ctx.close()
+    finally:
+        if old is None:
+            del os.environ["PDH_TERMS"]
+        else:
+            os.environ["PDH_TERMS"] = old
+    return v, used, kern
+
+
 MOMENT_CASES = [
     # fe, degree, log2 cells/dir, block, distort, variant, diag_first
     (po.FE_DGQ, 3, 2, 2, 0.0, "poisson", True),
@@ -1066,9 +1091,19 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world, basis, p):
     sc = np.max(np.abs(ref))
     has_general_paths = p == 3  # the kinds of lower degree exist for tensor rules only
     # no claim about the rules (0): the library finds their tensor structure on the points
-    v0, used_0 = _values(kw, "rows")
+    v0, used_0, kern_0 = _values_k(kw, "rows")
     assert used_0 == "rows"
     assert_parity_ah(v0, ref, ah, diag_first, what="rows")
+    if p == 3 and basis == "dgq":
+        assert kern_0 == "pieces"
+    else:
+        # the small elements take the term kernel (pdh_terms.h) while a polytope's tables fit its LDS budget (64 cells with 96
+        # sub-faces do not), else the streamed kinds of pdh_rows.h - which must agree with it to rounding
+        assert kern_0 == ("streamed" if b == 4 else "terms"), kern_0
+        vs, used_s, kern_s = _values_k(kw, "rows", terms=False)
+        assert used_s == "rows" and kern_s == "streamed"
+        assert_parity_ah(vs, ref, ah, diag_first, what="rows (streamed kind)")
+        assert np.max(np.abs(vs - v0)) <= 1e-13 * sc
     # verified claims: bit-identical
     vf, used_f = _values(dict(kw, fq_tensor_n=nq, vq_tensor_n=nq), "rows")
     assert used_f == "rows" and np.array_equal(v0, vf)
@@ -1115,11 +1150,13 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world, basis, p):
 
 def test_row_kernel_falls_back_when_faces_are_not_planar():
     """AUTO must not pick the row kernel on distorted grids (forcing it fails).  A polytopal face that spans two planes of a
-    Cartesian grid is no reason to fall back any more for FE_DGQ(3) (pdh_rows.h: MULTI); the other elements still do."""
+    Cartesian grid is no reason to fall back: FE_DGQ(3) has the MULTI instantiation of pdh_rows.h, the other elements the term
+    kernel (pdh_terms.h)."""
     import polydeal_amd as pa
 
     for mode, fe, expect in (("distorted", po.FE_DGQ(3, 3), "moment"), ("staircase", po.FE_DGQ(3, 3), "rows"),
-                             ("staircase", po.FE_DGQ(3, 2), "mixed"), ("staircase", po.FE_AggloDGP(3, 3), "direct")):
+                             ("staircase", po.FE_DGQ(3, 2), "rows"), ("staircase", po.FE_AggloDGP(3, 3), "rows"),
+                             ("distorted", po.FE_DGQ(3, 2), "mixed"), ("distorted", po.FE_AggloDGP(3, 3), "direct")):
         grid = po.hyper_cube_refined(3, 0.0, 1.0, 2)
         if mode == "distorted":
             grid.distort(1e-9, seed=1)  # even a tiny perturbation: the kernel evaluates ONE plane coordinate per face
@@ -1193,6 +1230,69 @@ def test_row_kernel_staircase_agglomerates(cells, per, vname, diag_first, seed):
         assert u == "rows"
         parts.append(v)
     assert_parity_ah(np.concatenate(parts), ref, ah, diag_first, what="row ranges")
+
+
+@pytest.mark.parametrize("basis,p", [("dgp", 3), ("dgq", 2), ("dgp", 2), ("dgq", 1), ("dgp", 1)])
+@pytest.mark.parametrize("cells,per,vname,diag_first,seed", [(4, 4, "poisson", True, 0), (4, 8, "dr", False, 1), (6, 6, "adm", True, 2),
+                                                             (6, 3, "minsip", True, 3), (8, 8, "poisson", False, 4)])
+def test_term_kernel_staircase_agglomerates(cells, per, vname, diag_first, seed, basis, p):
+    """The element the reference's own callers instantiate on the agglomerates they produce (examples/poisson.cc:413 FE_AggloDGP,
+    :543-566 METIS; here regions grown over the cell graph): neighbours met along several planes, many more than six faces,
+    boundary runs over up to five planes.  AUTO takes the row algorithm through the term kernel (pdh_terms.h) for all five small
+    elements: parity with the oracle per block, both CSR layouts, every caller variant (zeroed boundary: `minsip`), row ranges,
+    agreement with the two-kernel forms to rounding."""
+    from polydeal_amd.partition import row_range
+
+    fe = po.FE_DGQ(3, p) if basis == "dgq" else po.FE_AggloDGP(3, p)
+    grid = po.subdivided_hyper_cube(3, cells, 0.0, 1.0)
+    groups = _grown_agglomerates(grid, per, seed)
+    ah = po.AgglomerationHandler(grid)
+    order = np.random.default_rng(seed).permutation(len(groups))  # polytope index order != master cell order
+    for k in order:
+        ah.define_agglomerate(groups[k])
+    nq = p + 1
+    ah.initialize_fe_values(nq, nq)
+    ah.distribute_agglomerated_dofs(fe)
+    assert max(ah.n_faces) > 6  # more neighbours than a box has
+    var = variant(vname, fe)
+    kw = flatten(ah, var, diag_first=diag_first)
+    ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
+    v0, used, kern = _values_k(kw, "auto")
+    assert used == "rows" and kern == "terms"
+    assert_parity_ah(v0, ref, ah, diag_first, what="term kernel")
+    # without it these meshes take the two-kernel forms (the streamed kinds of pdh_rows.h need one plane per neighbour)
+    vd, used_d, kern_d = _values_k(kw, "auto", terms=False)
+    assert used_d != "rows" and kern_d == "none"
+    assert np.max(np.abs(v0 - vd)) <= 1e-13 * np.max(np.abs(ref))
+    n = fe.n_dofs_per_cell
+    parts = []
+    for r in range(3):
+        rb, re = row_range(ah.n_agglomerates, n, r, 3)
+        v, u, k = _values_k(kw, "rows", rb, re)
+        assert u == "rows" and k == "terms"
+        parts.append(v)
+    assert_parity_ah(np.concatenate(parts), ref, ah, diag_first, what="term kernel, row ranges")
+
+
+@pytest.mark.parametrize("basis,p,nq", [("dgp", 3, 7), ("dgq", 2, 5), ("dgp", 2, 6), ("dgq", 1, 3), ("dgp", 1, 8)])
+def test_term_kernel_rules_of_up_to_eight_points(basis, p, nq):
+    """QGauss(2p+1) and other rules with more points per direction than p + 1 (examples/minimal_SIP.cc:151-157; the tests of the
+    reference): the term kernel's instantiation for up to 8 points per direction, on boxes of different sizes (neighbours with
+    other bounding boxes) and on blocks."""
+    fe = po.FE_DGQ(3, p) if basis == "dgq" else po.FE_AggloDGP(3, p)
+    for b in (0, 2):
+        grid = po.hyper_cube_refined(3, 0.0, 1.0, 2)
+        ah = po.AgglomerationHandler(grid)
+        for g in (po.block_agglomerates(grid, b) if b else _box_groups(grid, 4)):
+            ah.define_agglomerate(g)
+        ah.initialize_fe_values(nq, nq)
+        ah.distribute_agglomerated_dofs(fe)
+        var = po.variant_assemble_dg_matrix()
+        kw = flatten(ah, var)
+        ref = po.assemble_csr(ah, var)[2]
+        v0, used, kern = _values_k(kw, "auto")
+        assert used == "rows" and kern == "terms"
+        assert_parity_ah(v0, ref, ah, what="term kernel, %d points per direction" % nq)
 
 
 def test_row_kernel_staircase_with_large_plane_entries():
@@ -1460,8 +1560,9 @@ def test_t3_mesh_parity_with_the_oracle(n_refine, n_sub, basis, p, vname):
         assert_parity(vals, ref, orp, oci, fe.n_dofs_per_cell)
 
 
+@pytest.mark.parametrize("basis,p", [("dgq", 3), ("dgp", 3), ("dgq", 2)])
 @pytest.mark.parametrize("world", [2, 3])
-def test_row_kernel_staircase_rank_local_descriptions(world):
+def test_row_kernel_staircase_rank_local_descriptions(world, basis, p):
     """Irregular (grown) agglomerates of Cartesian cells from the PRODUCT mirror, partitioned into `world` row ranges, every rank
     with its own rank-local description (pdh_problem.local = 1: own polytopes + ghost neighbours): the MULTI row kernel must
     reproduce the rows of the global assembly (faces cut by the partition are seen from the owned side only), and the global
@@ -1472,8 +1573,8 @@ def test_row_kernel_staircase_rank_local_descriptions(world):
     grid = pa.BackgroundGrid.subdivided_hyper_cube(3, 6, 0.0, 1.0)
     ah = pa.AgglomerationHandler(grid)
     ah.define_grown_agglomerates(6, seed=7)
-    fe = pa.FE_DGQ(3, 3)
-    ah.initialize_fe_values(4, 4)
+    fe = pa.FE_DGQ(3, p) if basis == "dgq" else pa.FE_AggloDGP(3, p)
+    ah.initialize_fe_values(p + 1, p + 1)
     ah.distribute_agglomerated_dofs(fe)
     var = pa.SipVariant.poisson_example(fe)
     n, nA, N = fe.n_dofs_per_cell, ah.n_agglomerates, ah.n_dofs
@@ -1481,6 +1582,7 @@ def test_row_kernel_staircase_rank_local_descriptions(world):
     ctx = pa.Context(0)
     ctx.set_problem(gflat)
     assert ctx.algorithm_in_use() == "rows"
+    assert ctx.rows_kernel_in_use() == ("multi" if (basis, p) == ("dgq", 3) else "terms")
     gvals = ctx.assemble()
     ctx.close()
     # oracle on the same agglomerates
@@ -1489,8 +1591,8 @@ def test_row_kernel_staircase_rank_local_descriptions(world):
     for P in range(nA):
         cells = ah.get_agglomerate(P)
         oah.define_agglomerate([cells[-1]] + cells[:-1])
-    ofe = po.FE_DGQ(3, 3)
-    oah.initialize_fe_values(4, 4)
+    ofe = po.FE_DGQ(3, p) if basis == "dgq" else po.FE_AggloDGP(3, p)
+    oah.initialize_fe_values(p + 1, p + 1)
     oah.distribute_agglomerated_dofs(ofe)
     orp, oci, ref = po.assemble_csr(oah, po.variant_poisson_example(ofe))
     ga = gflat.arrays()

@@ -293,3 +293,53 @@ def test_flatten_on_t3_mesh_matches_oracle(n_refine, n_sub, basis, p, vname):
         assert np.max(np.abs(a - bb)) <= 4e-15 * max(1.0, np.max(np.abs(a))), k
     # the two sides of a straight shared edge carry the same JxW point by point
     assert np.max(np.abs(flat["fq_w"] - flat["fq_w_out"])) <= 1e-15
+
+
+_TWO_QUADS = """$MeshFormat
+%s 0 8
+$EndMeshFormat
+$Nodes
+1 8 1 8
+2 1 0 8
+1
+2
+3
+4
+5
+6
+7
+8
+0 0 0
+1 0 0
+1 1 0
+0 1 0
+3 0 0
+4 0 0
+4 1 0
+3 1 0
+$EndNodes
+$Elements
+1 2 1 2
+2 1 3 2
+1 1 2 3 4
+2 5 6 7 8
+$EndElements
+"""
+
+
+def test_read_msh_takes_format_4_1_only_and_grown_regions_need_a_seed_per_component(tmp_path):
+    """a gmsh 4.0 file has another $Nodes / $Elements layout and must be refused, not misread; and a connected
+    component of the mesh that received no seed must end the pocket-filling loop of the grown agglomerates with an error."""
+    f41, f40 = tmp_path / "two_41.msh", tmp_path / "two_40.msh"
+    f41.write_text(_TWO_QUADS % "4.1")
+    f40.write_text(_TWO_QUADS % "4")
+    with pytest.raises(Exception, match="4.1"):
+        pa.BackgroundGrid.read_msh(str(f40), 0)
+    grid = pa.BackgroundGrid.read_msh(str(f41), 0)
+    assert grid.n_cells == 2
+    ah = pa.AgglomerationHandler(grid)
+    with pytest.raises(Exception, match="component"):
+        ah.define_grown_agglomerates(2, seed=0)  # one region, two components
+    ah2 = pa.AgglomerationHandler(pa.BackgroundGrid.read_msh(str(f41), 1))  # 8 cells, four per component
+    ah2.define_grown_agglomerates(1, seed=0)  # a region per cell: every component has its seeds
+    assert ah2.n_agglomerates == 8

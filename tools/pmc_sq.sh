@@ -15,8 +15,8 @@ for part in "ab":
         print("no csv", part, e); continue
     agg=collections.defaultdict(list)
     for r in rows:
-        agg[(r["Kernel_Name"][:34], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k in sorted(agg):
-        v=agg[k]; print("%-36s %-28s n=%d mean=%.4g"%(k[0],k[1],len(v),sum(v)/len(v)))
+        v=agg[k]; print("%s | %-28s n=%d mean=%.4g"%(k[0].replace("void ","").split("(")[0],k[1],len(v),sum(v)/len(v)))  # full kernel names: the instantiations differ
 PY
 tail -2 $OUT/a.err
