@@ -111,6 +111,69 @@ __device__ __forceinline__ int64_t pdhr_checked(int64_t idx, int64_t n, int code
 #define PDHR_ACC(var)
 #endif
 
+// Eight carries of a shifted piece, read from LDS by lane 0 ALONE straight into the registers that hold the products of rows
+// 8 g .. 8 g + 7 (the other lanes keep theirs): the statement narrows EXEC to lane 0 around eight ds_read_b64 and waits for them
+// itself, so nothing is outstanding that the compiler does not know of.  It SAVES the mask it finds and restores exactly that
+// (round 3 restored the constant -1, i.e. relied on the compiler never placing the statement under a partial mask - true of the
+// code it generated, checked by tools/isa_lint.py rule B, but not something an asm string may assume).  -DPDHR_EXEC_CONST
+// (diagnostic builds only) brings the old form back.
+#if !defined(PDHR_CARRY_ASM) && !defined(PDHR_EXEC_CONST)
+// Default since round 4: plain C++ - `if (lane == 0)` around eight LDS reads.  hipcc turns it into s_and_saveexec / ds_read2_b64 x 4
+// / s_or exec, i.e. the same instructions as the hand-written statement below (fewer: the reads pair up), counts the reads in its
+// own s_waitcnt bookkeeping and owns EXEC; no asm statement of the library changes EXEC any more.  -DPDHR_CARRY_ASM brings the
+// asm form back (A/B, tools/ab_bench.py).
+#define PDHR_CARRY_READ8(V0, V1, V2, V3, V4, V5, V6, V7, CADDR, G)                                                    \
+  do                                                                                                                  \
+    {                                                                                                                 \
+      if (lane == 0)                                                                                                  \
+        {                                                                                                             \
+          const double *cp_ = csrc + 8 * (G);                                                                         \
+          V0 = cp_[0], V1 = cp_[1], V2 = cp_[2], V3 = cp_[3], V4 = cp_[4], V5 = cp_[5], V6 = cp_[6], V7 = cp_[7];     \
+        }                                                                                                             \
+      (void)(CADDR);                                                                                                  \
+    }                                                                                                                 \
+  while (0)
+#elif defined(PDHR_EXEC_CONST)
+#define PDHR_CARRY_READ8(V0, V1, V2, V3, V4, V5, V6, V7, CADDR, G)                                                    \
+  asm volatile("s_mov_b64 exec, 1\n\t"                                                                               \
+               "ds_read_b64 %0, %8 offset:%9\n\t"                                                                    \
+               "ds_read_b64 %1, %8 offset:%10\n\t"                                                                   \
+               "ds_read_b64 %2, %8 offset:%11\n\t"                                                                   \
+               "ds_read_b64 %3, %8 offset:%12\n\t"                                                                   \
+               "ds_read_b64 %4, %8 offset:%13\n\t"                                                                   \
+               "ds_read_b64 %5, %8 offset:%14\n\t"                                                                   \
+               "ds_read_b64 %6, %8 offset:%15\n\t"                                                                   \
+               "ds_read_b64 %7, %8 offset:%16\n\t"                                                                   \
+               "s_mov_b64 exec, -1\n\t"                                                                              \
+               "s_waitcnt lgkmcnt(0)"                                                                                \
+               : "+v"(V0), "+v"(V1), "+v"(V2), "+v"(V3), "+v"(V4), "+v"(V5), "+v"(V6), "+v"(V7)                      \
+               : "v"(CADDR), "n"(64 * (G) + 0), "n"(64 * (G) + 8), "n"(64 * (G) + 16), "n"(64 * (G) + 24),           \
+                 "n"(64 * (G) + 32), "n"(64 * (G) + 40), "n"(64 * (G) + 48), "n"(64 * (G) + 56))
+#else
+#define PDHR_CARRY_READ8(V0, V1, V2, V3, V4, V5, V6, V7, CADDR, G)                                                    \
+  do                                                                                                                  \
+    {                                                                                                                 \
+      unsigned long long exec_saved_;                                                                                 \
+      asm volatile("s_mov_b64 %8, exec\n\t"                                                                          \
+                   "s_mov_b64 exec, 1\n\t"                                                                           \
+                   "ds_read_b64 %0, %9 offset:%10\n\t"                                                               \
+                   "ds_read_b64 %1, %9 offset:%11\n\t"                                                               \
+                   "ds_read_b64 %2, %9 offset:%12\n\t"                                                               \
+                   "ds_read_b64 %3, %9 offset:%13\n\t"                                                               \
+                   "ds_read_b64 %4, %9 offset:%14\n\t"                                                               \
+                   "ds_read_b64 %5, %9 offset:%15\n\t"                                                               \
+                   "ds_read_b64 %6, %9 offset:%16\n\t"                                                               \
+                   "ds_read_b64 %7, %9 offset:%17\n\t"                                                               \
+                   "s_mov_b64 exec, %8\n\t"                                                                          \
+                   "s_waitcnt lgkmcnt(0)"                                                                            \
+                   : "+v"(V0), "+v"(V1), "+v"(V2), "+v"(V3), "+v"(V4), "+v"(V5), "+v"(V6), "+v"(V7), "=&s"(exec_saved_) \
+                   : "v"(CADDR), "n"(64 * (G) + 0), "n"(64 * (G) + 8), "n"(64 * (G) + 16), "n"(64 * (G) + 24),       \
+                     "n"(64 * (G) + 32), "n"(64 * (G) + 40), "n"(64 * (G) + 48), "n"(64 * (G) + 56));                \
+      (void)exec_saved_;                                                                                              \
+    }                                                                                                                 \
+  while (0)
+#endif
+
 namespace pdhr
 {
 using pdh::static_for;
@@ -1508,24 +1571,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               v[r_] = Cl[kc] * sc[u];
             });
             if constexpr (LEFT)
-              {
-                // (one self-contained statement: EXEC is all ones before - uniform code of a one-wave workgroup - and after;
-                // the LDS reads are waited for inside, so nothing is outstanding that the compiler does not know of)
-                asm volatile("s_mov_b64 exec, 1\n\t"
-                             "ds_read_b64 %0, %8 offset:%9\n\t"
-                             "ds_read_b64 %1, %8 offset:%10\n\t"
-                             "ds_read_b64 %2, %8 offset:%11\n\t"
-                             "ds_read_b64 %3, %8 offset:%12\n\t"
-                             "ds_read_b64 %4, %8 offset:%13\n\t"
-                             "ds_read_b64 %5, %8 offset:%14\n\t"
-                             "ds_read_b64 %6, %8 offset:%15\n\t"
-                             "ds_read_b64 %7, %8 offset:%16\n\t"
-                             "s_mov_b64 exec, -1\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-                             : "v"(caddr), "n"(64 * g + 0), "n"(64 * g + 8), "n"(64 * g + 16), "n"(64 * g + 24), "n"(64 * g + 32),
-                               "n"(64 * g + 40), "n"(64 * g + 48), "n"(64 * g + 56));
-              }
+              PDHR_CARRY_READ8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], caddr, g); // (one self-contained statement)
             static_for<0, 8>([&](auto r_) {
 #if PDHR_EXP == 5
               if (P.n < 0)
@@ -2049,6 +2095,68 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
         const unsigned caddr = (unsigned)(uintptr_t)(lds_cchar *)reinterpret_cast<const char *>(csrc);
         double next_carry = 0.0;
         using std::integral_constant;
+#ifdef PDHR_MULTI_FUSED
+        // (diagnostic build only, never shipped: round 3's first MULTI version, which multiplied and stored the rows of a
+        // single-plane neighbour directly - the block kernel's fused path - next to the accumulating path, and faulted on the
+        // device.  Kept so that tools/isa_lint.py can be run on exactly that code: DESIGN.md 4c, "the fused-path fault".)
+        if (te - t == 1)
+          {
+            PDH_WAVE_SYNC();
+            build_S(t);
+            const int c = rl_i(t_axis, t);
+            const int lc = digit_c(jcol, c), vt = digits_t(jcol, c);
+            double Cl[4], sc[16];
+            for (int k = 0; k < 4; ++k)
+              Cl[k] = Cbuf[k * 4 + lc];
+            for (int u = 0; u < 16; ++u)
+              sc[u] = Sbuf[u * 16 + vt];
+            next_carry = left ? last_column(c) : 0.0;
+            if (left)
+              PDH_WAVE_SYNC();
+            auto rows = [&, lane_off](auto c_, auto left_) {
+              constexpr int cc = c_;
+              constexpr bool LEFT = left_;
+              const uint32_t loff = lane_off;
+              uint32_t rowrun = rowp;
+              static_for<0, 8>([&](auto g_) {
+                constexpr int g = g_;
+                double v[8];
+                static_for<0, 8>([&](auto r_) {
+                  constexpr int R = 8 * g + r_;
+                  constexpr int kc = (R >> (2 * cc)) & 3;
+                  constexpr int k0 = R & 3, k1 = (R >> 2) & 3, k2 = (R >> 4) & 3;
+                  constexpr int u = cc == 0 ? (k1 + 4 * k2) : (cc == 1 ? (k0 + 4 * k2) : (k0 + 4 * k1));
+                  v[r_] = Cl[kc] * sc[u];
+                });
+                if constexpr (LEFT)
+                  PDHR_CARRY_READ8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], caddr, g);
+                static_for<0, 8>([&](auto r_) {
+                  row_store(v[r_], loff, rowrun);
+                  rowrun += (uint32_t)rlen * 8u;
+                });
+              });
+            };
+            if (left)
+              {
+                if (c == 0)
+                  rows(integral_constant<int, 0>{}, std::true_type{});
+                else if (c == 1)
+                  rows(integral_constant<int, 1>{}, std::true_type{});
+                else
+                  rows(integral_constant<int, 2>{}, std::true_type{});
+              }
+            else
+              {
+                if (c == 0)
+                  rows(integral_constant<int, 0>{}, std::false_type{});
+                else if (c == 1)
+                  rows(integral_constant<int, 1>{}, std::false_type{});
+                else
+                  rows(integral_constant<int, 2>{}, std::false_type{});
+              }
+          }
+        else
+#endif
         {
           // acc[r] = sum_e C_e[k_c(R), l_c(j)] S_e[u(R), v(j)], in two halves of 32 rows (64 accumulators do not fit the
           // register file next to what lives across this phase).  S_e / C_e of the first three planes of a neighbour stay in
@@ -2106,21 +2214,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_rows(const PdhDev P, const PdhR
               static_for<0, 4>([&](auto g_) {
                 constexpr int g = 4 * half + g_;
                 if constexpr (LEFT)
-                  asm volatile("s_mov_b64 exec, 1\n\t"
-                               "ds_read_b64 %0, %8 offset:%9\n\t"
-                               "ds_read_b64 %1, %8 offset:%10\n\t"
-                               "ds_read_b64 %2, %8 offset:%11\n\t"
-                               "ds_read_b64 %3, %8 offset:%12\n\t"
-                               "ds_read_b64 %4, %8 offset:%13\n\t"
-                               "ds_read_b64 %5, %8 offset:%14\n\t"
-                               "ds_read_b64 %6, %8 offset:%15\n\t"
-                               "ds_read_b64 %7, %8 offset:%16\n\t"
-                               "s_mov_b64 exec, -1\n\t"
-                               "s_waitcnt lgkmcnt(0)"
-                               : "+v"(acc[8 * g_ + 0]), "+v"(acc[8 * g_ + 1]), "+v"(acc[8 * g_ + 2]), "+v"(acc[8 * g_ + 3]),
-                                 "+v"(acc[8 * g_ + 4]), "+v"(acc[8 * g_ + 5]), "+v"(acc[8 * g_ + 6]), "+v"(acc[8 * g_ + 7])
-                               : "v"(caddr), "n"(64 * g + 0), "n"(64 * g + 8), "n"(64 * g + 16), "n"(64 * g + 24), "n"(64 * g + 32),
-                                 "n"(64 * g + 40), "n"(64 * g + 48), "n"(64 * g + 56));
+                  PDHR_CARRY_READ8(acc[8 * g_ + 0], acc[8 * g_ + 1], acc[8 * g_ + 2], acc[8 * g_ + 3], acc[8 * g_ + 4], acc[8 * g_ + 5],
+                                   acc[8 * g_ + 6], acc[8 * g_ + 7], caddr, g);
                 static_for<0, 8>([&](auto r_) {
 #if PDHR_EXP == 5
                   if (P.n < 0)
