@@ -117,9 +117,13 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     n = fe.n_dofs_per_cell
     n_agg = ah.n_agglomerates
     # contiguous dof-row ranges of whole polytopes per rank (weak: slab r of the stacked mesh; strong: 1/N of the cube)
-    from polydeal_amd.partition import row_range
-    r0, r1 = row_range(n_agg, n, rank, world)
-    splits = [row_range(n_agg, n, r, world)[0] for r in range(world)] + [n_agg * n]
+    from polydeal_amd.partition import balanced_row_splits, row_range
+    if world > 1 and args.scaling == "strong":
+        # ranges of whole polytopes that balance the non-zeros a rank writes (rows x row length), not the polytope count
+        splits = balanced_row_splits(ah.blocks_per_row(), n, world)
+    else:
+        splits = [row_range(n_agg, n, r, world)[0] for r in range(world)] + [n_agg * n]
+    r0, r1 = splits[rank], splits[rank + 1]
     if world > 1:
         # every rank describes ONLY its own polytopes + their ghost neighbours (pdh_problem.local = 1), like an MPI rank of
         # the reference (source/agglomeration_handler.cc:1026-1091)

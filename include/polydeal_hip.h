@@ -245,6 +245,10 @@ int pdh_values_checksum(pdh_ctx *ctx, double *out4);
 #define PDH_ALG_ROWS 4
 /* Host-only: 1 if PDH_ALG_ROWS applies to this description / row range, 0 if not (pdh_last_error(NULL) says why). */
 int pdh_check_rows(const pdh_problem *problem, int32_t row_begin, int32_t row_end);
+/* Host-only: 1 if the term kernels (PDH_ROWS_TERMS) apply to this description / row range, 0 if not (pdh_last_error(NULL) says
+ * why).  stats5 (may be NULL): most runs (polytopal faces), sub-faces, interior sub-faces and cells of one owned polytope, and
+ * the LDS bytes a workgroup needs for them (the kernels apply while that stays within their budget).                          */
+int pdh_check_terms(const pdh_problem *problem, int32_t row_begin, int32_t row_end, int64_t *stats5);
 int pdh_set_algorithm(pdh_ctx *ctx, int algorithm);
 /* Which row kernel serves the resident problem (PDH_ALG_ROWS has several; all write whole rows, owner computes rows):
  *   PIECES   FE_DGQ(3), one plane per neighbour: moments + Kronecker form, rows in aligned 512-byte pieces (pdh_rows.h)

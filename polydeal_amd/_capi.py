@@ -50,7 +50,7 @@ EXPORTS = [
     "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
     "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows", "pdh_values_checksum",
     "pdh_assemble_rhs_device", "pdh_evaluate_device", "pdh_shape_values_device",
-    "pdh_global_error", "pdh_global_error_device", "pdh_rows_kernel_in_use",
+    "pdh_global_error", "pdh_global_error_device", "pdh_rows_kernel_in_use", "pdh_check_terms",
 ]
 
 _lib = None
@@ -92,6 +92,7 @@ def _bind(lib):
     lib.pdh_set_overlap.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_algorithm_in_use.argtypes = [C.c_void_p]
     lib.pdh_rows_kernel_in_use.argtypes = [C.c_void_p]
+    lib.pdh_check_terms.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, P(C.c_int64)]
     lib.pdh_set_exchange_mode.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_exchange_layout.argtypes = [C.c_void_p, C.c_int, P(C.c_int64), P(C.c_int64)]
     lib.pdh_exchange_get_send.argtypes = [C.c_void_p, C.c_void_p]

@@ -1564,6 +1564,37 @@ extern "C" int pdh_check_rows(const pdh_problem *p, int32_t row_begin, int32_t r
 }
 
 
+// Host-only: 1 if the term kernels (pdh_terms.h / pdh_terms_wg.h) apply to this description and row range, 0 if not
+// (pdh_last_error(NULL) says why), < 0 on an invalid description.  stats4 (may be NULL): most runs / sub-faces / interior
+// sub-faces / cells of one owned polytope... and the LDS bytes of a workgroup in stats4[4].
+extern "C" int pdh_check_terms(const pdh_problem *p, int32_t row_begin, int32_t row_end, int64_t *stats5)
+{
+  Packed K;
+  g_err_noctx.clear();
+  const int rc = pack_problem(nullptr, p, row_begin, row_end, K);
+  if (rc != PDH_OK)
+    return rc;
+  RowsHost R;
+  std::string why;
+  (void)build_rows_tables(p, K, R, &why);
+  if (!R.planar_ok)
+    {
+      g_err_noctx = why;
+      return 0;
+    }
+  const int vn = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
+  TermsHost TH;
+  std::string why_t;
+  const bool ok = build_terms_tables(p, K, R, vn, TH, &why_t);
+  if (stats5)
+    {
+      stats5[0] = TH.maxruns, stats5[1] = TH.maxsf, stats5[2] = TH.maxsi, stats5[3] = TH.maxcell, stats5[4] = TH.lds_bytes;
+    }
+  if (!ok)
+    g_err_noctx = why_t;
+  return ok ? 1 : 0;
+}
+
 // Host-only validation (no GPU needed): runs exactly the checks of pdh_set_problem.
 extern "C" int pdh_check_problem(const pdh_problem *p, int32_t row_begin, int32_t row_end, int64_t *stats)
 {
@@ -1931,7 +1962,11 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
       // per neighbour.  PDH_TERMS=0 (diagnostics) keeps the kinds of pdh_rows.h.
       const char *terms_e = getenv("PDH_TERMS"); // (read per call: the tests compare both kernels in one process)
       const bool terms_env = !(terms_e && terms_e[0] == '0');
-      if (terms_env && RH.planar_ok && RH.fq_tensor_n > 0 && pdh_terms_has_kind(K.n1d, p->basis == PDH_BASIS_AGGLODGP ? 1 : 0))
+      // (FE_DGQ(3) has the workgroup-per-polytope form of the term kernel, pdh_terms_wg.h: taken only on request - PDH_TERMS_DGQ3=1 -
+      // while pdh_rows.h is the measured default for that element)
+      const int terms_kind = pdh_terms_has_kind(K.n1d, p->basis == PDH_BASIS_AGGLODGP ? 1 : 0);
+      const char *terms_q3 = getenv("PDH_TERMS_DGQ3");
+      if (terms_env && RH.planar_ok && RH.fq_tensor_n > 0 && (terms_kind == 1 || (terms_kind == 2 && terms_q3 && terms_q3[0] == '1')))
         {
           if (vq_n_terms < 0)
             vq_n_terms = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });

@@ -201,6 +201,24 @@ int pdhh_n_faces(void *h, int P)
 {
   return guarded([&] { return (int)AH.n_faces(P); });
 }
+// Blocks per row of every polytope (1 + its neighbours), in DOF order (position = dof_offset / n): the weights of a work-balanced
+// partition into contiguous row ranges - rows x row length = non-zeros, which is what a rank writes (reference: the cell graph is
+// partitioned by work, include/poly_utils.h:553-704; here the polytopes are, by non-zeros).  out [n_agglomerates].
+int pdhh_blocks_per_row(void *h, int32_t *out)
+{
+  return guarded([&] {
+    const int nA = (int)AH.n_agglomerates(), n = (int)AH.n_dofs_per_cell();
+    for (int P = 0; P < nA; ++P)
+      {
+        int nb = 1;
+        for (unsigned f = 0; f < AH.n_faces(P); ++f)
+          if (!AH.at_boundary(P, f))
+            ++nb;
+        out[AH.dof_offset_of(P) / n] = nb;
+      }
+    return 0;
+  });
+}
 int pdhh_at_boundary(void *h, int P, int f)
 {
   return guarded([&] { return AH.at_boundary(P, (unsigned)f) ? 1 : 0; });

@@ -86,16 +86,205 @@ struct Kind
 
 // LDS of a workgroup in doubles (host and device agree through this one function)
 __host__ __device__ constexpr int terms_rec_doubles(int maxruns) { return (TERMS_HDR + maxruns * TERMS_ENT + 1) & ~1; }
-template <int N1D, int BASIS>
+// (BLOCK_IN_LDS: the wave-per-polytope kernel leaves the diagonal block in LDS over the dead tables; the workgroup kernel of
+// pdh_terms_wg.h stores it from registers)
+template <int N1D, int BASIS, bool BLOCK_IN_LDS = true>
 __host__ __device__ constexpr int terms_lds_doubles(int maxruns, int maxsf, int maxsi, int maxcell)
 {
   using K = Kind<N1D, BASIS>;
   const int dg = (K::NF + 1) / 2 + ((K::NF + 1) / 2 & 1);
   const int xa = maxsi * 3 * K::FULLS + ((maxsi * 3 * K::FULLS) & 1);
   int da = maxsf * 3 * K::SYMS + maxcell * 6 * K::SYMS;
-  da = da > K::NF * K::NF ? da : K::NF * K::NF;
+  if (BLOCK_IN_LDS)
+    da = da > K::NF * K::NF ? da : K::NF * K::NF;
   return terms_rec_doubles(maxruns) + dg + xa + da + (da & 1);
 }
+
+// Phase A of the term kernels: the lane tasks that build the small matrices of a polytope in LDS.  Shared by the wave-per-polytope
+// kernel below and the workgroup-per-polytope kernel of pdh_terms_wg.h.  PMAX: most points per direction of a rule (4 or 8): the
+// point data of a task sit in registers.
+template <int N1D, int BASIS, int PMAX>
+struct TermTasks
+{
+  using K = Kind<N1D, BASIS>;
+  static constexpr int NSYM = K::NSYM, SYMS = K::SYMS, FULL = K::FULL, FULLS = K::FULLS;
+  const PdhDev &P;
+  const double *rec; // LDS copy of the run entries (behind TERMS_HDR unused doubles)
+  double *Xa, *Da, *Ca;
+  double lo0, lo1, lo2, ih0, ih1, ih2; // own box: lower corner, 1 / side
+  int nsfb, fn, tn;
+  int64_t vq_b;
+  __device__ __forceinline__ static double sel3(int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); }
+  // 1-D basis in the centred variable of a box (pdh_basis.h: monomial coefficients, uniform -> scalar operands)
+  __device__ __forceinline__ void basis(double t, double *b) const
+  {
+    static_for<0, N1D>([&](auto k_) {
+      constexpr int k = k_;
+      double v = P.tab.coef[k][N1D - 1];
+      for (int m = N1D - 2; m >= 0; --m)
+        v = v * t + P.tab.coef[k][m];
+      b[k] = v;
+    });
+  }
+  __device__ __forceinline__ void basis_d(double t, double *b, double *db) const
+  {
+    static_for<0, N1D>([&](auto k_) {
+      constexpr int k = k_;
+      double v = P.tab.coef[k][N1D - 1], d = 0.0;
+      for (int m = N1D - 2; m >= 0; --m)
+        {
+          d = d * t + v;
+          v = v * t + P.tab.coef[k][m];
+        }
+      b[k] = v, db[k] = d;
+    });
+  }
+  // (sub-face, tangential direction): D_d (own x own, own-side weights) and, towards a neighbour, X_d (own x neighbour, JxW of
+  // side 1).  The rule of a sub-face is a_alpha b_beta: direction 0 takes w_(alpha,0), direction 1 takes w_(0,beta) / w_(0,0)
+  struct TPts
+  {
+    double x[PMAX], ws[PMAX], wc[PMAX];
+  };
+  __device__ __forceinline__ TPts tang_load(int info, int64_t pb, int dir) const
+  { // all loads of a task at once (fn <= PMAX, checked by the host)
+    TPts r;
+    const int c = (info >> 8) & 3;
+    const bool fast_j = ((info >> 11) & 1) != 0;
+    const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
+    const int64_t stp = ((dir == 1) == fast_j) ? 1 : fn;
+    static_for<0, PMAX>([&](auto i_) {
+      constexpr int al = i_;
+      const int64_t q = al < fn ? pb + al * stp : pb;
+      r.x[al] = P.ap_x[(int64_t)ax * P.ap_stride + q];
+      r.ws[al] = P.ap_wself[q];
+      r.wc[al] = P.ap_wcross[q]; // (zero on the boundary)
+    });
+    return r;
+  }
+  __device__ __forceinline__ void tang_compute(const TPts &r, int sf, int dir, int info) const
+  {
+    const int run = info & 0xff, c = (info >> 8) & 3;
+    const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
+    const double *re = rec + TERMS_HDR + run * TERMS_ENT;
+    const bool interior = (int)__double_as_longlong(re[1]) >= 0;
+    const double lo_d = sel3(ax, lo0, lo1, lo2), ih_d = sel3(ax, ih0, ih1, ih2);
+    const double loq = re[3 + ax], ihq = re[6 + ax];
+    const double sS = dir ? 1.0 / r.ws[0] : 1.0, sC = (dir && interior) ? 1.0 / r.wc[0] : 1.0;
+    double Dm[NSYM], Xm[FULL];
+    for (int i = 0; i < NSYM; ++i)
+      Dm[i] = 0.0;
+    for (int i = 0; i < FULL; ++i)
+      Xm[i] = 0.0;
+    static_for<0, PMAX>([&](auto i_) {
+      constexpr int al = i_;
+      if (al < fn)
+        {
+          double bp[N1D], bq[N1D];
+          basis((r.x[al] - lo_d) * ih_d - 0.5, bp);
+          basis((r.x[al] - loq) * ihq - 0.5, bq);
+          const double wS = r.ws[al] * sS, wC = r.wc[al] * sC;
+          static_for<0, N1D>([&](auto k_) {
+            constexpr int k = k_;
+            const double ws = wS * bp[k], wc = wC * bp[k];
+            static_for<k, N1D>([&](auto l_) { Dm[K::sym(k, l_)] += ws * bp[l_]; });
+            static_for<0, N1D>([&](auto l_) { Xm[l_ * N1D + k] += wc * bq[l_]; });
+          });
+        }
+    });
+    double *dd = Da + (sf * 3 + ax) * SYMS;
+    for (int i = 0; i < NSYM; ++i)
+      dd[i] = Dm[i];
+    if (interior)
+      {
+        double *xd = Xa + ((sf - nsfb) * 3 + ax) * FULLS;
+        for (int i = 0; i < FULL; ++i)
+          xd[i] = Xm[i];
+      }
+  }
+  // (sub-face, normal direction): D_c and X_c at the plane
+  __device__ __forceinline__ void norm_compute(double zeta, int sf, int info) const
+  {
+    const int run = info & 0xff, c = (info >> 8) & 3;
+    const double sg = ((info >> 10) & 1) ? 1.0 : -1.0;
+    const double *re = rec + TERMS_HDR + run * TERMS_ENT;
+    const bool interior = (int)__double_as_longlong(re[1]) >= 0;
+    const double sig = re[2];
+    const double lo_c = sel3(c, lo0, lo1, lo2), ih_c = sel3(c, ih0, ih1, ih2);
+    const double loq = re[3 + c], ihq = re[6 + c];
+    double bp[N1D], dp[N1D], bq[N1D], dq[N1D];
+    basis_d((zeta - lo_c) * ih_c - 0.5, bp, dp);
+    basis_d((zeta - loq) * ihq - 0.5, bq, dq);
+    double *dd = Da + (sf * 3 + c) * SYMS;
+    double *xd = Xa + ((sf - nsfb) * 3 + c) * FULLS;
+    const double hs = 0.5 * sg * ih_c, hq = 0.5 * sg * ihq;
+    static_for<0, N1D>([&](auto k_) {
+      constexpr int k = k_;
+      static_for<k, N1D>([&](auto l_) {
+        constexpr int l = l_;
+        dd[K::sym(k, l)] = sig * bp[k] * bp[l] - hs * (dp[k] * bp[l] + bp[k] * dp[l]);
+      });
+      if (interior)
+        static_for<0, N1D>([&](auto l_) {
+          constexpr int l = l_;
+          xd[l * N1D + k] = (hs * dp[k] - sig * bp[k]) * bq[l] - hq * bp[k] * dq[l];
+        });
+    });
+  }
+  // (cell, direction): M_d and K_d.  The rule of a cell is a_i b_j c_k: direction 0 takes w_(i,0,0), the others w / w_000
+  struct CPts
+  {
+    double x[PMAX], w[PMAX];
+  };
+  __device__ __forceinline__ CPts cell_load(int ct) const
+  {
+    CPts r;
+    const int cell = ct / 3, d = ct - 3 * cell;
+    const int64_t base = vq_b + (int64_t)cell * (tn * tn * tn);
+    const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
+    static_for<0, PMAX>([&](auto i_) {
+      constexpr int i = i_;
+      const int64_t q = i < tn ? base + i * step : base;
+      r.x[i] = P.vq_x[(int64_t)d * P.vq_stride + q];
+      r.w[i] = P.vq_w[q];
+    });
+    return r;
+  }
+  __device__ __forceinline__ void cell_compute(const CPts &r, int ct) const
+  {
+    const int cell = ct / 3, d = ct - 3 * cell;
+    const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
+    const double sc = d == 0 ? 1.0 : 1.0 / r.w[0];
+    double Mm[NSYM], Km[NSYM];
+    for (int i = 0; i < NSYM; ++i)
+      Mm[i] = Km[i] = 0.0;
+    static_for<0, PMAX>([&](auto i_) {
+      constexpr int i = i_;
+      if (i < tn)
+        {
+          double bp[N1D], dp[N1D];
+          basis_d((r.x[i] - lo_d) * ih_d - 0.5, bp, dp);
+          const double w = r.w[i] * sc;
+          static_for<0, N1D>([&](auto k_) {
+            constexpr int k = k_;
+            const double wb = w * bp[k], wd = w * (dp[k] * ih_d);
+            static_for<k, N1D>([&](auto l_) {
+              Mm[K::sym(k, l_)] += wb * bp[l_];
+              Km[K::sym(k, l_)] += wd * (dp[l_] * ih_d);
+            });
+          });
+        }
+    });
+    if (d == 0 && P.reaction_c != 0.0) // c phi_i phi_j rides on the first term of the cell
+      for (int i = 0; i < NSYM; ++i)
+        Km[i] += P.reaction_c * Mm[i];
+    double *cd = Ca + (cell * 3 + d) * 2 * SYMS;
+    for (int i = 0; i < NSYM; ++i)
+      {
+        cd[i] = Mm[i];
+        cd[SYMS + i] = Km[i];
+      }
+  }
+};
 
 // PMAX: most points per direction of a rule the instantiation takes (4 or 8): the point data of a lane task sit in registers
 template <int N1D, int BASIS, bool SHIFTED, int PMAX>
@@ -166,170 +355,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
       dig[lane] = k0 | (k1 << 4) | (k2 << 8);
     }
   double *Ca = Da + nsf * 3 * SYMS; // [cell][direction][M | K] behind the sub-faces' tables
-  // 1-D basis in the centred variable of a box (pdh_basis.h: monomial coefficients, uniform -> scalar operands)
-  auto basis = [&](double t, double *b) {
-    static_for<0, N1D>([&](auto k_) {
-      constexpr int k = k_;
-      double v = P.tab.coef[k][N1D - 1];
-      for (int m = N1D - 2; m >= 0; --m)
-        v = v * t + P.tab.coef[k][m];
-      b[k] = v;
-    });
-  };
-  auto basis_d = [&](double t, double *b, double *db) {
-    static_for<0, N1D>([&](auto k_) {
-      constexpr int k = k_;
-      double v = P.tab.coef[k][N1D - 1], d = 0.0;
-      for (int m = N1D - 2; m >= 0; --m)
-        {
-          d = d * t + v;
-          v = v * t + P.tab.coef[k][m];
-        }
-      b[k] = v, db[k] = d;
-    });
-  };
-
-  // ================= A: the small matrices =========================================================================
-  // (sub-face, tangential direction): D_d (own x own, own-side weights) and, towards a neighbour, X_d (own x neighbour, JxW of
-  // side 1).  The rule of a sub-face is a_alpha b_beta: direction 0 takes w_(alpha,0), direction 1 takes w_(0,beta) / w_(0,0)
-  struct TPts
-  {
-    double x[PMAX], ws[PMAX], wc[PMAX];
-  };
-  auto tang_load = [&](int info, int64_t pb, int dir) { // all loads of a task at once (fn <= PMAX, checked by the host)
-    TPts r;
-    const int c = (info >> 8) & 3;
-    const bool fast_j = ((info >> 11) & 1) != 0;
-    const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
-    const int64_t stp = ((dir == 1) == fast_j) ? 1 : fn;
-    static_for<0, PMAX>([&](auto i_) {
-      constexpr int al = i_;
-      const int64_t q = al < fn ? pb + al * stp : pb;
-      r.x[al] = P.ap_x[(int64_t)ax * P.ap_stride + q];
-      r.ws[al] = P.ap_wself[q];
-      r.wc[al] = P.ap_wcross[q]; // (zero on the boundary)
-    });
-    return r;
-  };
-  auto tang_compute = [&](const TPts &r, int sf, int dir, int info) {
-    const int run = info & 0xff, c = (info >> 8) & 3;
-    const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
-    const double *re = rec + TERMS_HDR + run * TERMS_ENT;
-    const bool interior = (int)__double_as_longlong(re[1]) >= 0;
-    const double lo_d = sel3(ax, lo0, lo1, lo2), ih_d = sel3(ax, ih0, ih1, ih2);
-    const double loq = re[3 + ax], ihq = re[6 + ax];
-    const double sS = dir ? 1.0 / r.ws[0] : 1.0, sC = (dir && interior) ? 1.0 / r.wc[0] : 1.0;
-    double Dm[NSYM], Xm[FULL];
-    for (int i = 0; i < NSYM; ++i)
-      Dm[i] = 0.0;
-    for (int i = 0; i < FULL; ++i)
-      Xm[i] = 0.0;
-    static_for<0, PMAX>([&](auto i_) {
-      constexpr int al = i_;
-      if (al < fn)
-        {
-          double bp[N1D], bq[N1D];
-          basis((r.x[al] - lo_d) * ih_d - 0.5, bp);
-          basis((r.x[al] - loq) * ihq - 0.5, bq);
-          const double wS = r.ws[al] * sS, wC = r.wc[al] * sC;
-          static_for<0, N1D>([&](auto k_) {
-            constexpr int k = k_;
-            const double ws = wS * bp[k], wc = wC * bp[k];
-            static_for<k, N1D>([&](auto l_) { Dm[K::sym(k, l_)] += ws * bp[l_]; });
-            static_for<0, N1D>([&](auto l_) { Xm[l_ * N1D + k] += wc * bq[l_]; });
-          });
-        }
-    });
-    double *dd = Da + (sf * 3 + ax) * SYMS;
-    for (int i = 0; i < NSYM; ++i)
-      dd[i] = Dm[i];
-    if (interior)
-      {
-        double *xd = Xa + ((sf - nsfb) * 3 + ax) * FULLS;
-        for (int i = 0; i < FULL; ++i)
-          xd[i] = Xm[i];
-      }
-  };
-  // (sub-face, normal direction): D_c and X_c at the plane
-  auto norm_compute = [&](double zeta, int sf, int info) {
-    const int run = info & 0xff, c = (info >> 8) & 3;
-    const double sg = ((info >> 10) & 1) ? 1.0 : -1.0;
-    const double *re = rec + TERMS_HDR + run * TERMS_ENT;
-    const bool interior = (int)__double_as_longlong(re[1]) >= 0;
-    const double sig = re[2];
-    const double lo_c = sel3(c, lo0, lo1, lo2), ih_c = sel3(c, ih0, ih1, ih2);
-    const double loq = re[3 + c], ihq = re[6 + c];
-    double bp[N1D], dp[N1D], bq[N1D], dq[N1D];
-    basis_d((zeta - lo_c) * ih_c - 0.5, bp, dp);
-    basis_d((zeta - loq) * ihq - 0.5, bq, dq);
-    double *dd = Da + (sf * 3 + c) * SYMS;
-    double *xd = Xa + ((sf - nsfb) * 3 + c) * FULLS;
-    const double hs = 0.5 * sg * ih_c, hq = 0.5 * sg * ihq;
-    static_for<0, N1D>([&](auto k_) {
-      constexpr int k = k_;
-      static_for<k, N1D>([&](auto l_) {
-        constexpr int l = l_;
-        dd[K::sym(k, l)] = sig * bp[k] * bp[l] - hs * (dp[k] * bp[l] + bp[k] * dp[l]);
-      });
-      if (interior)
-        static_for<0, N1D>([&](auto l_) {
-          constexpr int l = l_;
-          xd[l * N1D + k] = (hs * dp[k] - sig * bp[k]) * bq[l] - hq * bp[k] * dq[l];
-        });
-    });
-  };
-  // (cell, direction): M_d and K_d.  The rule of a cell is a_i b_j c_k: direction 0 takes w_(i,0,0), the others w / w_000
-  struct CPts
-  {
-    double x[PMAX], w[PMAX];
-  };
-  auto cell_load = [&](int ct) {
-    CPts r;
-    const int cell = ct / 3, d = ct - 3 * cell;
-    const int64_t base = vq_b + (int64_t)cell * (tn * tn * tn);
-    const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
-    static_for<0, PMAX>([&](auto i_) {
-      constexpr int i = i_;
-      const int64_t q = i < tn ? base + i * step : base;
-      r.x[i] = P.vq_x[(int64_t)d * P.vq_stride + q];
-      r.w[i] = P.vq_w[q];
-    });
-    return r;
-  };
-  auto cell_compute = [&](const CPts &r, int ct) {
-    const int cell = ct / 3, d = ct - 3 * cell;
-    const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
-    const double sc = d == 0 ? 1.0 : 1.0 / r.w[0];
-    double Mm[NSYM], Km[NSYM];
-    for (int i = 0; i < NSYM; ++i)
-      Mm[i] = Km[i] = 0.0;
-    static_for<0, PMAX>([&](auto i_) {
-      constexpr int i = i_;
-      if (i < tn)
-        {
-          double bp[N1D], dp[N1D];
-          basis_d((r.x[i] - lo_d) * ih_d - 0.5, bp, dp);
-          const double w = r.w[i] * sc;
-          static_for<0, N1D>([&](auto k_) {
-            constexpr int k = k_;
-            const double wb = w * bp[k], wd = w * (dp[k] * ih_d);
-            static_for<k, N1D>([&](auto l_) {
-              Mm[K::sym(k, l_)] += wb * bp[l_];
-              Km[K::sym(k, l_)] += wd * (dp[l_] * ih_d);
-            });
-          });
-        }
-    });
-    if (d == 0 && P.reaction_c != 0.0) // c phi_i phi_j rides on the first term of the cell
-      for (int i = 0; i < NSYM; ++i)
-        Km[i] += P.reaction_c * Mm[i];
-    double *cd = Ca + (cell * 3 + d) * 2 * SYMS;
-    for (int i = 0; i < NSYM; ++i)
-      {
-        cd[i] = Mm[i];
-        cd[SYMS + i] = Km[i];
-      }
-  };
+  using TT = TermTasks<N1D, BASIS, PMAX>;
+  using TPts = typename TT::TPts;
+  using CPts = typename TT::CPts;
+  const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, vq_b};
+  auto tang_load = [&](int info, int64_t pb, int dir) { return tt.tang_load(info, pb, dir); };
+  auto tang_compute = [&](const TPts &r, int sf, int dir, int info) { tt.tang_compute(r, sf, dir, info); };
+  auto norm_compute = [&](double zeta, int sf, int info) { tt.norm_compute(zeta, sf, info); };
+  auto cell_load = [&](int ct) { return tt.cell_load(ct); };
+  auto cell_compute = [&](const CPts &r, int ct) { tt.cell_compute(r, ct); };
   PDHT_MARK(1);
   // ---- level 2: the point data of the first round of BOTH kinds of task are requested before anything is computed
   const int ntask2 = nsf + 3 * ncell; // second kind: normal-direction tasks, then cell tasks

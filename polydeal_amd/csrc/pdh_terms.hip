@@ -1,6 +1,7 @@
 // pdh_terms.hip — instantiations and launcher of the term kernel (pdh_terms.h): 3-D FE_DGQ(1,2), FE_AggloDGP(1..3).
 #include <cstdlib>
 #include "pdh_terms.h"
+#include "pdh_terms_wg.h"
 
 namespace
 {
@@ -24,9 +25,12 @@ bool for_kind(int n1d, int basis, F &&f)
 }
 } // namespace
 
-// 1 if the term kernel is instantiated for this element
+// 1 if the term kernel (pdh_terms.h, a wave per polytope) is instantiated for this element, 2: FE_DGQ(3), which has the
+// workgroup-per-polytope kernel of pdh_terms_wg.h instead
 extern "C" int pdh_terms_has_kind(int n1d, int basis)
 {
+  if (n1d == 4 && basis == 0)
+    return 2;
   return for_kind(n1d, basis, [](auto, auto) {}) ? 1 : 0;
 }
 
@@ -34,6 +38,8 @@ extern "C" int pdh_terms_has_kind(int n1d, int basis)
 extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell)
 {
   int bytes = 0;
+  if (n1d == 4 && basis == 0)
+    return 8 * pdht::terms_lds_doubles<4, 0, false>(maxruns, maxsf, maxsi, maxcell);
   for_kind(n1d, basis, [&](auto n_, auto b_) {
     bytes = 8 * pdht::terms_lds_doubles<decltype(n_)::value, decltype(b_)::value>(maxruns, maxsf, maxsi, maxcell);
   });
@@ -47,6 +53,38 @@ extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int c
   const int full = P->n1d * P->n1d * P->n1d;
   const int basis = P->n == full ? 0 : 1;
   hipError_t rc = hipErrorInvalidValue;
+  if (P->n1d == 4 && basis == 0)
+    {
+      // FE_DGQ(3): a workgroup of W waves per polytope (pdh_terms_wg.h); PDH_TERMS_WG_WAVES = 4 | 8 (diagnostics)
+      static const int waves = [] {
+        const char *e = getenv("PDH_TERMS_WG_WAVES");
+        const int w = e ? atoi(e) : 4;
+        return w == 8 ? 8 : 4;
+      }();
+      const size_t lds = (size_t)T->lds_bytes;
+      const bool small = T->fq_tensor_n <= 4 && T->vq_tensor_n <= 4;
+      auto go = [&](auto w_, auto shifted_, auto pmax_) {
+        constexpr int W = decltype(w_)::value;
+        hipLaunchKernelGGL((pdht::k_terms_wg<W, decltype(shifted_)::value, decltype(pmax_)::value>), dim3((unsigned)count), dim3(PDH_WAVE * W),
+                           lds, stream, *P, *T, count);
+      };
+      using std::integral_constant;
+      auto go_w = [&](auto w_) {
+        if (P->diag_first && small)
+          go(w_, std::true_type{}, integral_constant<int, 4>{});
+        else if (P->diag_first)
+          go(w_, std::true_type{}, integral_constant<int, 8>{});
+        else if (small)
+          go(w_, std::false_type{}, integral_constant<int, 4>{});
+        else
+          go(w_, std::false_type{}, integral_constant<int, 8>{});
+      };
+      if (waves == 8)
+        go_w(integral_constant<int, 8>{});
+      else
+        go_w(integral_constant<int, 4>{});
+      return hipGetLastError();
+    }
   for_kind(P->n1d, basis, [&](auto n_, auto b_) {
     constexpr int N = decltype(n_)::value, B = decltype(b_)::value;
     if (P->n != pdht::Kind<N, B>::NF)

@@ -28,6 +28,7 @@ def _lib():
         lib.pdhh_grid_destroy.restype = None
         lib.pdhh_grid_n_cells.argtypes = [C.c_void_p]
         lib.pdhh_grid_distort.argtypes = [C.c_void_p, C.c_double, C.c_uint]
+        lib.pdhh_blocks_per_row.argtypes = [C.c_void_p, C.c_void_p]
         lib.pdhh_grid_vertices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.pdhh_handler_create.restype = C.c_void_p
         lib.pdhh_handler_create.argtypes = [C.c_void_p]
@@ -345,6 +346,13 @@ class AgglomerationHandler:
     def agglomerate_size(self, P):
         """Number of cells of polytope P (polytope->get_agglomerate().size())."""
         return _lib().pdhh_agglomerate_size(self.h, P)
+
+    def blocks_per_row(self):
+        """1 + number of neighbours of every polytope, in dof order: weights for partition.balanced_row_splits."""
+        out = np.zeros(self.n_agglomerates, dtype=np.int32)
+        if _lib().pdhh_blocks_per_row(self.h, out.ctypes.data) < 0:
+            _raise()
+        return out
 
     def n_faces_of(self, P):
         return _lib().pdhh_n_faces(self.h, P)
