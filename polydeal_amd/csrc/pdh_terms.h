@@ -141,10 +141,12 @@ struct TermTasks
   }
   // (sub-face, tangential direction): D_d (own x own, own-side weights) and, towards a neighbour, X_d (own x neighbour, JxW of
   // side 1).  The rule of a sub-face is a_alpha b_beta: direction 0 takes w_(alpha,0), direction 1 takes w_(0,beta) / w_(0,0)
-  struct TPts
+  struct Pts // point data of one lane task: tangential x | w_self | w_cross; cell x | w; normal-direction task: x[0] = plane coordinate
   {
     double x[PMAX], ws[PMAX], wc[PMAX];
   };
+  using TPts = Pts;
+  using CPts = Pts;
   __device__ __forceinline__ TPts tang_load(int info, int64_t pb, int dir) const
   { // all loads of a task at once (fn <= PMAX, checked by the host)
     TPts r;
@@ -231,10 +233,6 @@ struct TermTasks
     });
   }
   // (cell, direction): M_d and K_d.  The rule of a cell is a_i b_j c_k: direction 0 takes w_(i,0,0), the others w / w_000
-  struct CPts
-  {
-    double x[PMAX], w[PMAX];
-  };
   __device__ __forceinline__ CPts cell_load(int ct) const
   {
     CPts r;
@@ -245,7 +243,8 @@ struct TermTasks
       constexpr int i = i_;
       const int64_t q = i < tn ? base + i * step : base;
       r.x[i] = P.vq_x[(int64_t)d * P.vq_stride + q];
-      r.w[i] = P.vq_w[q];
+      r.ws[i] = P.vq_w[q];
+      r.wc[i] = 0.0;
     });
     return r;
   }
@@ -253,7 +252,7 @@ struct TermTasks
   {
     const int cell = ct / 3, d = ct - 3 * cell;
     const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
-    const double sc = d == 0 ? 1.0 : 1.0 / r.w[0];
+    const double sc = d == 0 ? 1.0 : 1.0 / r.ws[0];
     double Mm[NSYM], Km[NSYM];
     for (int i = 0; i < NSYM; ++i)
       Mm[i] = Km[i] = 0.0;
@@ -263,7 +262,7 @@ struct TermTasks
         {
           double bp[N1D], dp[N1D];
           basis_d((r.x[i] - lo_d) * ih_d - 0.5, bp, dp);
-          const double w = r.w[i] * sc;
+          const double w = r.ws[i] * sc;
           static_for<0, N1D>([&](auto k_) {
             constexpr int k = k_;
             const double wb = w * bp[k], wd = w * (dp[k] * ih_d);
@@ -371,7 +370,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
   double zeta0 = 0.0;
   CPts cp0;
   for (int i = 0; i < PMAX; ++i)
-    cp0.x[i] = cp0.w[i] = 0.0;
+    cp0.x[i] = cp0.ws[i] = cp0.wc[i] = 0.0;
   if (lane < nsf)
     zeta0 = P.ap_x[(int64_t)((infoN >> 8) & 3) * P.ap_stride + pbN];
   else if (lane < ntask2)

@@ -15,11 +15,19 @@
 //      l - 1 (its own table offsets), lane 0 the last column of the block before (another run's tables) or, in piece 0, receives
 //      the diagonal entry; the own block is computed in natural order and stored with lanes 0 .. R rotated by one position
 //      (lane R, whose diagonal entry belongs to position 0 of the ROW, carries the last column of the block before).
+// Status (round 4, profiles/r04_wg_variants.txt): parity green on blocks and staircase agglomerates in both layouts; 1.45-1.61 ms on
+// the bench mesh where pdh_rows.h takes 1.55-1.65 on the same boxes - within the spread between two allocations of the values, so
+// AUTO keeps pdh_rows.h and this kernel is taken on request (PDH_TERMS_DGQ3=1).  Without its stores it needs 1.02 ms (pdh_rows.h:
+// 0.86): the term form costs this element more VALU work than the moment form + MFMA contraction (8 000 against 5 900 instructions
+// per polytope), which eats what the shared store pattern gains.  A persistent variant that requests the next polytope's
+// descriptors and point data during phase B (raw s_barrier hand-offs, no vmcnt(0)) was measured equal at 156 VGPRs and 15 % slower
+// when held to 128: not kept.
 #pragma once
 #include "pdh_terms.h"
 
 #ifndef PDHW_STORE_AUX
-#define PDHW_STORE_AUX 18 // gfx940+ cache-policy bits of the row stores: 1 = sc0, 2 = nt, 16 = sc1 (as pdh_rows.h)
+#define PDHW_STORE_AUX 2 // gfx940+ cache-policy bits of the row stores: 1 = sc0, 2 = nt, 16 = sc1 (nt alone: 1.48-1.52 ms where sc1|nt, the
+                         // policy of pdh_rows.h, gives 1.51-1.61, profiles/r04_wg_variants.txt)
 #endif
 
 // -DPDHT_STAMP (diagnostic builds): cycle counter of wave w at four points -> stamps[slot][4 w + k] (W = 4 only)
@@ -99,7 +107,7 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
     typename TT::CPts cp0;
     double zeta0 = 0.0;
     for (int i = 0; i < PMAX; ++i)
-      tp0.x[i] = tp0.ws[i] = tp0.wc[i] = cp0.x[i] = cp0.w[i] = 0.0;
+      tp0.x[i] = tp0.ws[i] = tp0.wc[i] = cp0.x[i] = cp0.ws[i] = cp0.wc[i] = 0.0;
     if (first_kind)
       {
         desc(on0 ? tid0 >> 1 : 0, info0, pb0);

@@ -1295,6 +1295,71 @@ def test_term_kernel_rules_of_up_to_eight_points(basis, p, nq):
         assert_parity_ah(v0, ref, ah, what="term kernel, %d points per direction" % nq)
 
 
+@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("kind,cells,per,vname,diag_first,nq", [("block", 4, 2, "poisson", True, 4), ("block", 6, 2, "dr", False, 4), ("block", 4, 1, "test", True, 4),
+                                                                ("grown", 6, 6, "adm", True, 4), ("grown", 8, 8, "poisson", False, 4), ("grown", 6, 3, "minsip", True, 4),
+                                                                ("block", 4, 2, "adm", True, 7), ("boxes", 4, 0, "poisson", True, 4)])
+def test_term_kernel_workgroup_form_for_dgq3(kind, cells, per, vname, diag_first, nq, waves, monkeypatch):
+    """FE_DGQ(3) through the workgroup-per-polytope form of the term kernel (pdh_terms_wg.h; on request: PDH_TERMS_DGQ3=1, four or
+    eight waves per polytope): blocks, boxes of different sizes, staircase agglomerates, both CSR layouts, rules of 4 and 7 points
+    per direction, row ranges - per-block parity with the oracle and agreement with the kinds of pdh_rows.h to rounding."""
+    import subprocess
+    import sys
+
+    # (the number of waves is read once per process by the launcher: one child process per value)
+    if waves != "4":
+        here = __import__('os').path.dirname(__import__('os').path.abspath(__file__))
+        code = ("import os, sys; os.environ['PDH_TERMS_WG_WAVES'] = %r; sys.path.insert(0, %r); sys.path.insert(0, %r); "
+                "import test_gpu_parity as t; t._wg_case(%r, %r, %r, %r, %r, %r)"
+                % (waves, __import__('os').path.dirname(here), here, kind, cells, per, vname, diag_first, nq))
+        env = dict(__import__('os').environ, PDH_TERMS_DGQ3="1", PDH_TERMS_WG_WAVES=waves)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        return
+    monkeypatch.setenv("PDH_TERMS_DGQ3", "1")
+    _wg_case(kind, cells, per, vname, diag_first, nq)
+
+
+def _wg_case(kind, cells, per, vname, diag_first, nq):
+    import os
+
+    from polydeal_amd.partition import row_range
+
+    os.environ["PDH_TERMS_DGQ3"] = "1"
+    fe = po.FE_DGQ(3, 3)
+    grid = po.subdivided_hyper_cube(3, cells, 0.0, 1.0) if kind != "boxes" else po.hyper_cube_refined(3, 0.0, 1.0, 2)
+    if kind == "block":
+        groups = po.block_agglomerates(grid, per)
+    elif kind == "boxes":
+        groups = _box_groups(grid, 4)
+    else:
+        groups = _grown_agglomerates(grid, per, cells)
+    ah = po.AgglomerationHandler(grid)
+    for g in groups:
+        ah.define_agglomerate(g)
+    ah.initialize_fe_values(nq, nq)
+    ah.distribute_agglomerated_dofs(fe)
+    var = variant(vname, fe)
+    kw = flatten(ah, var, diag_first=diag_first)
+    ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
+    v0, used, kern = _values_k(kw, "auto")
+    assert used == "rows" and kern == "terms"
+    assert_parity_ah(v0, ref, ah, diag_first, what="workgroup term kernel")
+    os.environ["PDH_TERMS_DGQ3"] = "0"
+    v1, used1, kern1 = _values_k(kw, "auto")
+    os.environ["PDH_TERMS_DGQ3"] = "1"
+    assert used1 == "rows" and kern1 in ("pieces", "multi")
+    assert np.max(np.abs(v0 - v1)) <= 1e-13 * np.max(np.abs(ref))
+    n = fe.n_dofs_per_cell
+    parts = []
+    for r in range(2):
+        rb, re = row_range(ah.n_agglomerates, n, r, 2)
+        v, u, k = _values_k(kw, "rows", rb, re)
+        assert u == "rows" and k == "terms"
+        parts.append(v)
+    assert_parity_ah(np.concatenate(parts), ref, ah, diag_first, what="workgroup term kernel, row ranges")
+
+
 def test_row_kernel_staircase_with_large_plane_entries():
     """MULTI instantiation with plane entries of MORE sub-faces than one staging round of its S takes (14): 4x4x4 blocks of an
     8^3 grid, one corner cell moved from block A to its +x neighbour B - A and B then meet along a 15-sub-face plane, a
