@@ -188,6 +188,30 @@ def test_cpp_examples_run():
     assert out.stdout == open(os.path.join(root, "tests", "golden", "minimal_SIP_Poisson.output")).read()
 
 
+def test_cpp_diffusion_reaction_example_runs():
+    """examples/diffusion_reaction.cc (BASELINE configs[3]'s caller) through the C ABI: FE_DGQ(1..3), reaction term, right-hand side
+    and Nitsche datum of u = exp(xyz), the MPI ranks of the reference played in turn - every rank with its rank-local description
+    in Epetra column order assembling only its rows -, host CG, error norms summed over the ranks: p-convergence."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "diffusion_reaction")
+    assert os.path.exists(exe), "examples/ not built: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C examples)"
+    for ranks in ("4", "1"):
+        out = subprocess.run([exe, "3", ranks, "10" if ranks == "4" else "40"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = out.stdout.split("\n")
+        l2 = [float(l.split(":")[1]) for l in lines if l.startswith("L2 error (exponential solution):")]
+        h1 = [float(l.split(":")[1]) for l in lines if l.startswith("Semi H1 error (exponential solution):")]
+        assert len(l2) == len(h1) == 3 and sum(l.startswith("Time taken by assemble_system()") for l in lines) == 3
+        assert all(l2[k + 1] < l2[k] / 3.0 and h1[k + 1] < h1[k] / 3.0 for k in range(2)), (l2, h1)
+        assert l2[0] < 2e-2 and l2[2] < 1e-4 and h1[2] < 5e-3, (l2, h1)
+        if ranks == "4":
+            first = (l2, h1)
+    # the same 40 agglomerates (same seed) assembled by one rank: the split into ranks changes nothing but rounding
+    assert all(abs(a - b) <= 1e-9 * a for a, b in zip(first[0] + first[1], l2 + h1)), (first, l2, h1)
+
+
 def test_poisson_output_L2_error_with_gpu_matrix():
     """test/polydeal/poisson.output ('L2 error:0.00647702', printed by the reference itself): same pipeline
     as tests/test_oracle_golden.py::test_poisson_output_L2_error but with the matrix assembled by the HIP path."""
