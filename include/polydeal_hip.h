@@ -125,6 +125,32 @@ const char *pdh_last_error(const pdh_ctx *ctx); /* valid until the next call on 
 int pdh_set_problem(pdh_ctx *ctx, const pdh_problem *problem);
 int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *problem, int32_t row_begin, int32_t row_end);
 
+/* Set-up from a COMPACT description of agglomerates of CARTESIAN cells: the quadrature data of the problem are generated ON THE
+ * DEVICE instead of being gathered on the host and uploaded.  The reference gathers them per polytope inside the span it times
+ * (source/agglomeration_handler.cc:622-707 agglomerated_quadrature, :1103-1243 reinit_master; examples/poisson.cc:1099-1106); for
+ * sub-cells that are axis-aligned boxes with QGauss rules - every BASELINE configuration but the piston mesh - a group of nq^3
+ * volume points is a function of its cell's box, a group of nqf^2 face points of its cell's box and local face number.
+ *   problem : as for pdh_set_problem_local (global or rank-local), with vq_x, vq_w, fq_x, fq_n, fq_w, fq_w_out = NULL; dim = 3;
+ *             vq_ptr / fq_ptr count points as always (nq^3 per sub-cell, nqf^2 per sub-face); vq_tensor_n / fq_tensor_n ignored
+ *   points  : where the points come from.  Volume group g (the g-th group of nq^3 points in the order of vq_ptr) is QGauss<3>(nq)
+ *             on cell vq_cell[g] (x fastest); face group s (order of fq_ptr) is QGauss<2>(nqf) on local face fq_face[s] (deal.II
+ *             numbering 2 * axis + side) of cell fq_cell[s] - the sub-cell on side 0 of the polytopal face, whose outward normal
+ *             is the face's normal (reference include/poly_utils.h:1881) - lower tangential axis fastest.
+ * The generated arrays are exactly what the caller would have passed (to rounding of lo + h * xi), so everything downstream is
+ * unchanged; the assembly runs through the term kernels (PDH_ROWS_TERMS: a problem whose polytopes are too large for them is
+ * refused with PDH_EUNSUPPORTED - describe it with points then).                                                              */
+typedef struct pdh_cartesian_points
+{
+  int32_t n_cells;          /* cells of the background grid referred to below                                   */
+  const double *cell_box;   /* [n_cells][2][3] lower, upper corner                                              */
+  const int32_t *vq_cell;   /* [vq_ptr[n_agg] / nq^3] cell of every group of volume points                      */
+  const int32_t *fq_cell;   /* [fq_ptr[n_faces] / nqf^2] side-0 cell of every sub-face                          */
+  const int32_t *fq_face;   /* [same] its local face number 0 .. 5                                              */
+  int32_t nq, nqf;          /* points per direction of the cell / face rule (1 .. 8)                            */
+} pdh_cartesian_points;
+int pdh_set_problem_cartesian(pdh_ctx *ctx, const pdh_problem *problem, const pdh_cartesian_points *points, int32_t row_begin,
+                              int32_t row_end);
+
 /* The hot path.  Replaces the body of assemble_dg_matrix (poly_utils.h:2034-2193): volume term,
  * boundary (Nitsche) term and the four interface blocks, written straight into CSR value order.
  *   pdh_assemble_device : values stay in HBM (pointer from pdh_device_values); asynchronous on the

@@ -50,7 +50,7 @@ EXPORTS = [
     "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
     "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows", "pdh_values_checksum",
     "pdh_assemble_rhs_device", "pdh_evaluate_device", "pdh_shape_values_device",
-    "pdh_global_error", "pdh_global_error_device", "pdh_rows_kernel_in_use", "pdh_check_terms",
+    "pdh_global_error", "pdh_global_error_device", "pdh_rows_kernel_in_use", "pdh_check_terms", "pdh_set_problem_cartesian",
 ]
 
 _lib = None
@@ -82,6 +82,7 @@ def _bind(lib):
     lib.pdh_last_error.restype = C.c_char_p
     lib.pdh_set_problem.argtypes = [C.c_void_p, P(pdh_problem)]
     lib.pdh_set_problem_local.argtypes = [C.c_void_p, P(pdh_problem), C.c_int32, C.c_int32]
+    lib.pdh_set_problem_cartesian.argtypes = [C.c_void_p, P(pdh_problem), C.c_void_p, C.c_int32, C.c_int32]
     lib.pdh_assemble_device.argtypes = [C.c_void_p]
     lib.pdh_assemble.argtypes = [C.c_void_p, C.c_void_p]
     lib.pdh_assemble_sip.argtypes = [C.c_void_p, P(pdh_problem), C.c_void_p]
@@ -199,7 +200,11 @@ class Context:
     def set_problem(self, prob, row_begin=0, row_end=None):
         """prob: a Problem (NumPy-backed) or anything with a `.c` pdh_problem (e.g. handler.FlatView)."""
         row_end = prob.c.n_rows if row_end is None else row_end
-        self._chk(self.lib.pdh_set_problem_local(self.h, C.byref(prob.c), row_begin, row_end))
+        cart = getattr(prob, "cartesian", None)
+        if cart:  # a flatten_cartesian view: the points are generated on the device
+            self._chk(self.lib.pdh_set_problem_cartesian(self.h, C.byref(prob.c), C.c_void_p(cart), row_begin, row_end))
+        else:
+            self._chk(self.lib.pdh_set_problem_local(self.h, C.byref(prob.c), row_begin, row_end))
         self.n_values = self.stats()["n_values"]
         off = np.array((C.c_int32 * prob.c.n_agg).from_address(int(prob.c.dof_offset)), dtype=np.int64)
         self._owned = (off >= row_begin) & (off < row_end)  # polytopes whose rows live here

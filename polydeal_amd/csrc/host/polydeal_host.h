@@ -879,20 +879,33 @@ struct FlatProblem
   PointArray vq_x, vq_w, fq_x, fq_n, fq_w, fq_w_out;
   std::vector<int32_t> dof_offset, face_in, face_out, colind, col_offset, agg_rank;
   std::vector<int64_t> vq_ptr, fq_ptr, rowptr;
+  // flatten_cartesian: the compact description of the points (include/polydeal_hip.h: pdh_cartesian_points) instead of the points
+  pdh_cartesian_points cart{};
+  std::vector<double> cart_box;
+  std::vector<int32_t> cart_vq_cell, cart_fq_cell, cart_fq_face;
+  bool cartesian = false;
   void bind()
   {
+    if (cartesian)
+      {
+        cart.n_cells = (int32_t)(cart_box.size() / 6);
+        cart.cell_box = cart_box.data();
+        cart.vq_cell = cart_vq_cell.data();
+        cart.fq_cell = cart_fq_cell.data();
+        cart.fq_face = cart_fq_face.data();
+      }
     c.bbox = bbox.data();
     c.dof_offset = dof_offset.data();
     c.vq_ptr = vq_ptr.data();
-    c.vq_x = vq_x.data();
-    c.vq_w = vq_w.data();
+    c.vq_x = cartesian ? nullptr : vq_x.data();
+    c.vq_w = cartesian ? nullptr : vq_w.data();
     c.face_in = face_in.data();
     c.face_out = face_out.data();
     c.fq_ptr = fq_ptr.data();
-    c.fq_x = fq_x.data();
-    c.fq_n = fq_n.data();
-    c.fq_w = fq_w.data();
-    c.fq_w_out = fq_w_out.empty() ? nullptr : fq_w_out.data();
+    c.fq_x = cartesian ? nullptr : fq_x.data();
+    c.fq_n = cartesian ? nullptr : fq_n.data();
+    c.fq_w = cartesian ? nullptr : fq_w.data();
+    c.fq_w_out = (cartesian || fq_w_out.empty()) ? nullptr : fq_w_out.data();
     c.face_sigma = face_sigma.data();
     c.rowptr = rowptr.data();
     c.colind = colind.empty() ? nullptr : colind.data();
@@ -1106,6 +1119,19 @@ public:
   {
     flatten_impl(var, F, 0, (int)n_dofs_, false, diag_first, with_colind, nullptr, nullptr, false);
   }
+  // The same description WITHOUT the points: for agglomerates of Cartesian cells (axis-aligned boxes; 3-D) every group of points is
+  // named by its cell (and local face) and generated on the device by pdh_set_problem_cartesian - the gather the reference times
+  // (source/agglomeration_handler.cc:622-707, 1103-1243) leaves the host.  Throws if a cell is not a box.
+  void flatten_cartesian(const SipVariant &var, FlatProblem &F, bool diag_first = true, bool with_colind = false) const
+  {
+    flatten_impl(var, F, 0, (int)n_dofs_, false, diag_first, with_colind, nullptr, nullptr, false, true);
+  }
+  void flatten_local_cartesian(const SipVariant &var, FlatProblem &F, int row_begin, int row_end, bool diag_first = true,
+                               bool with_colind = false, std::vector<int> *local_of = nullptr,
+                               const std::vector<int> *row_splits = nullptr, bool epetra_columns = false) const
+  {
+    flatten_impl(var, F, row_begin, row_end, true, diag_first, with_colind, local_of, row_splits, epetra_columns, true);
+  }
 
   // Rank-local description (pdh_problem::local = 1) of the dof rows [row_begin,row_end): what one MPI rank of the
   // reference holds after setup_ghost_polytopes / the ghost exchanges (source/agglomeration_handler.cc:1026-1091,
@@ -1128,8 +1154,10 @@ public:
   // threads straight into the structure-of-arrays of the description.
   void flatten_impl(const SipVariant &var, FlatProblem &F, int row_begin, int row_end, bool local, bool diag_first,
                     bool with_colind, std::vector<int> *local_of, const std::vector<int> *row_splits,
-                    bool epetra_columns) const
+                    bool epetra_columns, bool cartesian = false) const
   {
+    if (cartesian && tria->dim != 3)
+      throw std::invalid_argument("flatten_cartesian: 3-D only");
     if (!connectivity_ready)
       throw std::logic_error("distribute_agglomerated_dofs must be called first");
     if (nq <= 0 || nqf <= 0)
@@ -1185,11 +1213,46 @@ public:
         F.vq_ptr.push_back(F.vq_ptr.back() + cnt);
       }
     const size_t nqt = (size_t)F.vq_ptr.back();
-    F.vq_w.resize(nqt);
-    F.vq_x.resize(nqt * dim);
+    F.cartesian = cartesian;
+    if (cartesian)
+      { // boxes of all cells (a cell that is not an axis-aligned box ends the attempt), then the cell of every group of volume points
+        const int nc = tria->n_active_cells();
+        F.cart_box.resize((size_t)nc * 6);
+        std::vector<char> bad((size_t)nc, 0);
+        parallel_for((size_t)nc, [&](size_t cell) {
+          const double *v0 = tria->vertex((int)cell, 0), *v7 = tria->vertex((int)cell, 7);
+          for (int c = 0; c < 3; ++c)
+            {
+              F.cart_box[cell * 6 + c] = v0[c];
+              F.cart_box[cell * 6 + 3 + c] = v7[c];
+            }
+          for (int v = 0; v < 8; ++v)
+            for (int c = 0; c < 3; ++c)
+              if (tria->vertex((int)cell, v)[c] != (((v >> c) & 1) ? v7[c] : v0[c]))
+                bad[cell] = 1;
+        });
+        for (char b : bad)
+          if (b)
+            throw std::invalid_argument("flatten_cartesian: a cell is not an axis-aligned box (use flatten)");
+        F.cart_vq_cell.resize(nqt / (size_t)npc);
+        for (int l = 0; l < n_owned; ++l)
+          {
+            size_t g = (size_t)(F.vq_ptr[l] / npc);
+            for (int cell : get_agglomerate(glob[l]))
+              F.cart_vq_cell[g++] = cell;
+          }
+        F.cart.nq = nq;
+        F.cart.nqf = nqf;
+      }
+    else
+      {
+        F.vq_w.resize(nqt);
+        F.vq_x.resize(nqt * dim);
+      }
     std::vector<double> x1, w1, xf1, wf1;
     qgauss_1d_compute(nq, x1, w1);
     qgauss_1d_compute(nqf, xf1, wf1);
+    if (!cartesian)
     parallel_for((size_t)n_owned, [&](size_t l) {
       size_t at = (size_t)F.vq_ptr[l];
       for (int cell : get_agglomerate(glob[l])) // slaves in insertion order, then the master (:622-707)
@@ -1243,10 +1306,27 @@ public:
       }
     F.c.n_faces = (int32_t)F.face_in.size();
     const size_t nft = (size_t)F.fq_ptr.back();
-    F.fq_w.resize(nft);
-    F.fq_w_out.resize(nft);
-    F.fq_x.resize(nft * dim);
-    F.fq_n.resize(nft * dim);
+    if (cartesian)
+      { // (cell, local face) of every sub-face as its owner side I sees it
+        F.cart_fq_cell.resize(nft / (size_t)npf);
+        F.cart_fq_face.resize(nft / (size_t)npf);
+        parallel_for(jobs.size(), [&](size_t j) {
+          size_t s = (size_t)(F.fq_ptr[j] / npf);
+          for (const auto &cf : *jobs[j].li)
+            {
+              F.cart_fq_cell[s] = cf.first;
+              F.cart_fq_face[s++] = cf.second;
+            }
+        });
+      }
+    else
+      {
+        F.fq_w.resize(nft);
+        F.fq_w_out.resize(nft);
+        F.fq_x.resize(nft * dim);
+        F.fq_n.resize(nft * dim);
+      }
+    if (!cartesian)
     parallel_for(jobs.size(), [&](size_t j) {
       const Job &J = jobs[j];
       size_t at = (size_t)F.fq_ptr[j];

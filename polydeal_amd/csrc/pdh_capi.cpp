@@ -81,6 +81,11 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
 extern "C" int pdh_rows_n_dofs(int n1d, int basis);
 extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int count, hipStream_t stream);
 extern "C" int pdh_terms_has_kind(int n1d, int basis);
+extern "C" hipError_t pdh_launch_gen_volume(int nq, const double *nodes, const double *weights, const double *d_box, const int32_t *d_gcell,
+                                            int64_t n_points, double *vq_x, int64_t stride, double *vq_w, hipStream_t stream);
+extern "C" hipError_t pdh_launch_gen_faces(int nqf, const double *nodes, const double *weights, const double *d_box, const int32_t *d_cell,
+                                           const int32_t *d_face, int64_t n_points, double *fq_x, double *fq_n, double *fq_w,
+                                           hipStream_t stream);
 extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell);
 extern "C" int pdh_rows_max_faces(void);
 extern "C" int pdh_moment_table_doubles(int n1d);
@@ -412,8 +417,10 @@ struct Packed
   std::vector<int32_t> run_cnt, run_bdry;
   // per run (owned slots only, same order): owning slot, neighbour polytope (-1 boundary) and the ascending rank of the
   // neighbour's block in the slot's rows, penalty as stored per point - input of the row kernel's face table (pdh_rows.h)
-  std::vector<int32_t> run_slot, run_nbr, run_blk;
+  std::vector<int32_t> run_slot, run_nbr, run_blk, run_face;
   std::vector<double> run_sig;
+  // pdh_set_problem_cartesian: the point arrays of `src` are NULL, the points are generated on the device from these
+  const pdh_cartesian_points *cart = nullptr;
   // host view of a packed face point (what the kernel writes): run r of the owned slots, point q of the run
   const pdh_problem *src = nullptr;
   int64_t nqf_src = 0;
@@ -440,10 +447,12 @@ struct Packed
   std::vector<int64_t> r21_src, r21_dst, r22_ptr, r22_src;
 };
 
-static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end, Packed &K, int exchange_mode = PDH_EXCHANGE_NONE)
+static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end, Packed &K, int exchange_mode = PDH_EXCHANGE_NONE,
+                        const pdh_cartesian_points *cart = nullptr)
 {
   if (!p)
     return fail(ctx, PDH_EINVAL, "problem is NULL");
+  K.cart = cart;
   if (p->dim != 2 && p->dim != 3)
     return fail(ctx, PDH_EINVAL, "dim must be 2 or 3");
   if (p->basis != PDH_BASIS_DGQ && p->basis != PDH_BASIS_AGGLODGP)
@@ -452,10 +461,34 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
     return fail(ctx, PDH_EUNSUPPORTED, "degree must be in [0,7]");
   if (p->n_agg <= 0 || p->n_faces < 0)
     return fail(ctx, PDH_EINVAL, "n_agg must be positive and n_faces non-negative");
-  if (!p->bbox || !p->dof_offset || !p->vq_ptr || !p->vq_x || !p->vq_w || !p->rowptr)
+  if (!p->bbox || !p->dof_offset || !p->vq_ptr || (!cart && (!p->vq_x || !p->vq_w)) || !p->rowptr)
     return fail(ctx, PDH_EINVAL, "a required array is NULL");
-  if (p->n_faces > 0 && (!p->face_in || !p->face_out || !p->fq_ptr || !p->fq_x || !p->fq_n || !p->fq_w || !p->face_sigma))
+  if (p->n_faces > 0 && (!p->face_in || !p->face_out || !p->fq_ptr || (!cart && (!p->fq_x || !p->fq_n || !p->fq_w)) || !p->face_sigma))
     return fail(ctx, PDH_EINVAL, "a required face array is NULL");
+  if (cart)
+    { // compact description of Cartesian cells: the groups of points must be whole rules on valid cells
+      if (p->dim != 3 || cart->nq < 1 || cart->nq > PDH_MAX_N1D || cart->nqf < 1 || cart->nqf > PDH_MAX_N1D)
+        return fail(ctx, PDH_EINVAL, "cartesian description: dim must be 3 and 1 <= nq, nqf <= 8");
+      if (cart->n_cells <= 0 || !cart->cell_box || !cart->vq_cell || (p->n_faces > 0 && (!cart->fq_cell || !cart->fq_face)))
+        return fail(ctx, PDH_EINVAL, "cartesian description: a required array is NULL");
+      const int64_t m3 = (int64_t)cart->nq * cart->nq * cart->nq, m2 = (int64_t)cart->nqf * cart->nqf;
+      for (int a = 0; a < p->n_agg; ++a)
+        if ((p->vq_ptr[a + 1] - p->vq_ptr[a]) % m3)
+          return fail(ctx, PDH_EINVAL, "cartesian description: the volume points of a polytope are not whole groups of nq^3");
+      for (int f = 0; f < p->n_faces; ++f)
+        if ((p->fq_ptr[f + 1] - p->fq_ptr[f]) % m2)
+          return fail(ctx, PDH_EINVAL, "cartesian description: the points of a face are not whole groups of nqf^2");
+      for (int64_t g = 0; g < p->vq_ptr[p->n_agg] / m3; ++g)
+        if (cart->vq_cell[g] < 0 || cart->vq_cell[g] >= cart->n_cells)
+          return fail(ctx, PDH_EINVAL, "cartesian description: vq_cell out of range");
+      for (int64_t g = 0; g < (p->n_faces ? p->fq_ptr[p->n_faces] / m2 : 0); ++g)
+        if (cart->fq_cell[g] < 0 || cart->fq_cell[g] >= cart->n_cells || cart->fq_face[g] < 0 || cart->fq_face[g] > 5)
+          return fail(ctx, PDH_EINVAL, "cartesian description: fq_cell / fq_face out of range");
+      for (int64_t c = 0; c < cart->n_cells; ++c)
+        for (int d = 0; d < 3; ++d)
+          if (!std::isfinite(cart->cell_box[c * 6 + d]) || !(cart->cell_box[c * 6 + 3 + d] > cart->cell_box[c * 6 + d]))
+            return fail(ctx, PDH_EINVAL, "cartesian description: degenerate cell box");
+    }
   const int dim = p->dim;
   const int n = pdh::n_dofs_per_cell(dim, p->degree, p->basis);
   if (n > 64)
@@ -546,6 +579,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
 
   const int64_t nq_tot = p->vq_ptr[nA];
   const int64_t nqf_tot = nF ? p->fq_ptr[nF] : 0;
+  if (!cart) // (generated weights are products of positive box sides and Gauss weights)
   {
     // JxW must be non-negative (and not NaN): chunks of 64k points per task
     const size_t nchunk = (size_t)((nq_tot + nqf_tot) / 65536 + 1);
@@ -748,6 +782,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
           K.run_cnt.push_back((int32_t)(qe - qb));
           K.run_bdry.push_back(other < 0 ? 1 : 0);
           K.run_slot.push_back(slot);
+          K.run_face.push_back(f);
           K.run_nbr.push_back(other);
           {
             int brank = -1;
@@ -897,7 +932,9 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
   for (int sl = 0; sl < K.n_owned && vq_identity; ++sl)
     vq_identity = K.vq_ptr[sl] == p->vq_ptr[K.own_agg[sl]];
   K.n_vq = nvq;
-  if (vq_identity)
+  if (cart)
+    K.vqx_h = K.vqw_h = nullptr, K.vq_stride_h = nvq, vq_identity = true; // (generated on the device, slot by slot)
+  else if (vq_identity)
     K.vqx_h = p->vq_x, K.vqw_h = p->vq_w, K.vq_stride_h = nq_tot;
   else
     {
@@ -1504,11 +1541,20 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
           }
         for (int g = 0; g < ns; ++g, ++at)
           {
-            int c = 0;
-            for (int d = 0; d < 3; ++d)
-              if (std::fabs(K.ap_n(d, t, g * gsz)) > 0.5)
-                c = d;
-            const int pos = K.ap_n(c, t, g * gsz) > 0 ? 1 : 0;
+            int c = 0, pos;
+            if (K.cart)
+              { // local face 2 c + side of the side-0 cell; the owner of this run sees the normal reversed if it is side 1
+                const int lf = K.cart->fq_face[K.pk_fq[t] / gsz + g];
+                c = lf >> 1;
+                pos = ((lf & 1) != 0) == ((K.pk_flags[t] & 1) != 0) ? 1 : 0;
+              }
+            else
+              {
+                for (int d = 0; d < 3; ++d)
+                  if (std::fabs(K.ap_n(d, t, g * gsz)) > 0.5)
+                    c = d;
+                pos = K.ap_n(c, t, g * gsz) > 0 ? 1 : 0;
+              }
             const int fj = RH.fast_j[3 * t + c] == 1 ? 1 : 0;
             T.sf_pt[(size_t)at] = K.run_ap[t] + g * gsz;
             T.sf_info[(size_t)at] = e | (c << 8) | (pos << 10) | (fj << 11);
@@ -1671,13 +1717,50 @@ static int pack_faces_on_device(pdh_ctx *ctx, const pdh_problem *p, const Packed
   };
   const void *d_x = nullptr, *d_n = nullptr, *d_w = nullptr, *d_wo = nullptr, *d_at = nullptr, *d_fq = nullptr, *d_cnt = nullptr,
              *d_fl = nullptr, *d_sg = nullptr;
-  hipError_t e = stage(p->fq_x, (size_t)dim * nqf * sizeof(double), &d_x);
-  if (e == hipSuccess)
-    e = stage(p->fq_n, (size_t)dim * nqf * sizeof(double), &d_n);
-  if (e == hipSuccess)
-    e = stage(p->fq_w, (size_t)nqf * sizeof(double), &d_w);
-  if (e == hipSuccess && p->fq_w_out)
-    e = stage(p->fq_w_out, (size_t)nqf * sizeof(double), &d_wo);
+  hipError_t e = hipSuccess;
+  if (K.cart)
+    { // the caller-order face arrays are generated here from (cell, local face) of every sub-face (pdh_cartgen.hip); JxW of side 1
+      // equals JxW of side 0 on a conforming Cartesian grid (d_wo stays NULL)
+      const pdh_cartesian_points *cp = K.cart;
+      const int64_t nsf = nqf / ((int64_t)cp->nqf * cp->nqf);
+      std::vector<long double> gx, gw;
+      pdh::gauss_legendre01(cp->nqf, gx, gw);
+      double nodes[PDH_MAX_N1D] = {0}, weights[PDH_MAX_N1D] = {0};
+      for (int i = 0; i < cp->nqf; ++i)
+        nodes[i] = (double)gx[i], weights[i] = (double)gw[i];
+      const void *d_box = nullptr, *d_cell = nullptr, *d_face = nullptr;
+      auto alloc = [&](size_t bytes, const void **dptr) -> hipError_t {
+        void *d = nullptr;
+        hipError_t e_ = hipMalloc(&d, std::max<size_t>(bytes, 8));
+        if (e_ == hipSuccess)
+          tmp.push_back(d), *dptr = d;
+        return e_;
+      };
+      e = stage(cp->cell_box, (size_t)cp->n_cells * 6 * sizeof(double), &d_box);
+      if (e == hipSuccess)
+        e = stage(cp->fq_cell, (size_t)nsf * sizeof(int32_t), &d_cell);
+      if (e == hipSuccess)
+        e = stage(cp->fq_face, (size_t)nsf * sizeof(int32_t), &d_face);
+      if (e == hipSuccess)
+        e = alloc((size_t)dim * nqf * sizeof(double), &d_x);
+      if (e == hipSuccess)
+        e = alloc((size_t)dim * nqf * sizeof(double), &d_n);
+      if (e == hipSuccess)
+        e = alloc((size_t)nqf * sizeof(double), &d_w);
+      if (e == hipSuccess)
+        e = pdh_launch_gen_faces(cp->nqf, nodes, weights, (const double *)d_box, (const int32_t *)d_cell, (const int32_t *)d_face, nqf,
+                                 (double *)d_x, (double *)d_n, (double *)d_w, ctx->stream);
+    }
+  else
+    {
+      e = stage(p->fq_x, (size_t)dim * nqf * sizeof(double), &d_x);
+      if (e == hipSuccess)
+        e = stage(p->fq_n, (size_t)dim * nqf * sizeof(double), &d_n);
+      if (e == hipSuccess)
+        e = stage(p->fq_w, (size_t)nqf * sizeof(double), &d_w);
+      if (e == hipSuccess && p->fq_w_out)
+        e = stage(p->fq_w_out, (size_t)nqf * sizeof(double), &d_wo);
+    }
   if (e == hipSuccess)
     e = stage(K.pk_at.data(), K.pk_at.size() * sizeof(int64_t), &d_at);
   if (e == hipSuccess)
@@ -1701,10 +1784,27 @@ static int pack_faces_on_device(pdh_ctx *ctx, const pdh_problem *p, const Packed
   return PDH_OK;
 }
 
+static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end, const pdh_cartesian_points *cart);
+
 extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end)
+{
+  return set_problem_impl(ctx, p, row_begin, row_end, nullptr);
+}
+
+extern "C" int pdh_set_problem_cartesian(pdh_ctx *ctx, const pdh_problem *p, const pdh_cartesian_points *points, int32_t row_begin,
+                                         int32_t row_end)
+{
+  if (!points)
+    return fail(ctx, PDH_EINVAL, "points is NULL");
+  return set_problem_impl(ctx, p, row_begin, row_end, points);
+}
+
+static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, int32_t row_end, const pdh_cartesian_points *cart)
 {
   if (!ctx)
     return fail(nullptr, PDH_EINVAL, "ctx is NULL");
+  if (cart && ctx->exchange_mode == PDH_EXCHANGE_GHOST)
+    return fail(ctx, PDH_EUNSUPPORTED, "the cartesian description runs owner-computes-rows only (no ghost-block exchange)");
   PDH_HIP(ctx, hipSetDevice(ctx->device));
   PDH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_problem(ctx);
@@ -1721,7 +1821,7 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   lap("wait for the stream, free the old problem");
   std::unique_ptr<Packed> K_owner(new Packed);
   Packed &K = *K_owner;
-  int rc = pack_problem(ctx, p, row_begin, row_end, K, ctx->exchange_mode);
+  int rc = pack_problem(ctx, p, row_begin, row_end, K, ctx->exchange_mode, cart);
   if (rc != PDH_OK)
     return rc;
   lap("validate + repack (host)");
@@ -1744,8 +1844,58 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   PDH_UP(bbox, bbox)
   PDH_UP(K.midx, midx)
   PDH_UP(K.vq_ptr, vq_ptr)
-  if ((rc = upload_n(ctx, K.vqx_h, (size_t)p->dim * K.vq_stride_h, &D.vq_x)) != PDH_OK ||
-      (rc = upload_n(ctx, K.vqw_h, (size_t)K.n_vq, &D.vq_w)) != PDH_OK)
+  if (cart)
+    { // volume points: generated slot by slot from the cells' boxes (pdh_cartgen.hip)
+      const int64_t m3 = (int64_t)cart->nq * cart->nq * cart->nq, ngroups = K.n_vq / m3;
+      std::vector<int32_t> gcell((size_t)std::max<int64_t>(ngroups, 1));
+      for (int sl = 0; sl < K.n_owned; ++sl)
+        {
+          const int64_t g0 = K.vq_ptr[sl] / m3, g1 = K.vq_ptr[sl + 1] / m3, src = K.vq_src[sl] / m3;
+          for (int64_t g = g0; g < g1; ++g)
+            gcell[(size_t)g] = cart->vq_cell[src + (g - g0)];
+        }
+      std::vector<long double> gx, gw;
+      pdh::gauss_legendre01(cart->nq, gx, gw);
+      double nodes[PDH_MAX_N1D] = {0}, weights[PDH_MAX_N1D] = {0};
+      for (int i = 0; i < cart->nq; ++i)
+        nodes[i] = (double)gx[i], weights[i] = (double)gw[i];
+      void *dx = nullptr, *dw = nullptr, *dbox = nullptr, *dgc = nullptr;
+      hipError_t eg = hipMalloc(&dx, std::max<size_t>((size_t)3 * K.n_vq, 1) * sizeof(double));
+      if (eg == hipSuccess)
+        {
+          ctx->allocs.push_back(dx);
+          eg = hipMalloc(&dw, std::max<size_t>((size_t)K.n_vq, 1) * sizeof(double));
+        }
+      if (eg == hipSuccess)
+        {
+          ctx->allocs.push_back(dw);
+          eg = hipMalloc(&dbox, (size_t)cart->n_cells * 6 * sizeof(double));
+        }
+      if (eg == hipSuccess)
+        eg = hipMalloc(&dgc, gcell.size() * sizeof(int32_t));
+      if (eg == hipSuccess)
+        eg = hipMemcpy(dbox, cart->cell_box, (size_t)cart->n_cells * 6 * sizeof(double), hipMemcpyHostToDevice);
+      if (eg == hipSuccess)
+        eg = hipMemcpy(dgc, gcell.data(), gcell.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+      if (eg == hipSuccess)
+        eg = pdh_launch_gen_volume(cart->nq, nodes, weights, (const double *)dbox, (const int32_t *)dgc, K.n_vq, (double *)dx, K.n_vq,
+                                   (double *)dw, ctx->stream);
+      if (eg == hipSuccess)
+        eg = hipStreamSynchronize(ctx->stream);
+      if (dbox)
+        (void)hipFree(dbox);
+      if (dgc)
+        (void)hipFree(dgc);
+      if (eg != hipSuccess)
+        {
+          free_problem(ctx);
+          return fail(ctx, PDH_EDEVICE, std::string("cartesian description: ") + hipGetErrorString(eg));
+        }
+      D.vq_x = static_cast<const double *>(dx);
+      D.vq_w = static_cast<const double *>(dw);
+    }
+  else if ((rc = upload_n(ctx, K.vqx_h, (size_t)p->dim * K.vq_stride_h, &D.vq_x)) != PDH_OK ||
+           (rc = upload_n(ctx, K.vqw_h, (size_t)K.n_vq, &D.vq_w)) != PDH_OK)
     {
       free_problem(ctx);
       return rc;
@@ -1876,8 +2026,17 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
   if (ctx->d_mtab && !ctx->problem_ghost)
     {
       RowsHost RH;
-      const bool rows_built = build_rows_tables(p, K, RH);
+      // (cartesian description: planar axis-aligned faces and tensor rules hold by construction - and there are no host copies of
+      // the points to look at: the kinds of pdh_rows.h, whose tables are made from the points, are not offered)
+      const bool rows_built = cart ? false : build_rows_tables(p, K, RH);
       int vq_n_terms = -1; // (not looked at yet)
+      if (cart)
+        {
+          RH.planar_ok = true;
+          RH.fq_tensor_n = cart->nqf;
+          RH.fast_j.assign(3 * K.run_ap.size(), 0); // (the generator runs the lower tangential axis fastest)
+          vq_n_terms = cart->nq;
+        }
       if (rows_built)
         {
           lap("row kernel: planes + records");
@@ -1966,7 +2125,8 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
       // while pdh_rows.h is the measured default for that element)
       const int terms_kind = pdh_terms_has_kind(K.n1d, p->basis == PDH_BASIS_AGGLODGP ? 1 : 0);
       const char *terms_q3 = getenv("PDH_TERMS_DGQ3");
-      if (terms_env && RH.planar_ok && RH.fq_tensor_n > 0 && (terms_kind == 1 || (terms_kind == 2 && terms_q3 && terms_q3[0] == '1')))
+      if ((terms_env || cart) && RH.planar_ok && RH.fq_tensor_n > 0 &&
+          (terms_kind == 1 || (terms_kind == 2 && (cart || (terms_q3 && terms_q3[0] == '1')))))
         {
           if (vq_n_terms < 0)
             vq_n_terms = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
@@ -1999,6 +2159,12 @@ extern "C" int pdh_set_problem_local(pdh_ctx *ctx, const pdh_problem *p, int32_t
               lap("term kernel: tables + upload");
             }
         }
+    }
+  if (cart && !ctx->terms_ok)
+    {
+      free_problem(ctx);
+      return fail(ctx, PDH_EUNSUPPORTED, "cartesian description: the term kernels do not apply (a polytope's tables exceed their LDS budget, "
+                                         "or the element has none): describe the problem with its points (pdh_set_problem)");
     }
   ctx->has_problem = true;
   ctx->ev_used = 0;

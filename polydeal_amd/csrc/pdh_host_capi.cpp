@@ -364,13 +364,50 @@ void *pdhh_flatten_local(void *h, double penalty_constant, int owner_rule, int h
       return nullptr;
     }
 }
+// The description without the points (agglomerates of Cartesian cells): pdh_problem with NULL point arrays + pdh_cartesian_points
+// (pdhh_flat_cartesian), for pdh_set_problem_cartesian.  row_end <= row_begin: all rows (global description).
+void *pdhh_flatten_cartesian(void *h, double penalty_constant, int owner_rule, int h_rule, int boundary, double reaction_c,
+                             int diag_first, int with_colind, int row_begin, int row_end, const int32_t *row_splits, int n_ranks)
+{
+  try
+    {
+      SipVariant v;
+      v.penalty_constant = penalty_constant;
+      v.owner_rule = owner_rule;
+      v.h_rule = h_rule;
+      v.boundary = boundary;
+      v.reaction_c = reaction_c;
+      std::unique_ptr<FlatH> F(new FlatH);
+      if (row_end <= row_begin)
+        AH.flatten_cartesian(v, F->flat, diag_first != 0, with_colind != 0);
+      else
+        {
+          std::vector<int> splits;
+          if (row_splits)
+            splits.assign(row_splits, row_splits + n_ranks + 1);
+          AH.flatten_local_cartesian(v, F->flat, row_begin, row_end, diag_first != 0, with_colind != 0, &F->local_of,
+                                     row_splits ? &splits : nullptr, false);
+        }
+      return F.release();
+    }
+  catch (const std::exception &e)
+    {
+      g_host_err = e.what();
+      return nullptr;
+    }
+}
+const pdh_cartesian_points *pdhh_flat_cartesian(void *fh)
+{
+  FlatH *H = static_cast<FlatH *>(fh);
+  return H->flat.cartesian ? &H->flat.cart : nullptr;
+}
 const pdh_problem *pdhh_flat_problem(void *fh) { return &static_cast<FlatH *>(fh)->flat.c; }
 void pdhh_flat_destroy(void *fh) { delete static_cast<FlatH *>(fh); }
 int64_t pdhh_flat_sizes(void *fh, int64_t *out /*[4]: Nq_tot, Nqf_tot, nnz, n_faces*/)
 {
   FlatH *H = static_cast<FlatH *>(fh);
-  out[0] = (int64_t)H->flat.vq_w.size();
-  out[1] = (int64_t)H->flat.fq_w.size();
+  out[0] = H->flat.vq_ptr.empty() ? 0 : H->flat.vq_ptr.back();
+  out[1] = H->flat.fq_ptr.empty() ? 0 : H->flat.fq_ptr.back();
   out[2] = H->flat.rowptr.empty() ? 0 : H->flat.rowptr.back();
   out[3] = (int64_t)H->flat.face_in.size();
   return 0;

@@ -29,6 +29,11 @@ def _lib():
         lib.pdhh_grid_n_cells.argtypes = [C.c_void_p]
         lib.pdhh_grid_distort.argtypes = [C.c_void_p, C.c_double, C.c_uint]
         lib.pdhh_blocks_per_row.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pdhh_flatten_cartesian.restype = C.c_void_p
+        lib.pdhh_flatten_cartesian.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_int]
+        lib.pdhh_flat_cartesian.restype = C.c_void_p
+        lib.pdhh_flat_cartesian.argtypes = [C.c_void_p]
         lib.pdhh_grid_vertices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.pdhh_handler_create.restype = C.c_void_p
         lib.pdhh_handler_create.argtypes = [C.c_void_p]
@@ -235,6 +240,7 @@ class FlatView:
         _lib().pdhh_flat_sizes(fh, sizes)
         self.nq_tot, self.nqf_tot, self.nnz, self.n_faces = [int(x) for x in sizes]
         self.local = bool(self.c.local)
+        self.cartesian = _lib().pdhh_flat_cartesian(fh)  # address of the pdh_cartesian_points of a flatten_cartesian view, or None
 
     @property
     def n_local_rows(self):
@@ -422,6 +428,21 @@ class AgglomerationHandler:
         if not p:
             _raise()
         return FlatView(p)
+
+    def flatten_cartesian(self, variant: SipVariant, diag_first=True, with_colind=False, row_begin=0, row_end=0, row_splits=None) -> FlatView:
+        """The description WITHOUT the points (agglomerates of Cartesian cells, 3-D): every group of quadrature points is named by its
+        cell (and local face); Context.set_problem takes the view and has the points generated on the device
+        (pdh_set_problem_cartesian).  row_end > row_begin: rank-local description of those rows."""
+        rs = None if row_splits is None else np.ascontiguousarray(row_splits, dtype=np.int32)
+        p = _lib().pdhh_flatten_cartesian(self.h, variant.penalty_constant, variant.owner_rule, variant.h_rule, variant.boundary,
+                                          variant.reaction_c, int(diag_first), int(with_colind), int(row_begin), int(row_end),
+                                          None if rs is None else rs.ctypes.data, 0 if rs is None else len(rs) - 1)
+        if not p:
+            _raise()
+        v = FlatView(p)
+        if row_end > row_begin:
+            v._n_local_rows = row_end - row_begin
+        return v
 
     def flatten_local(self, variant: SipVariant, row_begin, row_end, diag_first=True, with_colind=False, row_splits=None,
                       epetra_columns=False) -> FlatView:
