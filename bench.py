@@ -299,6 +299,44 @@ def time_aux_kernels(torch, ctx, flat, n, stats):
                                           "(incl. the 16 B per polytope copied back and the stream synchronisation)"}}
 
 
+def end_to_end(pa, args):
+    """What a caller that assembles ONCE per mesh sees (every example of the reference does): the gather of the quadrature data
+    (source/agglomeration_handler.cc:622-707 agglomerated_quadrature, :1103-1243 reinit_master - inside the span the reference
+    times, examples/poisson.cc:1099-1106, and inside the CPU baseline's span) + the library's set-up + one assembly, for the headline
+    problem.  Two ways to hand the problem over: with its points (flatten: the host mirror gathers 29 M points, the library checks
+    and uploads them) and without them (flatten_cartesian + pdh_set_problem_cartesian: groups of points named by cell and local
+    face, generated on the device).  The agglomeration handler itself (define_agglomerate, connectivity, dof numbering: set-up in
+    the reference too) is timed apart."""
+    out = {}
+    t0 = time.perf_counter()
+    grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, args.fe, args.degree, args.degree + 1)
+    out["handler_s"] = time.perf_counter() - t0
+    var = make_variant(pa, args.variant, fe)
+    for name in ("points", "cartesian"):
+        best = None
+        for rep in range(2):
+            ctx = pa.Context(0)
+            t1 = time.perf_counter()
+            flat = ah.flatten(var, True, False) if name == "points" else ah.flatten_cartesian(var, True, False)
+            t2 = time.perf_counter()
+            ctx.set_problem(flat)
+            t3 = time.perf_counter()
+            ctx.assemble_device()
+            ctx.synchronize()
+            t4 = time.perf_counter()
+            cs = ctx.checksum()
+            rec = {"describe_s": t2 - t1, "set_problem_s": t3 - t2, "first_assembly_s": t4 - t3, "total_s": t4 - t1,
+                   "value": ah.n_dofs / (t4 - t1), "rows_kernel": ctx.rows_kernel_in_use(), "checksum_sum": cs["sum"],
+                   "non_finite": cs["non_finite"]}
+            ctx.close()
+            del flat
+            if best is None or rec["total_s"] < best["total_s"]:
+                best = rec
+        out[name] = best
+    out["unit"] = "DoF/s = n_dofs / (describe + set_problem + first assembly), best of 2; handler_s not included"
+    return out
+
+
 def strong_proxy(pa, args, steps):
     """Strong-scaling readiness measured on ONE device (last bullet: at ~2 k polytopes per GPU occupancy, not xGMI, is
     the risk): the share of rank 0 in an N-rank strong-scaling run - the first 1/N of the rows, with its ghost neighbours - timed
@@ -629,6 +667,11 @@ def main():
                 "algorithmic_bytes_per_step": by8, "frac_of_hbm_peak": by8 / t8 * 1e-9 / HBM_PEAK_GBS, "checksum": r8["checksum"]}
         except Exception as exc:
             extra["distorted"] = {"error": repr(exc)}
+    if world == 1 and not args.no_extra and args.dim == 3:
+        try:
+            extra["end_to_end"] = end_to_end(pa, args)
+        except Exception as exc:
+            extra["end_to_end"] = {"error": repr(exc)}
     if world == 1 and args.strong_proxy and not args.no_extra:
         try:
             extra["strong_proxy"] = strong_proxy(pa, args, max(5, args.steps))

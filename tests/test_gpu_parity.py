@@ -1699,3 +1699,97 @@ def test_row_kernel_staircase_rank_local_descriptions(world, basis, p):
         want = gvals[orp[r0]:orp[r1]]
         assert v.shape == want.shape
         assert np.max(np.abs(v - want)) <= 1e-13 * np.max(np.abs(gvals))
+
+
+@pytest.mark.parametrize("basis,p", [("dgp", 3), ("dgq", 3), ("dgq", 2), ("dgp", 2), ("dgq", 1), ("dgp", 1)])
+@pytest.mark.parametrize("kind,cells,per,vname,diag_first,nq", [("block", 4, 2, "poisson", True, 0), ("grown", 6, 6, "dr", False, 0), ("grown", 8, 8, "adm", True, 0),
+                                                                ("block", 6, 3, "minsip", True, 0), ("block", 4, 2, "test", False, 7)])
+def test_cartesian_description_points_generated_on_device(kind, cells, per, vname, diag_first, nq, basis, p):
+    """pdh_set_problem_cartesian: the PRODUCT mirror describes the agglomerates of Cartesian cells without their quadrature points
+    (every group of points named by its cell and local face), the points are generated on the device - the gather the reference
+    times (source/agglomeration_handler.cc:622-707, 1103-1243).  Values against the oracle per block (own mesh + agglomerates
+    rebuilt there), against the points-based description to rounding, and on row ranges with rank-local descriptions."""
+    import polydeal_amd as pa
+    from polydeal_amd.partition import row_range
+
+    nq = nq or p + 1
+    grid = pa.BackgroundGrid.subdivided_hyper_cube(3, cells, 0.0, 1.0)
+    ah = pa.AgglomerationHandler(grid)
+    if kind == "block":
+        ah.define_block_agglomerates(per)
+    else:
+        ah.define_grown_agglomerates(per, seed=cells)
+    fe = (pa.FE_DGQ if basis == "dgq" else pa.FE_AggloDGP)(3, p)
+    ah.initialize_fe_values(nq, nq)
+    ah.distribute_agglomerated_dofs(fe)
+    var = {"poisson": pa.SipVariant.poisson_example(fe), "dr": pa.SipVariant.diffusion_reaction(fe), "adm": pa.SipVariant.assemble_dg_matrix(),
+           "minsip": pa.SipVariant.minimal_sip_example(), "test": pa.SipVariant.minimal_sip_test()}[vname]
+    n, nA = fe.n_dofs_per_cell, ah.n_agglomerates
+    cf = ah.flatten_cartesian(var, diag_first, True)
+    assert cf.cartesian and cf.c.vq_x is None and cf.c.fq_x is None
+    ctx = pa.Context(0)
+    ctx.set_problem(cf)
+    assert ctx.algorithm_in_use() == "rows" and ctx.rows_kernel_in_use() == "terms"
+    vals = ctx.assemble()
+    ctx.close()
+    # the same problem described with its points
+    pf = ah.flatten(var, diag_first, True)
+    ca, pa_ = cf.arrays(), pf.arrays()
+    for key in ("bbox", "dof_offset", "vq_ptr", "face_in", "face_out", "fq_ptr", "face_sigma", "rowptr", "colind"):
+        assert np.array_equal(ca[key], pa_[key]), key
+    ctx = pa.Context(0)
+    ctx.set_problem(pf)
+    vpts = ctx.assemble()
+    ctx.close()
+    assert np.max(np.abs(vals - vpts)) <= 1e-13 * np.max(np.abs(vpts))
+    # the oracle on the same agglomerates
+    og = po.subdivided_hyper_cube(3, cells, 0.0, 1.0)
+    oah = po.AgglomerationHandler(og)
+    for P in range(nA):
+        c_ = ah.get_agglomerate(P)
+        oah.define_agglomerate([c_[-1]] + c_[:-1])
+    ofe = po.FE_DGQ(3, p) if basis == "dgq" else po.FE_AggloDGP(3, p)
+    oah.initialize_fe_values(nq, nq)
+    oah.distribute_agglomerated_dofs(ofe)
+    orp, oci, ref = po.assemble_csr(oah, variant(vname, ofe), diag_first=diag_first)
+    assert np.array_equal(ca["rowptr"], orp) and np.array_equal(ca["colind"], oci)
+    assert_parity(vals, ref, orp, oci, n)
+    # rank-local compact descriptions of two row ranges reproduce the rows
+    splits = [row_range(nA, n, r, 2)[0] for r in range(2)] + [ah.n_dofs]
+    for r in range(2):
+        loc = ah.flatten_cartesian(var, diag_first, False, splits[r], splits[r + 1], splits)
+        ctx = pa.Context(0)
+        ctx.set_problem(loc, splits[r], splits[r + 1])
+        v = ctx.assemble()
+        ctx.close()
+        want = vals[orp[splits[r]]:orp[splits[r + 1]]]
+        assert v.shape == want.shape and np.max(np.abs(v - want)) <= 1e-13 * np.max(np.abs(vals))
+
+
+def test_cartesian_description_refuses_what_it_cannot_describe():
+    """A distorted grid has no boxes (the mirror refuses to write the compact description); polytopes whose tables exceed the term
+    kernels' LDS budget are refused by the library with PDH_EUNSUPPORTED and a message that says what to do."""
+    import polydeal_amd as pa
+
+    grid = pa.BackgroundGrid.subdivided_hyper_cube(3, 4, 0.0, 1.0)
+    grid.distort(0.1, 1)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_block_agglomerates(2)
+    fe = pa.FE_AggloDGP(3, 2)
+    ah.initialize_fe_values(3, 3)
+    ah.distribute_agglomerated_dofs(fe)
+    with pytest.raises(Exception, match="box"):
+        ah.flatten_cartesian(pa.SipVariant.poisson_example(fe))
+    grid = pa.BackgroundGrid.subdivided_hyper_cube(3, 8, 0.0, 1.0)
+    ah = pa.AgglomerationHandler(grid)
+    ah.define_block_agglomerates(4)  # 64 cells, up to 96 sub-faces per polytope
+    fe = pa.FE_DGQ(3, 3)
+    ah.initialize_fe_values(4, 4)
+    ah.distribute_agglomerated_dofs(fe)
+    cf = ah.flatten_cartesian(pa.SipVariant.poisson_example(fe))
+    ctx = pa.Context(0)
+    with pytest.raises(pa.PdhError, match="points"):
+        ctx.set_problem(cf)
+    ctx.set_problem(ah.flatten(pa.SipVariant.poisson_example(fe)))  # the context is still usable; the points-based path takes it
+    assert ctx.algorithm_in_use() == "rows"
+    ctx.close()
