@@ -86,7 +86,7 @@ extern "C" hipError_t pdh_launch_gen_volume(int nq, const double *nodes, const d
 extern "C" hipError_t pdh_launch_gen_faces(int nqf, const double *nodes, const double *weights, const double *d_box, const int32_t *d_cell,
                                            const int32_t *d_face, int64_t n_points, double *fq_x, double *fq_n, double *fq_w,
                                            hipStream_t stream);
-extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell);
+extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell, int split);
 extern "C" int pdh_rows_max_faces(void);
 extern "C" int pdh_moment_table_doubles(int n1d);
 
@@ -1444,7 +1444,7 @@ struct TermsHost
   std::vector<double> meta;
   std::vector<int64_t> sf_pt;
   std::vector<int32_t> sf_info;
-  int maxruns = 0, maxsf = 0, maxsi = 0, maxcell = 0, lds_bytes = 0;
+  int maxruns = 0, maxsf = 0, maxsi = 0, maxcell = 0, lds_bytes = 0, split = 0;
 };
 static constexpr int PDH_TERMS_LDS_CAP = 40 * 1024; // bytes per workgroup: four resident waves per CU at least
 static bool build_terms_tables(const pdh_problem *p, const Packed &K, const RowsHost &RH, int vq_n, TermsHost &T, std::string *why = nullptr)
@@ -1498,7 +1498,21 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
       return no("run bookkeeping");
   }
   T.maxruns = std::max(T.maxruns, 1);
-  T.lds_bytes = pdh_terms_lds_bytes(K.n1d, basis, T.maxruns, T.maxsf, T.maxsi, T.maxcell);
+  {
+    // one pass or two (pdh_terms.h: SPLIT): whichever lets more single-wave workgroups stay resident on a CU - by LDS (160 KB in
+    // granules of 1280 bytes), capped by the 12 waves the kernels' registers allow; a tie goes to the single pass (fewer
+    // instructions), and so does FE_DGQ(2): with 27 functions its phases are bound by VALU issue rather than by latency, and the
+    // second evaluation of the bases costs more than three more waves give (grown agglomerates of the bench cells: 0.79 ms in one
+    // pass at 6 waves, 0.83 in two at 9; FE_AggloDGP(3) 0.71 -> 0.59, FE_AggloDGP(2) 0.29 -> 0.24: profiles/r04_terms_split.txt)
+    const int one = pdh_terms_lds_bytes(K.n1d, basis, T.maxruns, T.maxsf, T.maxsi, T.maxcell, 0);
+    const int two = pdh_terms_lds_bytes(K.n1d, basis, T.maxruns, T.maxsf, T.maxsi, T.maxcell, 1);
+    auto waves = [](int bytes) { return bytes <= 0 ? 0 : std::min(12, (int)(160 * 1024 / (((int64_t)bytes + 1279) / 1280 * 1280))); };
+    const char *fs = getenv("PDH_TERMS_SPLIT"); // (diagnostics: 0 / 1 forces the form)
+    T.split = fs ? (fs[0] == '1') : ((waves(two) > waves(one) && K.n <= 20) ? 1 : 0);
+    if (pdh_terms_has_kind(K.n1d, basis) == 2)
+      T.split = 0; // (workgroup kernel: no such form)
+    T.lds_bytes = T.split ? two : one;
+  }
   if (T.lds_bytes <= 0 || T.lds_bytes > PDH_TERMS_LDS_CAP)
     return no("term kernel: the tables of the largest polytope do not fit its LDS budget (moment-based kinds take over)");
   constexpr int HDR = 12, ENT = 10;
@@ -2143,6 +2157,7 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
               T.maxruns = TH.maxruns, T.maxsf = TH.maxsf, T.maxsi = TH.maxsi, T.maxcell = TH.maxcell;
               T.vq_tensor_n = vq_n_terms, T.fq_tensor_n = RH.fq_tensor_n;
               T.lds_bytes = TH.lds_bytes;
+              T.split = TH.split;
               {
                 void *ds = nullptr;
                 const size_t nb = (size_t)std::max(K.n_owned, 1) * 16 * sizeof(long long);

@@ -86,15 +86,27 @@ struct Kind
 
 // LDS of a workgroup in doubles (host and device agree through this one function)
 __host__ __device__ constexpr int terms_rec_doubles(int maxruns) { return (TERMS_HDR + maxruns * TERMS_ENT + 1) & ~1; }
+// Two-phase tables (SPLIT): the D / M / K tables are needed by the diagonal block only, the X tables by the row pieces only.  Made
+// in one pass they cost FE_AggloDGP(3) on block polytopes 21 KB of LDS per wave = 7 resident waves per CU, 30-40 KB on METIS-like
+// agglomerates, and the kernel runs at the speed its occupancy allows; made one after the other - the X tables from the point data
+// still held in registers, behind the finished block - 13.7 KB = 11 waves, for 250 more VALU instructions per polytope (the bases
+// at the tangential points are evaluated twice): 0.384 -> 0.373 ms on the bench mesh, 0.71 -> 0.56 ms on its grown agglomerates
+// (profiles/r04_terms_split.txt).  The host takes the form that gives a polytope's workgroup more resident waves (PdhTerms::split).
 // (BLOCK_IN_LDS: the wave-per-polytope kernel leaves the diagonal block in LDS over the dead tables; the workgroup kernel of
 // pdh_terms_wg.h stores it from registers)
-template <int N1D, int BASIS, bool BLOCK_IN_LDS = true>
+template <int N1D, int BASIS, bool BLOCK_IN_LDS = true, bool SPLIT = false>
 __host__ __device__ constexpr int terms_lds_doubles(int maxruns, int maxsf, int maxsi, int maxcell)
 {
   using K = Kind<N1D, BASIS>;
   const int dg = (K::NF + 1) / 2 + ((K::NF + 1) / 2 & 1);
   const int xa = maxsi * 3 * K::FULLS + ((maxsi * 3 * K::FULLS) & 1);
   int da = maxsf * 3 * K::SYMS + maxcell * 6 * K::SYMS;
+  if (BLOCK_IN_LDS && SPLIT)
+    { // the X tables are made after the diagonal block and stand BEHIND it, over the D tables (dead by then)
+      const int xb = K::NF * K::NF + xa;
+      da = da > xb ? da : xb;
+      return terms_rec_doubles(maxruns) + dg + da + (da & 1);
+    }
   if (BLOCK_IN_LDS)
     da = da > K::NF * K::NF ? da : K::NF * K::NF;
   return terms_rec_doubles(maxruns) + dg + xa + da + (da & 1);
@@ -163,6 +175,9 @@ struct TermTasks
     });
     return r;
   }
+  // WANT_D / WANT_X: which of the two kinds of table a call produces (both by default; the kernel of FE_AggloDGP(3) makes them in
+  // two phases so that the X tables can take the place of the D tables in LDS)
+  template <bool WANT_D = true, bool WANT_X = true>
   __device__ __forceinline__ void tang_compute(const TPts &r, int sf, int dir, int info) const
   {
     const int run = info & 0xff, c = (info >> 8) & 3;
@@ -188,15 +203,20 @@ struct TermTasks
           static_for<0, N1D>([&](auto k_) {
             constexpr int k = k_;
             const double ws = wS * bp[k], wc = wC * bp[k];
-            static_for<k, N1D>([&](auto l_) { Dm[K::sym(k, l_)] += ws * bp[l_]; });
-            static_for<0, N1D>([&](auto l_) { Xm[l_ * N1D + k] += wc * bq[l_]; });
+            if constexpr (WANT_D)
+              static_for<k, N1D>([&](auto l_) { Dm[K::sym(k, l_)] += ws * bp[l_]; });
+            if constexpr (WANT_X)
+              static_for<0, N1D>([&](auto l_) { Xm[l_ * N1D + k] += wc * bq[l_]; });
           });
         }
     });
-    double *dd = Da + (sf * 3 + ax) * SYMS;
-    for (int i = 0; i < NSYM; ++i)
-      dd[i] = Dm[i];
-    if (interior)
+    if constexpr (WANT_D)
+      {
+        double *dd = Da + (sf * 3 + ax) * SYMS;
+        for (int i = 0; i < NSYM; ++i)
+          dd[i] = Dm[i];
+      }
+    if (WANT_X && interior)
       {
         double *xd = Xa + ((sf - nsfb) * 3 + ax) * FULLS;
         for (int i = 0; i < FULL; ++i)
@@ -204,6 +224,7 @@ struct TermTasks
       }
   }
   // (sub-face, normal direction): D_c and X_c at the plane
+  template <bool WANT_D = true, bool WANT_X = true>
   __device__ __forceinline__ void norm_compute(double zeta, int sf, int info) const
   {
     const int run = info & 0xff, c = (info >> 8) & 3;
@@ -221,11 +242,12 @@ struct TermTasks
     const double hs = 0.5 * sg * ih_c, hq = 0.5 * sg * ihq;
     static_for<0, N1D>([&](auto k_) {
       constexpr int k = k_;
-      static_for<k, N1D>([&](auto l_) {
-        constexpr int l = l_;
-        dd[K::sym(k, l)] = sig * bp[k] * bp[l] - hs * (dp[k] * bp[l] + bp[k] * dp[l]);
-      });
-      if (interior)
+      if constexpr (WANT_D)
+        static_for<k, N1D>([&](auto l_) {
+          constexpr int l = l_;
+          dd[K::sym(k, l)] = sig * bp[k] * bp[l] - hs * (dp[k] * bp[l] + bp[k] * dp[l]);
+        });
+      if (WANT_X && interior)
         static_for<0, N1D>([&](auto l_) {
           constexpr int l = l_;
           xd[l * N1D + k] = (hs * dp[k] - sig * bp[k]) * bq[l] - hq * bp[k] * dq[l];
@@ -286,7 +308,7 @@ struct TermTasks
 };
 
 // PMAX: most points per direction of a rule the instantiation takes (4 or 8): the point data of a lane task sit in registers
-template <int N1D, int BASIS, bool SHIFTED, int PMAX>
+template <int N1D, int BASIS, bool SHIFTED, int PMAX, bool SPLIT>
 __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const PdhTerms T, const int n_owned)
 {
   using K = Kind<N1D, BASIS>;
@@ -300,8 +322,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
   const int REC = TERMS_HDR + T.maxruns * TERMS_ENT;
   double *rec = lds;
   int *dig = reinterpret_cast<int *>(lds + terms_rec_doubles(T.maxruns));
+  // (SPLIT: X tables in a second pass, behind the diagonal block - see above)
   double *Xa = lds + terms_rec_doubles(T.maxruns) + ((NF + 1) / 2 + ((NF + 1) / 2 & 1));
-  double *Da = Xa + (T.maxsi * 3 * FULLS + ((T.maxsi * 3 * FULLS) & 1));
+  double *Da = SPLIT ? Xa : Xa + (T.maxsi * 3 * FULLS + ((T.maxsi * 3 * FULLS) & 1));
+  if constexpr (SPLIT)
+    Xa = Da + NF * NF;
   auto sel3 = [](int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); };
   // ---- level 1 of the loads: header (uniform address: scalar loads), run entries (-> LDS), sub-face descriptors of the first
   // round of lane tasks of either kind.  The descriptors of a polytope stand at a fixed stride (maxsf per polytope), so nothing
@@ -359,8 +384,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
   using CPts = typename TT::CPts;
   const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, vq_b};
   auto tang_load = [&](int info, int64_t pb, int dir) { return tt.tang_load(info, pb, dir); };
-  auto tang_compute = [&](const TPts &r, int sf, int dir, int info) { tt.tang_compute(r, sf, dir, info); };
-  auto norm_compute = [&](double zeta, int sf, int info) { tt.norm_compute(zeta, sf, info); };
+  auto tang_compute = [&](const TPts &r, int sf, int dir, int info) { tt.template tang_compute<true, !SPLIT>(r, sf, dir, info); };
+  auto norm_compute = [&](double zeta, int sf, int info) { tt.template norm_compute<true, !SPLIT>(zeta, sf, info); };
   auto cell_load = [&](int ct) { return tt.cell_load(ct); };
   auto cell_compute = [&](const CPts &r, int ct) { tt.cell_compute(r, ct); };
   PDHT_MARK(1);
@@ -492,6 +517,39 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
     PDH_WAVE_SYNC();
   }
 
+  if constexpr (SPLIT)
+    {
+      // ---- second pass of the lane tasks: the X tables, from the point data of the first round still in registers (later rounds:
+      // loaded again), into the space behind the block
+      if (lane < 2 * nsf)
+        tt.template tang_compute<false, true>(tp0, lane >> 1, lane & 1, infoT);
+      for (int t0 = PDH_WAVE; t0 < 2 * nsf; t0 += PDH_WAVE)
+        {
+          const int tid = t0 + lane;
+          if (tid < 2 * nsf)
+            {
+              int info;
+              int64_t pb;
+              desc(tid >> 1, info, pb);
+              const TPts tp = tang_load(info, pb, tid & 1);
+              tt.template tang_compute<false, true>(tp, tid >> 1, tid & 1, info);
+            }
+        }
+      if (lane < nsf)
+        tt.template norm_compute<false, true>(zeta0, lane, infoN);
+      for (int t0 = PDH_WAVE; t0 < nsf; t0 += PDH_WAVE)
+        {
+          const int tid = t0 + lane;
+          if (tid < nsf)
+            {
+              int info;
+              int64_t pb;
+              desc(tid, info, pb);
+              tt.template norm_compute<false, true>(P.ap_x[(int64_t)((info >> 8) & 3) * P.ap_stride + pb], tid, info);
+            }
+        }
+      PDH_WAVE_SYNC();
+    }
   PDHT_MARK(4);
   // ================= B2: the rows ===================================================================================
   {

@@ -35,13 +35,16 @@ extern "C" int pdh_terms_has_kind(int n1d, int basis)
 }
 
 // dynamic LDS of a workgroup for the maxima of a resident problem, bytes (0: no such kind)
-extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell)
+// split: the two-phase form of the wave-per-polytope kernel (pdh_terms.h: SPLIT; ignored for the workgroup kernel)
+extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell, int split)
 {
   int bytes = 0;
   if (n1d == 4 && basis == 0)
     return 8 * pdht::terms_lds_doubles<4, 0, false>(maxruns, maxsf, maxsi, maxcell);
   for_kind(n1d, basis, [&](auto n_, auto b_) {
-    bytes = 8 * pdht::terms_lds_doubles<decltype(n_)::value, decltype(b_)::value>(maxruns, maxsf, maxsi, maxcell);
+    constexpr int N = decltype(n_)::value, B = decltype(b_)::value;
+    bytes = 8 * (split ? pdht::terms_lds_doubles<N, B, true, true>(maxruns, maxsf, maxsi, maxcell)
+                       : pdht::terms_lds_doubles<N, B, true, false>(maxruns, maxsf, maxsi, maxcell));
   });
   return bytes;
 }
@@ -92,8 +95,12 @@ extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int c
     const size_t lds = (size_t)T->lds_bytes;
     const bool small = T->fq_tensor_n <= 4 && T->vq_tensor_n <= 4; // (rules of up to 4 / up to 8 points per direction)
     auto go = [&](auto shifted_, auto pmax_) {
-      hipLaunchKernelGGL((pdht::k_terms<N, B, decltype(shifted_)::value, decltype(pmax_)::value>), dim3((unsigned)count), dim3(PDH_WAVE), lds,
-                         stream, *P, *T, count);
+      constexpr bool S = decltype(shifted_)::value;
+      constexpr int PM = decltype(pmax_)::value;
+      if (T->split)
+        hipLaunchKernelGGL((pdht::k_terms<N, B, S, PM, true>), dim3((unsigned)count), dim3(PDH_WAVE), lds, stream, *P, *T, count);
+      else
+        hipLaunchKernelGGL((pdht::k_terms<N, B, S, PM, false>), dim3((unsigned)count), dim3(PDH_WAVE), lds, stream, *P, *T, count);
     };
     using std::integral_constant;
     if (P->diag_first && small)

@@ -17,5 +17,6 @@ struct PdhTerms
   int32_t maxsf, maxsi, maxcell; // most sub-faces / interior sub-faces / cells of one owned polytope
   int32_t vq_tensor_n, fq_tensor_n; // verified points per direction of the sub-cell / sub-face rules
   int32_t lds_bytes;      // dynamic LDS of a workgroup for these maxima
+  int32_t split;          // 1: X tables made in a second pass over the D tables (pdh_terms.h: SPLIT) - lds_bytes is that form's
   long long *stamps;      // [n_owned][16] cycle counter at the phase boundaries; written by -DPDHT_STAMP builds only
 };
