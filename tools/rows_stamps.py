@@ -18,6 +18,8 @@ cells = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 basis = sys.argv[3] if len(sys.argv) > 3 else "dgq"
 degree = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 grown = len(sys.argv) > 5 and sys.argv[5] == "grown"  # irregular agglomerates (MULTI instantiation of the kernel)
+if basis != "dgq" or degree != 3:
+    os.environ["PDH_TERMS"] = "0"  # (the streamed kinds of pdh_rows.h: the term kernel has its own stamps, tools/terms_stamps.py)
 grid, ah, fe = bench.build_handler(pa, 3, cells, 2, basis, degree, degree + 1, grown=grown)
 flat = ah.flatten(pa.SipVariant.poisson_example(fe), True, False)
 ctx = pa.Context(0, lib_path=lib_path)
@@ -53,21 +55,8 @@ if basis == "dgq" and degree == 3:
 else:
     for k, nm in ((7, "P4 (streamed kinds): stage 1"), (14, "P4 (streamed kinds): stage 2"), (15, "P4 (streamed kinds): stage 3")):
         print("%-40s mean %9.0f" % (nm, out[:, k].mean()))
-# Balance between the persistent waves: wave g works through slots g, g + G, g + 2 G, ... (G = grid size); the stamps of one
-# wave come from one counter, so its own span (first start -> last end) is meaningful, absolute times of different waves are not
-G = int(os.environ.get("PDH_ROWS_GRID", "0")) or min(n, 8 * 256)
-if basis == "dgq" and degree == 3:
-    # (this kind hands its polytopes out through a device-wide counter since round 3: a slot no longer tells which wave worked on
-    # it; the balance figures below belong to the kinds with the static stride - profiles/r03_rows_stamps_static_balance.txt holds
-    # the last measurement of FE_DGQ(3) with the stride: spans 0.81 .. 1.15 of the mean)
-    sys.exit(0)
-per_wave = []
-for g in range(min(G, n)):
-    sl = np.arange(g, n, G)
-    per_wave.append((out[sl[-1], 6] - out[sl[0], 0], len(sl), float(tot[sl].sum())))
-pw = np.array(per_wave, dtype=np.float64)
-print("per wave (%d waves, %d-%d polytopes each): span min %.0f  mean %.0f  median %.0f  p95 %.0f  max %.0f ticks; busy (sum of polytope lifetimes) / span: mean %.3f"
-      % (len(pw), pw[:, 1].min(), pw[:, 1].max(), pw[:, 0].min(), pw[:, 0].mean(), np.median(pw[:, 0]), np.percentile(pw[:, 0], 95), pw[:, 0].max(),
-         float((pw[:, 2] / pw[:, 0]).mean())))
-by_xcd = [pw[x::8, 0].mean() for x in range(8)]
-print("mean span by blockIdx %% 8 (XCD under round-robin placement): " + " ".join("%.0f" % v for v in by_xcd))
+# (Round 3 printed a "balance between the persistent waves" block here that assumed a grid of min(n, 8 x 256) waves with a static
+# stride.  FE_DGQ(3) hands its polytopes out through a device-wide counter (a slot no longer tells which wave worked on it) and the
+# streamed kinds run with the grid the occupancy query gives (7 x 256 for FE_AggloDGP(3)), so the slots it grouped belonged to
+# different waves: per-wave spans of -3e11 .. +3e11 ticks.  Removed; profiles/r03_rows_stamps_static_balance.txt holds the last valid
+# measurement of the static stride - spans 0.81 .. 1.15 of the mean.  The phase shares above do not depend on it.)
