@@ -757,9 +757,13 @@ def main():
                     "algorithmic_bytes_per_launch": ke[0]["algorithmic_bytes_per_launch"],
                     "algorithmic_bytes_parts": {k: v * frac_rows for k, v in w["bytes_parts"].items()},
                     "algorithmic_flops_per_launch": ke[0]["algorithmic_flops_per_launch"],
-                    "algorithm": "row kernel (pdh_rows.h): one wave per polytope writes all blocks of its 64 rows as whole 128-byte "
-                                 "lines; planar axis-aligned faces -> rank-one face moments, Kronecker form C (x) S of the coupling "
-                                 "blocks; volume moments + three-stage contraction of the diagonal block on the f64 MFMA",
+                    "algorithm": ("term kernel (pdh_terms.h): one wave per polytope writes all blocks of its rows; every entry a short "
+                                  "sum of products of three 1-D matrix entries (mass / stiffness per cell, trace / flux per sub-face) "
+                                  "held in LDS; no moments, no MFMA"
+                                  if r.get("rows_kernel") == "terms" else
+                                  "row kernel (pdh_rows.h): one wave per polytope writes all blocks of its 64 rows as whole 128-byte "
+                                  "lines; planar axis-aligned faces -> rank-one face moments, Kronecker form C (x) S of the coupling "
+                                  "blocks; volume moments + three-stage contraction of the diagonal block on the f64 MFMA"),
                     "whole_step_GBs": ke[0]["algorithmic_bytes_per_launch"] / (r["dt"] / args.steps) * 1e-9,
                     "whole_step_algorithmic_TFLOPs": ke[0]["algorithmic_flops_per_launch"] / (r["dt"] / args.steps) * 1e-12,
                     "quadrature_structure": "tensor rules per sub-cell / sub-face found on the points by pdh_set_problem "

@@ -261,13 +261,12 @@ int pdh_values_checksum(pdh_ctx *ctx, double *out4);
 #define PDH_ALG_DIRECT 1
 #define PDH_ALG_MOMENT 2
 #define PDH_ALG_MIXED 3 /* reported only: AUTO chose MOMENT for the diagonal blocks and DIRECT for the coupling blocks */
-/* ROWS: one wave per polytope writes ALL blocks of its rows as whole 128-byte lines (pdh_rows.h).  Exists in 3-D for
- * FE_DGQ / FE_AggloDGP of degree 1 .. 3 when every face of every owned polytope lies in an axis-aligned plane (agglomerates
- * of Cartesian cells): the face moments are then rank one and a coupling block is a Kronecker product C (4x4) x S.  Every
+/* ROWS: the owner of a polytope writes ALL blocks of its rows as whole 128-byte lines (owner computes rows).  Exists in 3-D for
+ * FE_DGQ / FE_AggloDGP of degree 1 .. 3 when every face of every owned polytope lies in axis-aligned planes (agglomerates of
+ * Cartesian cells; a neighbour may be met along several planes - METIS-like "staircase" agglomerates - for every element).  Every
  * element but FE_DGQ(3) additionally needs tensor-product rules on the sub-cells and sub-faces (vq_tensor_n / fq_tensor_n).
- * FE_DGQ(3) also takes polytopes that meet a neighbour along several planes (METIS-like agglomerates of Cartesian cells).
- * AUTO takes it whenever the resident problem qualifies (tested on the quadrature points at pdh_set_problem, no mesh flag
- * needed).                                                                                                           */
+ * Several kernels serve it (pdh_rows_kernel_in_use below).  AUTO takes it whenever the resident problem qualifies (tested on the
+ * quadrature points at pdh_set_problem - or known by construction after pdh_set_problem_cartesian - no mesh flag needed).   */
 #define PDH_ALG_ROWS 4
 /* Host-only: 1 if PDH_ALG_ROWS applies to this description / row range, 0 if not (pdh_last_error(NULL) says why). */
 int pdh_check_rows(const pdh_problem *problem, int32_t row_begin, int32_t row_end);

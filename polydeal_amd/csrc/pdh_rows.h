@@ -50,8 +50,9 @@
 // tests otherwise (a store directly behind an MFMA result; a row pointer restored from a spilled SGPR by v_readlane right in
 // front of the store: "VALU writes SGPR -> VMEM reads it" needs five wait states, the store went to a stale address).  The
 // resource's size is the polytope's n rows: an offset that is off is DROPPED by the bounds check instead of written.
-// Carries still move from lane R to lane 0 by v_readlane / v_writelane (the latter as asm: this compiler has no builtin; it
-// reads its SGPR as data, for which there is no hazard).
+// Carries travel through LDS and are read back by lane 0 alone (PDHR_CARRY_READ8 below, plain C++ in the shipped build): no asm
+// statement of this file issues a memory instruction the compiler cannot see or changes EXEC (tools/isa_lint.py checks the
+// generated code object for both).
 #pragma once
 #include "pdh_moment.h"
 

@@ -7,7 +7,7 @@ exactly blocks of 2^k cells per direction (test/polydeal/rtree_mesh.output, 3DRt
 `block_hierarchy` produces; each level is assembled by the same HIP kernels."""
 from __future__ import annotations
 
-from .handler import AgglomerationHandler, BackgroundGrid, FiniteElement, SipVariant, assemble_dg_matrix
+from .handler import AgglomerationHandler, BackgroundGrid, FiniteElement, SipVariant, assemble_dg_matrix  # noqa: F401
 
 
 def block_hierarchy(grid: BackgroundGrid, fe: FiniteElement, blocks, n_q_points_1d=None):
@@ -25,6 +25,33 @@ def block_hierarchy(grid: BackgroundGrid, fe: FiniteElement, blocks, n_q_points_
 
 
 def assemble_levels(levels, fe: FiniteElement, variant: SipVariant | None = None, diag_first=True, device=0):
-    """[(rowptr, colind, values)] - the 'V-cycle assembly' of BASELINE.json configs[4]: one
-    assemble_dg_matrix per level."""
-    return [assemble_dg_matrix(fe, ah, variant, diag_first, device) for ah in levels]
+    """[(rowptr, colind, values)] - the 'V-cycle assembly' of BASELINE.json configs[4]: one assemble_dg_matrix per level
+    (examples/simplex_agglomerated_multigrid.cc:378-390), all on ONE context (stream, events, scratch buffers are created once;
+    every level replaces the resident problem).  Levels of Cartesian cells are handed over without their quadrature points
+    (flatten_cartesian: generated on the device) where the term kernels take them; distorted cells and polytopes too large for those
+    kernels go through the points-based description as before."""
+    from ._capi import Context, PdhError
+    from .handler import HostError
+
+    variant = variant or SipVariant.assemble_dg_matrix()
+    out = []
+    ctx = Context(device)
+    try:
+        for ah in levels:
+            if fe != ah.fe:
+                raise ValueError("FE passed to assemble_levels differs from a level handler's")
+            flat = None
+            if ah.grid.dim == 3:
+                try:
+                    flat = ah.flatten_cartesian(variant, diag_first, True)
+                    ctx.set_problem(flat)
+                except (PdhError, HostError):
+                    flat = None
+            if flat is None:
+                flat = ah.flatten(variant, diag_first, True)
+                ctx.set_problem(flat)
+            arr = flat.arrays()
+            out.append((arr["rowptr"].copy(), arr["colind"].copy(), ctx.assemble()))
+    finally:
+        ctx.close()
+    return out

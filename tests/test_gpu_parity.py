@@ -251,6 +251,31 @@ def test_multilevel_block_hierarchy():
         assert_parity(vals, ref, orp, oci, fe.n_dofs_per_cell)
 
 
+@pytest.mark.parametrize("basis,p,blocks", [("dgq", 1, [4, 2, 1]), ("dgp", 3, [4, 2]), ("dgq", 3, [2, 1])])
+def test_multilevel_block_hierarchy_on_a_cartesian_grid(basis, p, blocks):
+    """The same per-level assembly on an UNDISTORTED grid: assemble_levels hands every level over without its quadrature points
+    (generated on the device) where the term kernels take it, on one context for all levels; the level of 4^3-cell polytopes at degree
+    3 exceeds their LDS budget and silently takes the points-based description.  Every level against the oracle."""
+    import polydeal_amd as pa
+    from polydeal_amd.levels import assemble_levels, block_hierarchy
+
+    grid = pa.BackgroundGrid.hyper_cube_refined(3, 0.0, 1.0, 3)
+    fe = (pa.FE_DGQ if basis == "dgq" else pa.FE_AggloDGP)(3, p)
+    levels = block_hierarchy(grid, fe, blocks)
+    mats = assemble_levels(levels, fe, pa.SipVariant.poisson_example(fe))
+    og = po.hyper_cube_refined(3, 0.0, 1.0, 3)
+    ofe = po.FE_DGQ(3, p) if basis == "dgq" else po.FE_AggloDGP(3, p)
+    for b, (rp, ci, vals) in zip(blocks, mats):
+        oah = po.AgglomerationHandler(og)
+        for g in po.block_agglomerates(og, b):
+            oah.define_agglomerate(g)
+        oah.initialize_fe_values(p + 1, p + 1)
+        oah.distribute_agglomerated_dofs(ofe)
+        orp, oci, ref = po.assemble_csr(oah, po.variant_poisson_example(ofe))
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+        assert_parity(vals, ref, orp, oci, fe.n_dofs_per_cell)
+
+
 @pytest.mark.parametrize("dim,lg,b,fe_cls,p,dist", [
     (2, 3, 2, po.FE_DGQ, 1, 0.0),
     (2, 3, 2, po.FE_AggloDGP, 3, 0.2),
