@@ -81,6 +81,8 @@ extern "C" hipError_t pdh_launch_rows(const PdhDev *P, const PdhRows *R, const d
 extern "C" int pdh_rows_n_dofs(int n1d, int basis);
 extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int count, hipStream_t stream);
 extern "C" int pdh_terms_has_kind(int n1d, int basis);
+extern "C" hipError_t pdh_launch_tiled(int dim, int n1d, int which, const PdhDev *P, int count, hipStream_t stream);
+extern "C" int pdh_tiled_has_kind(int dim, int n1d, int n);
 extern "C" hipError_t pdh_launch_gen_volume(int nq, const double *nodes, const double *weights, const double *d_box, const int32_t *d_gcell,
                                             int64_t n_points, double *vq_x, int64_t stride, double *vq_w, hipStream_t stream);
 extern "C" hipError_t pdh_launch_gen_faces(int nqf, const double *nodes, const double *weights, const double *d_box, const int32_t *d_cell,
@@ -139,6 +141,7 @@ struct pdh_ctx
   std::vector<void *> allocs;
   PdhDev dev;
   int n_owned = 0, n_items = 0, NT = 0, LB = 0, group = -1;
+  bool tiled = false; // n > 64 dofs per polytope: pdh_tiled.h instead of the kernels of `group`
   size_t lds_diag = 0, lds_off = 0;
   int64_t n_values = 0, n_vq = 0, n_ap = 0;
   // host-side maps from the caller's quadrature arrays to the packed device layout (for pdh_assemble_rhs)
@@ -396,6 +399,7 @@ using dvec = std::vector<double, UninitAlloc<double>>;
 struct Packed
 {
   int n = 0, n1d = 0, NT = 0, LB = 0;
+  bool tiled = false; // n > 64: blocks in 64 x 64 tiles (pdh_tiled.h)
   std::vector<int32_t> midx;
   PdhBasisTab tab;
   std::vector<int32_t> own_agg, own_row, row_len, diag_L, it_own, it_nbr, it_pcnt, it_pos, it_nbr_slot, it_pos_t;
@@ -491,8 +495,10 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
     }
   const int dim = p->dim;
   const int n = pdh::n_dofs_per_cell(dim, p->degree, p->basis);
-  if (n > 64)
-    return fail(ctx, PDH_EUNSUPPORTED, "more than 64 dofs per polytope are not supported by this build");
+  // more than 64 dofs per polytope: blocks are computed in 64 x 64 tiles (pdh_tiled.h; 3-D, degree 4 .. 7)
+  K.tiled = n > 64;
+  if (K.tiled && !pdh_tiled_has_kind(p->dim, p->degree + 1, n))
+    return fail(ctx, PDH_EUNSUPPORTED, "more than 64 dofs per polytope are supported in 3-D for degree 4 .. 7 only");
   const bool local = p->local != 0;
   if (!local && (int64_t)n * p->n_agg != p->n_rows)
     return fail(ctx, PDH_EINVAL, "n_rows != dofs_per_cell * n_agg (global description)");
@@ -511,7 +517,9 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
   const int T = (n + 3) / 4;
   K.NT = (T + 3) / 4;
   K.LB = T - 4 * (K.NT - 1);
-  if (combo_group(dim, K.n1d, K.NT, K.LB) < 0)
+  if (K.tiled)
+    K.NT = K.LB = 4; // every tile is the full 64 x 64 product
+  else if (combo_group(dim, K.n1d, K.NT, K.LB) < 0)
     return fail(ctx, PDH_EUNSUPPORTED, "no kernel instantiated for this (dim, basis, degree)");
 
   // basis tables
@@ -521,7 +529,7 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
     for (int m = 0; m < K.n1d; ++m)
       K.tab.coef[k][m] = (double)b1.coef[k][m];
   const auto mi = pdh::multi_indices(dim, p->degree, p->basis);
-  K.midx.assign(16 * K.NT, (int32_t)0xffffffffu);
+  K.midx.assign(K.tiled ? (size_t)(n + 63) / 64 * 64 : (size_t)16 * K.NT, (int32_t)0xffffffffu);
   for (int i = 0; i < n; ++i)
     K.midx[i] = (int32_t)mi[i];
 
@@ -606,6 +614,8 @@ static int pack_problem(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begin, i
   // its owner side: the reference's `id() < neighbor->id()` rule, include/poly_utils.h:2089, 2134-2190): that rank adds
   // M11, M12 to its own rows and ships M21 (one block per face) and M22 (summed per remote polytope) to the other rank.
   const bool ghost = exchange_mode == PDH_EXCHANGE_GHOST;
+  if (ghost && K.tiled)
+    return fail(ctx, PDH_EUNSUPPORTED, "more than 64 dofs per polytope run owner-computes-rows only (no ghost-block exchange)");
   int my_rank = -1, n_ranks = 1;
   if (ghost)
     {
@@ -1971,7 +1981,8 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
   ctx->n_ap = K.n_ap;
   ctx->NT = K.NT;
   ctx->LB = K.LB;
-  ctx->group = combo_group(p->dim, K.n1d, K.NT, K.LB);
+  ctx->tiled = K.tiled;
+  ctx->group = K.tiled ? -1 : combo_group(p->dim, K.n1d, K.NT, K.LB);
   ctx->lds_diag = pdh::lds_bytes_diag(p->dim, K.n1d, K.NT);
   ctx->lds_off = pdh::lds_bytes_offdiag(p->dim, K.n1d, K.NT);
   lap("values allocation");
@@ -2014,6 +2025,12 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
       ko += ksteps(K.it_pcnt[it], ch_o);
     ctx->mfma_diag = kv * (p->dim + (p->reaction_c != 0.0 ? 1 : 0)) * i_sym + kf * 2 * i_sym;
     ctx->mfma_offdiag = ko * 2 * i_full;
+    if (K.tiled)
+      { // every tile (ti <= tj of the own block, all of a coupling block) is one full 64 x 64 product: 64 instructions per k-step
+        const int64_t nt = (K.n + 63) / 64;
+        ctx->mfma_diag = (kv * (p->dim + (p->reaction_c != 0.0 ? 1 : 0)) + kf * 2) * 64 * (nt * (nt + 1) / 2);
+        ctx->mfma_offdiag = ko * 2 * 64 * nt * nt;
+      }
   }
   ctx->basis = p->basis;
   ctx->d_mtab = nullptr;
@@ -2235,7 +2252,7 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
   if (!ctx->has_problem)
     return fail(ctx, PDH_ESTATE, "pdh_assemble_device called before pdh_set_problem");
   PDH_HIP(ctx, hipSetDevice(ctx->device));
-  pdh_launch_fn fn = g_launch[ctx->group];
+  pdh_launch_fn fn = ctx->tiled ? nullptr : g_launch[ctx->group];
   const int dim = ctx->dev.dim, n1d = ctx->dev.n1d, nt = ctx->NT, lb = ctx->LB;
   if (ctx->algorithm == PDH_ALG_MOMENT && !ctx->d_mtab)
     return fail(ctx, PDH_EUNSUPPORTED, "the moment form exists for 3-D bases of degree 1..3 only");
@@ -2328,8 +2345,9 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
     PDH_HIP(ctx, hipEventRecord(e0, sd));
   {
     const hipError_t le = ctx->use_moment(0) ? pdh_launch_moment(n1d, 0, &ctx->dev, ctx->d_mtab, ctx->n_diag_slots, sd)
-                                             : fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_diag_slots,
-                                                  ctx->lds_diag, sd);
+                          : ctx->tiled     ? pdh_launch_tiled(dim, n1d, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_diag_slots, sd)
+                                           : fn(dim, n1d, nt, lb, ctx->dev.reaction_c != 0.0 ? 2 : 0, &ctx->dev, ctx->n_diag_slots,
+                                                ctx->lds_diag, sd);
     if (le != hipSuccess)
       {
         end_capture(false); // (a stream must not be left in capture mode)
@@ -2343,7 +2361,8 @@ extern "C" int pdh_assemble_device(pdh_ctx *ctx)
     PDH_HIP(ctx, hipEventRecord(f0, so));
   {
     const hipError_t le = ctx->use_moment(1) ? pdh_launch_moment(n1d, 1, &ctx->dev, ctx->d_mtab, ctx->n_items, so)
-                                             : fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, so);
+                          : ctx->tiled     ? pdh_launch_tiled(dim, n1d, 1, &ctx->dev, ctx->n_items, so)
+                                           : fn(dim, n1d, nt, lb, 1, &ctx->dev, ctx->n_items, ctx->lds_off, so);
     if (le != hipSuccess)
       {
         end_capture(false);
@@ -2758,7 +2777,7 @@ extern "C" int pdh_shape_values_device(pdh_ctx *ctx, int dim, int degree, int ba
     return fail(ctx, PDH_EINVAL, "dim must be 2 or 3, degree >= 0, basis DGQ or AGGLODGP");
   const int n = pdh::n_dofs_per_cell(dim, degree, basis);
   const int n1d = degree + 1;
-  if (n > 64 || n1d > (dim == 2 ? 8 : 6))
+  if (n1d > 8 || (dim == 2 && n > 64))
     return fail(ctx, PDH_EUNSUPPORTED, "no kernel instantiated for this (dim, basis, degree)");
   if (n_boxes <= 0 || n_points <= 0)
     return PDH_OK;
@@ -2769,12 +2788,12 @@ extern "C" int pdh_shape_values_device(pdh_ctx *ctx, int dim, int degree, int ba
   if (ctx->shape_key != key)
     {
       const auto mi = pdh::multi_indices(dim, degree, basis);
-      std::vector<int32_t> midx(64, (int32_t)0xffffffffu);
+      std::vector<int32_t> midx(512, (int32_t)0xffffffffu); // (n <= 8^3)
       for (int i = 0; i < n; ++i)
         midx[i] = (int32_t)mi[i];
       if (!ctx->d_shape_midx)
-        PDH_HIP(ctx, hipMalloc((void **)&ctx->d_shape_midx, 64 * sizeof(int32_t)));
-      PDH_HIP(ctx, hipMemcpy(ctx->d_shape_midx, midx.data(), 64 * sizeof(int32_t), hipMemcpyHostToDevice));
+        PDH_HIP(ctx, hipMalloc((void **)&ctx->d_shape_midx, 512 * sizeof(int32_t)));
+      PDH_HIP(ctx, hipMemcpy(ctx->d_shape_midx, midx.data(), 512 * sizeof(int32_t), hipMemcpyHostToDevice));
       ctx->shape_key = key;
     }
   PdhDev D;
@@ -2802,7 +2821,7 @@ extern "C" int pdh_shape_values(pdh_ctx *ctx, int dim, int degree, int basis, in
   if (n_boxes < 0 || (n_boxes > 0 && (!bbox || !pt_ptr || !pts || !values)))
     return fail(ctx, PDH_EINVAL, "bbox, pt_ptr, pts and values are required");
   const int n = pdh::n_dofs_per_cell(dim, degree, basis);
-  if (n > 64 || degree + 1 > (dim == 2 ? 8 : 6))
+  if (degree + 1 > 8 || (dim == 2 && n > 64))
     return fail(ctx, PDH_EUNSUPPORTED, "no kernel instantiated for this (dim, basis, degree)");
   if (n_boxes == 0)
     return PDH_OK;

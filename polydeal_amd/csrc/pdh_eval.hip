@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(PDH_WAVE) k_eval(const PdhDev P, const int n_o
       lo[c] = P.bbox[(int64_t)agg * 2 * DIM + c];
       h[c] = P.bbox[(int64_t)agg * 2 * DIM + DIM + c] - lo[c];
     }
-  if (lane < P.n)
-    lds[lane] = coef[P.own_row[slot] + lane];
+  for (int i = lane; i < P.n; i += PDH_WAVE) // (n > 64: FE_DGQ(4..7) / FE_AggloDGP(6, 7) in 3-D)
+    lds[i] = coef[P.own_row[slot] + i];
   PDH_WAVE_SYNC();
   const int64_t qb = pt_ptr[by_agg ? agg : slot], qe = pt_ptr[(by_agg ? agg : slot) + 1];
   double e_l2 = 0.0, e_h1 = 0.0;
@@ -205,10 +205,11 @@ __global__ void __launch_bounds__(PDH_WAVE) k_shape(const PdhDev P, const int n_
       lo[c] = P.bbox[(int64_t)box * 2 * DIM + c];
       h[c] = P.bbox[(int64_t)box * 2 * DIM + DIM + c] - lo[c];
     }
-  const bool live = lane < P.n;
+  const int fi = (int)blockIdx.y * PDH_WAVE + lane; // blockIdx.y: 64 functions each (n > 64)
+  const bool live = fi < P.n;
   int off[DIM];
   {
-    const uint32_t packed = live ? (uint32_t)P.midx[lane] : 0u;
+    const uint32_t packed = live ? (uint32_t)P.midx[fi] : 0u;
     for (int c = 0; c < DIM; ++c)
       off[c] = (c * N1D + (int)((packed >> (8 * c)) & 0xff)) * 2;
   }
@@ -232,7 +233,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_shape(const PdhDev P, const int n_
             double phi = r[off[0]];
             for (int c = 1; c < DIM; ++c)
               phi *= r[off[c]];
-            out[(base + q) * P.n + lane] = phi;
+            out[(base + q) * P.n + fi] = phi;
           }
     }
 }
@@ -243,7 +244,7 @@ extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_
 {
   if (n_boxes <= 0)
     return hipSuccess;
-  const dim3 grid((unsigned)n_boxes), block(PDH_WAVE);
+  const dim3 grid((unsigned)n_boxes, (unsigned)((P->n + PDH_WAVE - 1) / PDH_WAVE)), block(PDH_WAVE);
 #define PDH_SHAPE_CASE(D, N)                                                                                         \
   if (dim == D && n1d == N)                                                                                          \
     {                                                                                                                \
@@ -254,7 +255,7 @@ extern "C" hipError_t pdh_launch_shape(int dim, int n1d, const PdhDev *P, int n_
   PDH_SHAPE_CASE(2, 1) PDH_SHAPE_CASE(2, 2) PDH_SHAPE_CASE(2, 3) PDH_SHAPE_CASE(2, 4)
   PDH_SHAPE_CASE(2, 5) PDH_SHAPE_CASE(2, 6) PDH_SHAPE_CASE(2, 7) PDH_SHAPE_CASE(2, 8)
   PDH_SHAPE_CASE(3, 1) PDH_SHAPE_CASE(3, 2) PDH_SHAPE_CASE(3, 3) PDH_SHAPE_CASE(3, 4)
-  PDH_SHAPE_CASE(3, 5) PDH_SHAPE_CASE(3, 6)
+  PDH_SHAPE_CASE(3, 5) PDH_SHAPE_CASE(3, 6) PDH_SHAPE_CASE(3, 7) PDH_SHAPE_CASE(3, 8)
 #undef PDH_SHAPE_CASE
   return hipErrorInvalidValue;
 }
@@ -271,7 +272,7 @@ extern "C" hipError_t pdh_launch_eval_err(int dim, int n1d, const PdhDev *P, int
     full *= n1d;
   const bool dgq = P->n == full;
   const pdh::EvalErr E{w, exact_u, exact_g, err};
-  const size_t lds = (size_t)PDH_WAVE * sizeof(double);
+  const size_t lds = (size_t)((P->n + PDH_WAVE - 1) / PDH_WAVE) * PDH_WAVE * sizeof(double);
 #define PDH_ERR_CASE(D, N)                                                                                           \
   if (dim == D && n1d == N)                                                                                          \
     {                                                                                                                \
@@ -286,7 +287,7 @@ extern "C" hipError_t pdh_launch_eval_err(int dim, int n1d, const PdhDev *P, int
   PDH_ERR_CASE(2, 1) PDH_ERR_CASE(2, 2) PDH_ERR_CASE(2, 3) PDH_ERR_CASE(2, 4)
   PDH_ERR_CASE(2, 5) PDH_ERR_CASE(2, 6) PDH_ERR_CASE(2, 7) PDH_ERR_CASE(2, 8)
   PDH_ERR_CASE(3, 1) PDH_ERR_CASE(3, 2) PDH_ERR_CASE(3, 3) PDH_ERR_CASE(3, 4)
-  PDH_ERR_CASE(3, 5) PDH_ERR_CASE(3, 6)
+  PDH_ERR_CASE(3, 5) PDH_ERR_CASE(3, 6) PDH_ERR_CASE(3, 7) PDH_ERR_CASE(3, 8)
 #undef PDH_ERR_CASE
   return hipErrorInvalidValue;
 }
@@ -308,7 +309,7 @@ extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *
 #define PDH_EVAL_CASE(D, N)                                                                                          \
   if (dim == D && n1d == N)                                                                                          \
     {                                                                                                                \
-      const size_t lds = (size_t)PDH_WAVE * sizeof(double);                                                          \
+      const size_t lds = (size_t)((P->n + PDH_WAVE - 1) / PDH_WAVE) * PDH_WAVE * sizeof(double);                                                          \
       if (grad && dgq)                                                                                               \
         PDH_EVAL_LAUNCH(D, N, true, 0);                                                                              \
       else if (grad)                                                                                                 \
@@ -322,7 +323,7 @@ extern "C" hipError_t pdh_launch_eval(int dim, int n1d, int grad, const PdhDev *
   PDH_EVAL_CASE(2, 1) PDH_EVAL_CASE(2, 2) PDH_EVAL_CASE(2, 3) PDH_EVAL_CASE(2, 4)
   PDH_EVAL_CASE(2, 5) PDH_EVAL_CASE(2, 6) PDH_EVAL_CASE(2, 7) PDH_EVAL_CASE(2, 8)
   PDH_EVAL_CASE(3, 1) PDH_EVAL_CASE(3, 2) PDH_EVAL_CASE(3, 3) PDH_EVAL_CASE(3, 4)
-  PDH_EVAL_CASE(3, 5) PDH_EVAL_CASE(3, 6)
+  PDH_EVAL_CASE(3, 5) PDH_EVAL_CASE(3, 6) PDH_EVAL_CASE(3, 7) PDH_EVAL_CASE(3, 8)
 #undef PDH_EVAL_CASE
 #undef PDH_EVAL_LAUNCH
   return hipErrorInvalidValue;

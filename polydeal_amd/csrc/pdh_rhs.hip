@@ -3,7 +3,7 @@
 //   rhs_i(P) = sum_q phi_i f(x_q) JxW                                          reference examples/poisson.cc:745-759
 //            + sum_{q on boundary faces of P} (sigma g phi_i - grad phi_i . n g) JxW          examples/poisson.cc:788-828
 //
-// One wavefront per owned polytope, lanes = basis functions (n <= 64).  Per chunk of 64 quadrature points each
+// One wavefront per owned polytope (and per 64 basis functions of it: blockIdx.y, for n > 64), lanes = basis functions.  Per chunk of 64 quadrature points each
 // lane first evaluates the 1-D basis of one POINT (lanes = points), then every lane runs over the chunk's points and
 // accumulates ITS function's value - all lanes read the same point's entries.
 //   volume: the point phase stores  F0[k0] = f JxW B0_k0  and  P12[k1,k2] = B1_k1 B2_k2, so a (function, point) pair costs
@@ -61,10 +61,11 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
       h[c] = P.bbox[(int64_t)agg * 2 * DIM + DIM + c] - lo[c];
     }
   // this lane's basis function
-  const bool live = lane < P.n;
+  const int fi = (int)blockIdx.y * PDH_WAVE + lane;
+  const bool live = fi < P.n;
   int off[DIM];
   {
-    const uint32_t packed = live ? (uint32_t)P.midx[lane] : 0u;
+    const uint32_t packed = live ? (uint32_t)P.midx[fi] : 0u;
     for (int c = 0; c < DIM; ++c)
       off[c] = live ? (c * N1D + (int)((packed >> (8 * c)) & 0xff)) * 2 : RC::ZERO_OFF / 8;
   }
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
   // offsets of this lane's function into a volume record
   int voff0 = 0, voff12 = N1D;
   {
-    const uint32_t packed = live ? (uint32_t)P.midx[lane] : 0u;
+    const uint32_t packed = live ? (uint32_t)P.midx[fi] : 0u;
     const int k0 = (int)(packed & 0xff), k1 = (int)((packed >> 8) & 0xff), k2 = (int)((packed >> 16) & 0xff);
     voff0 = k0;
     voff12 = N1D + k1 + (DIM == 3 ? N1D * k2 : 0);
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
           PDH_WAVE_SYNC();
           if (live)
             {
-              const uint32_t packed = (uint32_t)P.midx[lane];
+              const uint32_t packed = (uint32_t)P.midx[fi];
               acc += lds[(int)(packed & 0xff) + 4 * (int)((packed >> 8) & 0xff) + 16 * (int)((packed >> 16) & 0xff)];
             }
           PDH_WAVE_SYNC();
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(PDH_WAVE) k_rhs(const PdhDev P, const int n_ow
         }
     }
   if (live)
-    rhs[(int64_t)P.own_row[slot] + lane] = acc;
+    rhs[(int64_t)P.own_row[slot] + fi] = acc;
 }
 } // namespace pdh
 
@@ -263,7 +264,7 @@ extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int coun
 {
   if (count <= 0)
     return hipSuccess;
-  const dim3 grid((unsigned)count), block(PDH_WAVE);
+  const dim3 grid((unsigned)count, (unsigned)((P->n + PDH_WAVE - 1) / PDH_WAVE)), block(PDH_WAVE);
 #define PDH_RHS_CASE(D, N)                                                                                 \
   if (dim == D && n1d == N)                                                                                \
     {                                                                                                      \
@@ -275,7 +276,7 @@ extern "C" hipError_t pdh_launch_rhs(int dim, int n1d, const PdhDev *P, int coun
   PDH_RHS_CASE(2, 1) PDH_RHS_CASE(2, 2) PDH_RHS_CASE(2, 3) PDH_RHS_CASE(2, 4)
   PDH_RHS_CASE(2, 5) PDH_RHS_CASE(2, 6) PDH_RHS_CASE(2, 7) PDH_RHS_CASE(2, 8)
   PDH_RHS_CASE(3, 1) PDH_RHS_CASE(3, 2) PDH_RHS_CASE(3, 3) PDH_RHS_CASE(3, 4)
-  PDH_RHS_CASE(3, 5) PDH_RHS_CASE(3, 6)
+  PDH_RHS_CASE(3, 5) PDH_RHS_CASE(3, 6) PDH_RHS_CASE(3, 7) PDH_RHS_CASE(3, 8)
 #undef PDH_RHS_CASE
   return hipErrorInvalidValue;
 }

@@ -76,6 +76,46 @@ def test_block_agglomeration_parity(case):
     assert_parity(got, ref, rp, ci, fe.n_dofs_per_cell)
 
 
+TILED_CASES = [
+    # (log2 cells/dir, block, fe ctor, degree, variant, distort, diag_first): more than 64 dofs per polytope (pdh_tiled.h)
+    (1, 1, po.FE_DGQ, 4, "poisson", 0.1, True),      # n = 125: 2 x 2 tiles, the last one 61 functions wide
+    (2, 2, po.FE_DGQ, 4, "dr", 0.1, False),          # 8-cell polytopes, reaction term, ascending (Trilinos) columns
+    (2, 2, po.FE_DGQ, 4, "adm", 0.0, True),          # undistorted: must not be taken by a row kernel
+    (1, 1, po.FE_AggloDGP, 6, "poisson", 0.15, True),  # n = 84
+    (1, 1, po.FE_AggloDGP, 7, "dr", 0.0, False),     # n = 120, N1D = 8
+    (1, 1, po.FE_DGQ, 5, "poisson", 0.1, True),      # n = 216: 4 x 4 tiles, the last one 24 wide
+    (1, 1, po.FE_DGQ, 6, "adm", 0.1, True),          # n = 343: the largest degree examples/3D_piston.cc:912-914 runs
+]
+
+
+@pytest.mark.parametrize("case", TILED_CASES, ids=lambda c: "n%d_b%d_%s%d_%s_d%g_%s" % (2 ** c[0], c[1], c[2].name, c[3], c[4], c[5], "df" if c[6] else "asc"))
+def test_more_than_64_dofs_per_polytope(case):
+    """3-D FE_DGQ(4..6) / FE_AggloDGP(6, 7): blocks computed in 64 x 64 tiles (csrc/pdh_tiled.h), entry by entry against the oracle,
+    both CSR layouts, with and without the reaction term, distorted and Cartesian cells; the right-hand side of the same problem too
+    (reference examples/3D_piston.cc:912-914 sweeps degree 1 .. 6 with FE_DGQ<3>)."""
+    import polydeal_amd as pa
+
+    lg, b, fe_cls, p, vname, dist, diag_first = case
+    fe = fe_cls(3, p)
+    assert fe.n_dofs_per_cell > 64
+    ah = build(3, lg, b, fe, p + 1, distort=dist)
+    var = variant(vname, fe)
+    rp, ci, ref = po.assemble_csr(ah, var, diag_first=diag_first)
+    kw = flatten(ah, var, diag_first=diag_first, with_colind=True)
+    ctx = pa.Context(0)
+    ctx.set_problem(pa.Problem(**kw))
+    assert ctx.algorithm_in_use() == "direct" and ctx.rows_kernel_in_use() == "none"
+    got = ctx.assemble()
+    assert_parity(got, ref, rp, ci, fe.n_dofs_per_cell)
+    # right-hand side: volume source + Nitsche boundary datum (examples/poisson.cc:745-759, 788-828)
+    f = lambda x: np.sin(2.0 * x[:, 0]) + x[:, 1] ** 2 + x[:, 2]
+    g = lambda x: 1.0 + x[:, 0] * x[:, 1] - 0.5 * x[:, 2]
+    ref_rhs = po.assemble_rhs(ah, var, f, g)
+    got_rhs = ctx.assemble_rhs(f(kw["vq_x"].T), g(kw["fq_x"].T))
+    ctx.close()
+    assert np.max(np.abs(got_rhs - ref_rhs)) <= 1e-12 * np.max(np.abs(ref_rhs))
+
+
 def test_irregular_agglomerates_and_ascending_layout():
     grid = po.hyper_cube_refined(2, 0.0, 1.0, 3)
     ah = po.AgglomerationHandler(grid)
@@ -429,6 +469,8 @@ def test_random_irregular_agglomerates(dim, lg, n_seeds, fe_cls, p, seed, disc):
     (2, 3, 4, po.FE_AggloDGP, 4, 0.0),
     (3, 2, 2, po.FE_DGQ, 3, 0.1),
     (3, 2, 2, po.FE_AggloDGP, 3, 0.0),
+    (3, 1, 1, po.FE_DGQ, 4, 0.1),       # n = 125 > 64
+    (3, 1, 1, po.FE_AggloDGP, 7, 0.0),  # n = 120, N1D = 8
 ])
 def test_evaluate_and_global_error_parity(dim, lg, b, fe_cls, p, dist):
     """pdh_evaluate vs the oracle (values and gradients at the volume quadrature points, 1e-12 relative) and
@@ -559,6 +601,7 @@ def test_multilevel_block_hierarchy_p3():
 @pytest.mark.parametrize("dim,lg,bc,bf,p,dist", [
     (2, 3, 4, 2, 1, 0.0), (2, 3, 4, 1, 3, 0.2), (2, 4, 8, 2, 7, 0.1), (3, 2, 4, 2, 2, 0.1), (3, 2, 2, 1, 3, 0.0),
     (3, 3, 4, 2, 3, 0.15), (3, 3, 2, 1, 3, 0.15),  # the level pairs of the p = 3 hierarchy below (configs[4] stand-in)
+    (3, 2, 2, 1, 4, 0.1),  # n = 125 > 64
 ])
 def test_injection_matrix_parity(dim, lg, bc, bf, p, dist):
     """Utils::fill_injection_matrix (include/utils.h:95-270) through the host mirror + pdh_shape_values vs the
@@ -1148,7 +1191,9 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world, basis, p):
     else:
         # the small elements take the term kernel (pdh_terms.h) while a polytope's tables fit its LDS budget (64 cells with 96
         # sub-faces do not), else the streamed kinds of pdh_rows.h - which must agree with it to rounding
-        assert kern_0 == ("streamed" if (b == 4 and p >= 2) else "terms"), kern_0  # (degree 1: 2 x 2 matrices, even 64 cells fit)
+        # (degree 1: 2 x 2 matrices, even 64 cells fit; FE_AggloDGP(2): ten functions, tables in two passes, fit as well)
+        big = b == 4 and p >= 2 and not (basis == "dgp" and p == 2)
+        assert kern_0 == ("streamed" if big else "terms"), kern_0
         vs, used_s, kern_s = _values_k(kw, "rows", terms=False)
         assert used_s == "rows" and kern_s == "streamed"
         assert_parity_ah(vs, ref, ah, diag_first, what="rows (streamed kind)")
