@@ -717,6 +717,8 @@ def main():
         frac_rows = 1.0 if r["local"] else r["stats"]["n_owned_agg"] / r["n_agg"]
         # "moment": both kinds of block through pdh_moment.h; "mixed": diagonal blocks moment, coupling blocks direct
         names = ("k_mdiag" if r["alg"] in ("moment", "mixed") else "k_diag", "k_moffdiag" if r["alg"] == "moment" else "k_offdiag")
+        if r["n"] > 64:  # blocks in 64 x 64 tiles, one wave per tile (csrc/pdh_tiled.h)
+            names = ("k_tdiag", "k_toffdiag")
         moment = r["alg"] != "direct"
         t_k = [max(r["kms"][0] * 1e-3, 1e-9), max(r["kms"][1] * 1e-3, 1e-9)]
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -791,7 +793,7 @@ def main():
                                     "region above serialises them so that kernel_ms are undisturbed per-kernel durations",
                     "whole_step_GBs": w["bytes_total"] * frac_rows / (r["dt"] / args.steps) * 1e-9,
                     "whole_step_algorithmic_TFLOPs": (w["flops"][0] + w["flops"][1]) * frac_rows / (r["dt"] / args.steps) * 1e-12}
-            if names[dom] in ("k_diag", "k_offdiag"):
+            if names[dom] in ("k_diag", "k_offdiag", "k_tdiag", "k_toffdiag"):
                 # mixed form whose dominant kernel is a DIRECT (MFMA contraction) one: that kernel is bound by the f64 MFMA
                 roof.update(bound="mfma", achieved=ke[dom]["algorithmic_TFLOPs"], peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
                             frac=ke[dom]["algorithmic_TFLOPs"] / FP64_PEAK_TFLOPS, hbm_achieved_GBs=ke[dom]["hbm_achieved_GBs"])

@@ -46,7 +46,9 @@ typedef struct pdh_ctx pdh_ctx; /* opaque; owns all device memory */
 typedef struct pdh_problem
 {
   int32_t dim;     /* 2 or 3                                                                       */
-  int32_t degree;  /* polynomial degree p                                                          */
+  int32_t degree;  /* polynomial degree p, 0 .. 7.  Polytopes of up to 64 dofs run one wavefront per
+                      block; more (3-D only: FE_DGQ(4..7), FE_AggloDGP(6, 7)) in 64 x 64 tiles
+                      (pdh_tiled.h; owner-computes-rows only, no ghost-block exchange)             */
   int32_t basis;   /* PDH_BASIS_*                                                                  */
   int32_t n_agg;   /* number of polytopes (agglomerates) in this description                       */
   int32_t n_faces; /* polytopal faces; each interior face stored ONCE (in/out), boundary: out = -1 */
@@ -254,7 +256,8 @@ int pdh_copy_values(pdh_ctx *ctx, double *values);
 int pdh_values_checksum(pdh_ctx *ctx, double *out4);
 
 /* Two algebraically identical forms of the same sums exist (results differ by rounding only, both are tested against
- * the oracle): DIRECT contracts basis values over the quadrature points for all n^2 pairs (f64 MFMA, pdh_kernels.h);
+ * the oracle): DIRECT contracts basis values over the quadrature points for all n^2 pairs (f64 MFMA, pdh_kernels.h;
+ * pdh_tiled.h for more than 64 dofs per polytope);
  * MOMENT first reduces the quadrature to (2p+1)^3 Legendre moments per polytope / face and obtains the blocks by sum
  * factorisation (pdh_moment.h; 3-D, degree 1..3).  AUTO picks the faster one for the resident problem.          */
 #define PDH_ALG_AUTO 0
