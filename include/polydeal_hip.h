@@ -277,6 +277,11 @@ int pdh_check_rows(const pdh_problem *problem, int32_t row_begin, int32_t row_en
  * why).  stats5 (may be NULL): most runs (polytopal faces), sub-faces, interior sub-faces and cells of one owned polytope, and
  * the LDS bytes a workgroup needs for them (the kernels apply while that stays within their budget).                          */
 int pdh_check_terms(const pdh_problem *problem, int32_t row_begin, int32_t row_end, int64_t *stats5);
+/* Term kernels sum over the cells and sub-faces of a polytope; where those form tensor grids (block agglomerates: the R-tree levels of a
+ * structured grid; the sub-faces shared with one neighbour in one plane) a sub-grid of them is ONE cell / sub-face with composite 1-D
+ * rules - found on the data at pdh_set_problem.  out4 = { cells, cells after merging, sub-faces, sub-faces after merging } of the
+ * resident problem's owned polytopes (zeros if another kernel serves it).                                                          */
+int pdh_terms_merge_stats(pdh_ctx *ctx, int64_t *out4);
 int pdh_set_algorithm(pdh_ctx *ctx, int algorithm);
 /* Which row kernel serves the resident problem (PDH_ALG_ROWS has several; all write whole rows, owner computes rows):
  *   PIECES   FE_DGQ(3), one plane per neighbour: moments + Kronecker form, rows in aligned 512-byte pieces (pdh_rows.h)

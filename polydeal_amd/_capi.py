@@ -50,7 +50,7 @@ EXPORTS = [
     "pdh_set_exchange_mode", "pdh_exchange_layout", "pdh_exchange_get_send", "pdh_exchange_apply", "pdh_set_stream",
     "pdh_check_exchange", "pdh_copy_values", "pdh_check_rows", "pdh_values_checksum",
     "pdh_assemble_rhs_device", "pdh_evaluate_device", "pdh_shape_values_device",
-    "pdh_global_error", "pdh_global_error_device", "pdh_rows_kernel_in_use", "pdh_check_terms", "pdh_set_problem_cartesian",
+    "pdh_global_error", "pdh_global_error_device", "pdh_rows_kernel_in_use", "pdh_check_terms", "pdh_terms_merge_stats", "pdh_set_problem_cartesian",
 ]
 
 _lib = None
@@ -94,6 +94,7 @@ def _bind(lib):
     lib.pdh_algorithm_in_use.argtypes = [C.c_void_p]
     lib.pdh_rows_kernel_in_use.argtypes = [C.c_void_p]
     lib.pdh_check_terms.argtypes = [P(pdh_problem), C.c_int32, C.c_int32, P(C.c_int64)]
+    lib.pdh_terms_merge_stats.argtypes = [C.c_void_p, P(C.c_int64)]
     lib.pdh_set_exchange_mode.argtypes = [C.c_void_p, C.c_int]
     lib.pdh_exchange_layout.argtypes = [C.c_void_p, C.c_int, P(C.c_int64), P(C.c_int64)]
     lib.pdh_exchange_get_send.argtypes = [C.c_void_p, C.c_void_p]
@@ -359,6 +360,12 @@ class Context:
         if rc < 0:
             self._chk(rc)
         return {0: "none", 1: "pieces", 2: "multi", 3: "streamed", 4: "terms"}[rc]
+
+    def terms_merge_stats(self):
+        """Term kernels: {cells, cells_merged, sub_faces, sub_faces_merged} of the owned polytopes (pdh_terms_merge_stats)."""
+        out = (C.c_int64 * 4)()
+        self._chk(self.lib.pdh_terms_merge_stats(self.h, out))
+        return dict(cells=out[0], cells_merged=out[1], sub_faces=out[2], sub_faces_merged=out[3])
 
     def set_profiling(self, on=True):
         self._chk(self.lib.pdh_set_profiling(self.h, int(on)))

@@ -142,6 +142,7 @@ struct pdh_ctx
   PdhDev dev;
   int n_owned = 0, n_items = 0, NT = 0, LB = 0, group = -1;
   bool tiled = false; // n > 64 dofs per polytope: pdh_tiled.h instead of the kernels of `group`
+  int64_t terms_merge[4] = {0, 0, 0, 0}; // term kernels: cells before / after merging, sub-faces before / after
   size_t lds_diag = 0, lds_off = 0;
   int64_t n_values = 0, n_vq = 0, n_ap = 0;
   // host-side maps from the caller's quadrature arrays to the packed device layout (for pdh_assemble_rhs)
@@ -1453,9 +1454,318 @@ struct TermsHost
 {
   std::vector<double> meta;
   std::vector<int64_t> sf_pt;
-  std::vector<int32_t> sf_info;
-  int maxruns = 0, maxsf = 0, maxsi = 0, maxcell = 0, lds_bytes = 0, split = 0;
+  std::vector<int32_t> sf_info, sf_ivl, cell_ivl;
+  int maxruns = 0, maxsf = 0, maxsi = 0, maxcell = 0, lds_bytes = 0, split = 0, task_pts = 0;
+  int64_t n_cells_in = 0, n_cells_out = 0, n_sf_in = 0, n_sf_out = 0; // before / after merging (reporting)
 };
+
+// ---- merged cells and sub-faces of the term kernels --------------------------------------------------------------------------------
+// A term is a product of three 1-D matrices, one per direction; the kernels sum the terms of all cells (sub-faces) of a polytope.
+// Where cells form a TENSOR GRID - cell (i, j, k) has the i-th interval of the 1-D rules along x, the j-th along y, the k-th along z,
+// and its weight factorises - the sum over a sub-grid of products is the product of the sums over the intervals:
+//   sum_ijk A_i (x) B_j (x) C_k = (sum_i A_i) (x) (sum_j B_j) (x) (sum_k C_k),
+// i.e. the sub-grid is ONE cell with composite 1-D rules of several intervals.  Block agglomerates (what an R-tree gives on a structured
+// grid) are such grids as a whole; so are the sub-faces a polytope shares with one neighbour in one plane.  Found on the data (first
+// points of the rules, compared to rounding; weights checked for the factorisation), never assumed; anything else stays unmerged.  A
+// composite rule has at most 8 points and TERMS_MI intervals (register slots of a lane task): larger grids are cut into sub-grids.
+struct TermsMerged
+{
+  struct Cell
+  {
+    int32_t ivl[3][TERMS_MI];
+  };
+  struct Sf
+  {
+    int64_t pb;
+    int c, pos, fj, ni, nj;
+    int32_t ivl[2][TERMS_MI];
+  };
+  std::vector<Cell> cells;
+  std::vector<std::vector<Sf>> runs; // in the order of the record's runs
+};
+namespace
+{
+// indices of the values of v in the sorted list of its distinct values (equal within tol); returns the number of distinct values
+int cluster_1d(const std::vector<double> &v, double tol, std::vector<int> &idx)
+{
+  std::vector<size_t> o(v.size());
+  for (size_t i = 0; i < o.size(); ++i)
+    o[i] = i;
+  std::sort(o.begin(), o.end(), [&](size_t a, size_t b) { return v[a] < v[b]; });
+  idx.assign(v.size(), 0);
+  int n = 0;
+  for (size_t k = 0; k < o.size(); ++k)
+    {
+      if (k > 0 && v[o[k]] - v[o[k - 1]] > tol)
+        ++n;
+      idx[o[k]] = n;
+    }
+  return v.empty() ? 0 : n + 1;
+}
+} // namespace
+
+static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const RowsHost &RH, int tn, int fn, size_t sl,
+                                const std::vector<size_t> &order, bool enabled, TermsMerged &M)
+{
+  const int a = K.own_agg[sl];
+  const int64_t m3 = (int64_t)tn * tn * tn, gsz = (int64_t)fn * fn;
+  const int ncell = (int)((K.vq_ptr[sl + 1] - K.vq_ptr[sl]) / m3);
+  double hbox[3];
+  for (int d = 0; d < 3; ++d)
+    hbox[d] = p->bbox[(size_t)a * 6 + 3 + d] - p->bbox[(size_t)a * 6 + d];
+  const double wtol = 8.0 * geometry_rounding(p, a);
+  const bool cart = K.cart != nullptr;
+  auto single_cells = [&] {
+    M.cells.resize((size_t)ncell);
+    for (int u = 0; u < ncell; ++u)
+      for (int d = 0; d < 3; ++d)
+        for (int i = 0; i < TERMS_MI; ++i)
+          M.cells[(size_t)u].ivl[d][i] = i == 0 ? u : -1;
+  };
+  // ---------------- cells
+  const int mc = tn >= 1 && tn <= 4 ? std::min(TERMS_MI, 8 / tn) : 1;
+  bool done = false;
+  if (enabled && mc > 1 && ncell > 1)
+    {
+      auto cellbox = [&](int u) { return K.cart->cell_box + (size_t)K.cart->vq_cell[p->vq_ptr[a] / m3 + u] * 6; };
+      const int64_t b0 = K.vq_ptr[sl], st = K.vq_stride_h;
+      const int64_t step[3] = {1, tn, (int64_t)tn * tn};
+      std::vector<double> key[3];
+      std::vector<int> idx[3];
+      int nd[3];
+      for (int d = 0; d < 3; ++d)
+        {
+          key[d].resize((size_t)ncell);
+          for (int u = 0; u < ncell; ++u)
+            key[d][(size_t)u] = cart ? cellbox(u)[d] : K.vqx_h[d * st + b0 + u * m3];
+          nd[d] = cluster_1d(key[d], 1e-9 * hbox[d], idx[d]);
+        }
+      bool ok = (int64_t)nd[0] * nd[1] * nd[2] == ncell;
+      std::vector<int> grid;
+      if (ok)
+        {
+          grid.assign((size_t)ncell, -1);
+          for (int u = 0; u < ncell && ok; ++u)
+            {
+              int &g = grid[(size_t)(idx[0][u] + nd[0] * (idx[1][u] + nd[1] * idx[2][u]))];
+              ok = g < 0;
+              g = u;
+            }
+        }
+      auto at = [&](int i, int j, int k) { return grid[(size_t)(i + nd[0] * (j + nd[1] * k))]; };
+      // sub-grids of at most mc intervals per direction
+      int cb[3];
+      for (int d = 0; d < 3; ++d)
+        cb[d] = (nd[d] + mc - 1) / mc;
+      if (ok)
+        for (int u = 0; u < ncell && ok; ++u)
+          {
+            const int o[3] = {idx[0][u] / mc * mc, idx[1][u] / mc * mc, idx[2][u] / mc * mc}; // origin of the cell's sub-grid
+            if (cart)
+              { // same interval = same extent along the direction
+                for (int d = 0; d < 3 && ok; ++d)
+                  {
+                    int r[3] = {o[0], o[1], o[2]};
+                    r[d] = idx[d][u];
+                    const double *bu = cellbox(u), *br = cellbox(at(r[0], r[1], r[2]));
+                    ok = std::fabs(bu[d] - br[d]) <= 1e-12 * hbox[d] && std::fabs(bu[3 + d] - br[3 + d]) <= 1e-12 * hbox[d];
+                  }
+                continue;
+              }
+            // points mode: 1-D nodes and weight ratios of the cell equal those of the sub-grid's reference cell of its interval, and
+            // the weight of the first point factorises over the sub-grid
+            const int64_t bu = b0 + u * m3;
+            const double wu = K.vqw_h[bu];
+            double wf = 1.0;
+            const int uo = at(o[0], o[1], o[2]);
+            const double w0 = K.vqw_h[b0 + uo * m3];
+            for (int d = 0; d < 3 && ok; ++d)
+              {
+                int r[3] = {o[0], o[1], o[2]};
+                r[d] = idx[d][u];
+                const int64_t br = b0 + at(r[0], r[1], r[2]) * m3;
+                const double wr = K.vqw_h[br];
+                wf *= wr / w0;
+                for (int i = 0; i < tn && ok; ++i)
+                  {
+                    const double X = K.vqx_h[d * st + br + i * step[d]];
+                    ok = std::fabs(K.vqx_h[d * st + bu + i * step[d]] - X) <= 3e-15 * (std::fabs(X) + hbox[d]) &&
+                         std::fabs(K.vqw_h[bu + i * step[d]] / wu - K.vqw_h[br + i * step[d]] / wr) <= wtol * (K.vqw_h[br + i * step[d]] / wr);
+                  }
+              }
+            ok = ok && std::fabs(wu - w0 * wf) <= wtol * wu;
+          }
+      if (ok)
+        {
+          for (int k = 0; k < cb[2]; ++k)
+            for (int j = 0; j < cb[1]; ++j)
+              for (int i = 0; i < cb[0]; ++i)
+                {
+                  TermsMerged::Cell c;
+                  const int o[3] = {i * mc, j * mc, k * mc};
+                  for (int d = 0; d < 3; ++d)
+                    for (int t = 0; t < TERMS_MI; ++t)
+                      {
+                        int r[3] = {o[0], o[1], o[2]};
+                        r[d] = o[d] + t;
+                        c.ivl[d][t] = (t < mc && r[d] < nd[d]) ? at(r[0], r[1], r[2]) : -1;
+                      }
+                  M.cells.push_back(c);
+                }
+          done = true;
+        }
+    }
+  if (!done)
+    single_cells();
+  // ---------------- sub-faces, run by run
+  const int mf = fn >= 1 && fn <= 4 ? std::min(TERMS_MI, 8 / fn) : 1;
+  M.runs.resize(order.size());
+  for (size_t e = 0; e < order.size(); ++e)
+    {
+      const size_t t = order[e];
+      const int ns = (int)(K.run_cnt[t] / gsz);
+      auto &out = M.runs[e];
+      struct G
+      {
+        int c, pos, fj;
+        double z, xi, xj;
+      };
+      std::vector<G> gs((size_t)ns);
+      for (int g = 0; g < ns; ++g)
+        {
+          G &s = gs[(size_t)g];
+          if (cart)
+            {
+              const int64_t grp = K.pk_fq[t] / gsz + g;
+              const int lf = K.cart->fq_face[grp];
+              const double *bx = K.cart->cell_box + (size_t)K.cart->fq_cell[grp] * 6;
+              s.c = lf >> 1;
+              s.pos = ((lf & 1) != 0) == ((K.pk_flags[t] & 1) != 0) ? 1 : 0;
+              s.z = bx[(lf & 1) ? 3 + s.c : s.c];
+              const int ti = s.c == 0 ? 1 : 0, tj = s.c == 2 ? 1 : 2;
+              s.xi = bx[ti], s.xj = bx[tj];
+            }
+          else
+            {
+              s.c = 0;
+              for (int d = 0; d < 3; ++d)
+                if (std::fabs(K.ap_n(d, t, g * gsz)) > 0.5)
+                  s.c = d;
+              s.pos = K.ap_n(s.c, t, g * gsz) > 0 ? 1 : 0;
+              const int ti = s.c == 0 ? 1 : 0, tj = s.c == 2 ? 1 : 2;
+              s.z = K.ap_x(s.c, t, g * gsz);
+              s.xi = K.ap_x(ti, t, g * gsz), s.xj = K.ap_x(tj, t, g * gsz);
+            }
+          s.fj = RH.fast_j[3 * t + s.c] == 1 ? 1 : 0;
+        }
+      auto single = [&](int g) {
+        TermsMerged::Sf f;
+        f.pb = K.run_ap[t] + g * gsz;
+        f.c = gs[(size_t)g].c, f.pos = gs[(size_t)g].pos, f.fj = gs[(size_t)g].fj, f.ni = f.nj = 1;
+        for (int d = 0; d < 2; ++d)
+          for (int i = 0; i < TERMS_MI; ++i)
+            f.ivl[d][i] = 0;
+        out.push_back(f);
+      };
+      if (!enabled || mf <= 1 || ns <= 1)
+        {
+          for (int g = 0; g < ns; ++g)
+            single(g);
+          continue;
+        }
+      // planes of the run: (axis, side, coordinate)
+      std::vector<char> used((size_t)ns, 0);
+      for (int g0 = 0; g0 < ns; ++g0)
+        {
+          if (used[(size_t)g0])
+            continue;
+          const G &r0 = gs[(size_t)g0];
+          std::vector<int> mem;
+          for (int g = g0; g < ns; ++g)
+            if (!used[(size_t)g] && gs[(size_t)g].c == r0.c && gs[(size_t)g].pos == r0.pos && gs[(size_t)g].fj == r0.fj &&
+                std::fabs(gs[(size_t)g].z - r0.z) <= 1e-9 * hbox[r0.c])
+              {
+                mem.push_back(g);
+                used[(size_t)g] = 1;
+              }
+          const int c = r0.c, ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
+          std::vector<double> ki(mem.size()), kj(mem.size());
+          for (size_t m = 0; m < mem.size(); ++m)
+            ki[m] = gs[(size_t)mem[m]].xi, kj[m] = gs[(size_t)mem[m]].xj;
+          std::vector<int> ii, jj;
+          const int ni = cluster_1d(ki, 1e-9 * hbox[ti], ii), nj = cluster_1d(kj, 1e-9 * hbox[tj], jj);
+          bool ok = mem.size() > 1 && (size_t)ni * nj == mem.size();
+          std::vector<int> grid;
+          if (ok)
+            {
+              grid.assign(mem.size(), -1);
+              for (size_t m = 0; m < mem.size() && ok; ++m)
+                {
+                  int &gg = grid[(size_t)(ii[m] + ni * jj[m])];
+                  ok = gg < 0;
+                  gg = (int)m;
+                }
+            }
+          auto at = [&](int i, int j) { return mem[(size_t)grid[(size_t)(i + ni * j)]]; };
+          if (ok)
+            for (size_t m = 0; m < mem.size() && ok; ++m)
+              {
+                const int g = mem[m];
+                const int o[2] = {ii[m] / mf * mf, jj[m] / mf * mf};
+                if (cart)
+                  { // same interval = same extent along the tangential direction (the side-0 cell's box carries the sub-face)
+                    const int64_t grp = K.pk_fq[t] / gsz;
+                    const double *bu = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + g] * 6;
+                    const double *bi = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + at(ii[m], o[1])] * 6;
+                    const double *bj = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + at(o[0], jj[m])] * 6;
+                    ok = std::fabs(bu[ti] - bi[ti]) <= 1e-12 * hbox[ti] && std::fabs(bu[3 + ti] - bi[3 + ti]) <= 1e-12 * hbox[ti] &&
+                         std::fabs(bu[tj] - bj[tj]) <= 1e-12 * hbox[tj] && std::fabs(bu[3 + tj] - bj[3 + tj]) <= 1e-12 * hbox[tj];
+                    continue;
+                  }
+                const int fj = r0.fj;
+                const int64_t st_i = fj ? fn : 1, st_j = fj ? 1 : fn;
+                const int gi = at(ii[m], o[1]), gj = at(o[0], jj[m]), go = at(o[0], o[1]);
+                for (int which = 0; which < 2 && ok; ++which)
+                  { // own-side and cross weights (the latter zero on the boundary)
+                    auto W = [&](int gq, int64_t q) { return which ? K.ap_wcross(t, gq * gsz + q) : K.ap_wself(t, gq * gsz + q); };
+                    const double wu = W(g, 0), wi = W(gi, 0), wj = W(gj, 0), wo = W(go, 0);
+                    if (which && wu == 0.0 && wo == 0.0)
+                      continue;
+                    ok = wu > 0.0 && wo > 0.0 && std::fabs(wu - wi * wj / wo) <= wtol * wu;
+                    for (int al = 0; al < fn && ok; ++al)
+                      {
+                        const double Xi = K.ap_x(ti, t, gi * gsz + al * st_i), Xj = K.ap_x(tj, t, gj * gsz + al * st_j);
+                        ok = std::fabs(K.ap_x(ti, t, g * gsz + al * st_i) - Xi) <= 3e-15 * (std::fabs(Xi) + hbox[ti]) &&
+                             std::fabs(K.ap_x(tj, t, g * gsz + al * st_j) - Xj) <= 3e-15 * (std::fabs(Xj) + hbox[tj]) &&
+                             std::fabs(W(g, al * st_i) / wu - W(gi, al * st_i) / wi) <= wtol * (W(gi, al * st_i) / wi) &&
+                             std::fabs(W(g, al * st_j) / wu - W(gj, al * st_j) / wj) <= wtol * (W(gj, al * st_j) / wj);
+                      }
+                  }
+              }
+          if (!ok)
+            {
+              for (int g : mem)
+                single(g);
+              continue;
+            }
+          for (int j0 = 0; j0 < nj; j0 += mf)
+            for (int i0 = 0; i0 < ni; i0 += mf)
+              {
+                TermsMerged::Sf f;
+                const int go = at(i0, j0);
+                f.pb = K.run_ap[t] + go * gsz;
+                f.c = c, f.pos = r0.pos, f.fj = r0.fj;
+                f.ni = std::min(mf, ni - i0), f.nj = std::min(mf, nj - j0);
+                for (int q = 0; q < TERMS_MI; ++q)
+                  {
+                    f.ivl[0][q] = q < f.ni ? (int32_t)((at(i0 + q, j0) - go) * gsz) : 0;
+                    f.ivl[1][q] = q < f.nj ? (int32_t)((at(i0, j0 + q) - go) * gsz) : 0;
+                  }
+                out.push_back(f);
+              }
+        }
+    }
+}
 static constexpr int PDH_TERMS_LDS_CAP = 40 * 1024; // bytes per workgroup: four resident waves per CU at least
 static bool build_terms_tables(const pdh_problem *p, const Packed &K, const RowsHost &RH, int vq_n, TermsHost &T, std::string *why = nullptr)
 {
@@ -1482,16 +1792,12 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
         for (; r < nruns && K.run_slot[r] == sl; ++r)
           idx.push_back(r);
         std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return K.run_blk[x] < K.run_blk[y]; });
-        int nsf = 0, nsi = 0, nb = 0;
+        int nb = 0;
         for (size_t t : idx)
           {
             if (K.run_cnt[t] % gsz)
               return no("term kernel: a face is not made of whole sub-face rules");
-            const int ns = (int)(K.run_cnt[t] / gsz);
-            nsf += ns;
-            if (K.run_nbr[t] >= 0)
-              nsi += ns;
-            else
+            if (K.run_nbr[t] < 0)
               ++nb;
           }
         if (nb > 1)
@@ -1500,14 +1806,48 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
         if (nq % m3 || nq / m3 > 65535 || idx.size() > 250)
           return no("term kernel: too many cells or faces on a polytope");
         T.maxruns = std::max<int>(T.maxruns, (int)idx.size());
-        T.maxsf = std::max(T.maxsf, nsf);
-        T.maxsi = std::max(T.maxsi, nsi);
-        T.maxcell = std::max<int>(T.maxcell, (int)(nq / m3));
       }
     if (r != nruns)
       return no("run bookkeeping");
   }
   T.maxruns = std::max(T.maxruns, 1);
+  // cells and sub-faces the kernel sums over: merged where they form tensor grids (merge_terms_of_slot); PDH_TERMS_MERGE=0: as given
+  const char *me = getenv("PDH_TERMS_MERGE");
+  const bool merge = !(me && me[0] == '0');
+  std::vector<TermsMerged> MG((size_t)K.n_owned);
+  host_parallel_for((size_t)K.n_owned, [&](size_t sl) { merge_terms_of_slot(p, K, RH, vq_n, fn, sl, order[sl], merge, MG[sl]); });
+  int ivl_c = 1, ivl_f = 1;
+  for (int sl = 0; sl < K.n_owned; ++sl)
+    {
+      const TermsMerged &M = MG[(size_t)sl];
+      int nsf = 0, nsi = 0;
+      for (size_t e = 0; e < order[sl].size(); ++e)
+        {
+          nsf += (int)M.runs[e].size();
+          if (K.run_nbr[order[sl][e]] >= 0)
+            nsi += (int)M.runs[e].size();
+          T.n_sf_in += K.run_cnt[order[sl][e]] / gsz;
+          for (const auto &f : M.runs[e])
+            ivl_f = std::max(ivl_f, std::max(f.ni, f.nj));
+        }
+      for (const auto &c : M.cells)
+        for (int d = 0; d < 3; ++d)
+          {
+            int k = 0;
+            for (int i = 0; i < TERMS_MI; ++i)
+              k += c.ivl[d][i] >= 0 ? 1 : 0;
+            ivl_c = std::max(ivl_c, k);
+          }
+      T.n_sf_out += nsf;
+      T.n_cells_in += (K.vq_ptr[sl + 1] - K.vq_ptr[sl]) / m3;
+      T.n_cells_out += (int64_t)M.cells.size();
+      if (nsf > 65535)
+        return no("term kernel: too many sub-faces on a polytope");
+      T.maxsf = std::max(T.maxsf, nsf);
+      T.maxsi = std::max(T.maxsi, nsi);
+      T.maxcell = std::max<int>(T.maxcell, (int)M.cells.size());
+    }
+  T.task_pts = std::max(vq_n * ivl_c, fn * ivl_f);
   {
     // one pass or two (pdh_terms.h: SPLIT): whichever lets more single-wave workgroups stay resident on a CU - by LDS (160 KB in
     // granules of 1280 bytes), capped by the 12 waves the kernels' registers allow; a tie goes to the single pass (fewer
@@ -1532,22 +1872,27 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
     std::memcpy(&d, &v, sizeof(d));
     return d;
   };
-  // the sub-faces of a polytope stand at a fixed stride (maxsf): the kernel requests them together with the record
+  // the sub-faces (cells) of a polytope stand at a fixed stride (maxsf, maxcell): the kernel requests them together with the record
   T.maxsf = std::max(T.maxsf, 1);
+  T.maxcell = std::max(T.maxcell, 1);
   T.sf_pt.assign((size_t)K.n_owned * T.maxsf, 0);
   T.sf_info.assign((size_t)K.n_owned * T.maxsf, 0);
+  T.sf_ivl.assign((size_t)K.n_owned * T.maxsf * 2 * TERMS_MI, 0);
+  T.cell_ivl.assign((size_t)K.n_owned * T.maxcell * 3 * TERMS_MI, -1);
   T.meta.assign((size_t)K.n_owned * REC, 0.0);
   std::vector<char> bad((size_t)K.n_owned, 0);
   host_parallel_for((size_t)K.n_owned, [&](size_t sl) {
     double *rec = T.meta.data() + sl * REC;
     const int a = K.own_agg[sl];
     const auto &idx = order[sl];
+    const TermsMerged &M = MG[sl];
     int64_t at = (int64_t)sl * T.maxsf;
     const int64_t at0 = at;
     int nsfb = 0, e = 0;
     for (size_t t : idx)
       {
-        const int ns = (int)(K.run_cnt[t] / gsz), nb = K.run_nbr[t];
+        const auto &fs = M.runs[(size_t)e];
+        const int ns = (int)fs.size(), nb = K.run_nbr[t];
         double *en = rec + HDR + e * ENT;
         en[0] = as_d((long long)(uint32_t)(at - at0) | ((long long)ns << 32));
         en[1] = as_d((long long)K.run_blk[t]);
@@ -1563,30 +1908,22 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
             if (e != 0)
               bad[sl] = 1; // (the kernel takes the boundary run to be run 0)
           }
-        for (int g = 0; g < ns; ++g, ++at)
+        for (const auto &f : fs)
           {
-            int c = 0, pos;
-            if (K.cart)
-              { // local face 2 c + side of the side-0 cell; the owner of this run sees the normal reversed if it is side 1
-                const int lf = K.cart->fq_face[K.pk_fq[t] / gsz + g];
-                c = lf >> 1;
-                pos = ((lf & 1) != 0) == ((K.pk_flags[t] & 1) != 0) ? 1 : 0;
-              }
-            else
-              {
-                for (int d = 0; d < 3; ++d)
-                  if (std::fabs(K.ap_n(d, t, g * gsz)) > 0.5)
-                    c = d;
-                pos = K.ap_n(c, t, g * gsz) > 0 ? 1 : 0;
-              }
-            const int fj = RH.fast_j[3 * t + c] == 1 ? 1 : 0;
-            T.sf_pt[(size_t)at] = K.run_ap[t] + g * gsz;
-            T.sf_info[(size_t)at] = e | (c << 8) | (pos << 10) | (fj << 11);
+            T.sf_pt[(size_t)at] = f.pb;
+            T.sf_info[(size_t)at] = e | (f.c << 8) | (f.pos << 10) | (f.fj << 11) | (f.ni << 12) | (f.nj << 15);
+            for (int d = 0; d < 2; ++d)
+              for (int i = 0; i < TERMS_MI; ++i)
+                T.sf_ivl[((size_t)at * 2 + d) * TERMS_MI + i] = f.ivl[d][i];
+            ++at;
           }
         ++e;
       }
-    const int64_t nq = K.vq_ptr[sl + 1] - K.vq_ptr[sl];
-    rec[0] = as_d((long long)idx.size() | ((long long)(nq / m3) << 16) | ((long long)nsfb << 32));
+    for (size_t u = 0; u < M.cells.size(); ++u)
+      for (int d = 0; d < 3; ++d)
+        for (int i = 0; i < TERMS_MI; ++i)
+          T.cell_ivl[((sl * T.maxcell + u) * 3 + d) * TERMS_MI + i] = M.cells[u].ivl[d][i];
+    rec[0] = as_d((long long)idx.size() | ((long long)M.cells.size() << 16) | ((long long)nsfb << 32));
     for (int c = 0; c < 3; ++c)
       {
         rec[1 + c] = p->bbox[(size_t)a * 6 + c];
@@ -1637,6 +1974,19 @@ extern "C" int pdh_check_rows(const pdh_problem *p, int32_t row_begin, int32_t r
 // Host-only: 1 if the term kernels (pdh_terms.h / pdh_terms_wg.h) apply to this description and row range, 0 if not
 // (pdh_last_error(NULL) says why), < 0 on an invalid description.  stats4 (may be NULL): most runs / sub-faces / interior
 // sub-faces / cells of one owned polytope... and the LDS bytes of a workgroup in stats4[4].
+// Term kernels of the resident problem: cells before / after merging, sub-faces before / after (pdh_terms_tables.h); zeros if another
+// kernel serves the problem.
+extern "C" int pdh_terms_merge_stats(pdh_ctx *ctx, int64_t *out4)
+{
+  if (!ctx || !out4)
+    return fail(ctx, PDH_EINVAL, "ctx and out4 are required");
+  if (!ctx->has_problem)
+    return fail(ctx, PDH_ESTATE, "pdh_terms_merge_stats called before pdh_set_problem");
+  for (int i = 0; i < 4; ++i)
+    out4[i] = ctx->terms_ok ? ctx->terms_merge[i] : 0;
+  return PDH_OK;
+}
+
 extern "C" int pdh_check_terms(const pdh_problem *p, int32_t row_begin, int32_t row_end, int64_t *stats5)
 {
   Packed K;
@@ -2166,7 +2516,8 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
             {
               PdhTerms &T = ctx->terms;
               if ((rc = upload(ctx, TH.meta, &T.meta)) != PDH_OK || (rc = upload(ctx, TH.sf_pt, &T.sf_pt)) != PDH_OK ||
-                  (rc = upload(ctx, TH.sf_info, &T.sf_info)) != PDH_OK)
+                  (rc = upload(ctx, TH.sf_info, &T.sf_info)) != PDH_OK || (rc = upload(ctx, TH.sf_ivl, &T.sf_ivl)) != PDH_OK ||
+                  (rc = upload(ctx, TH.cell_ivl, &T.cell_ivl)) != PDH_OK)
                 {
                   free_problem(ctx);
                   return rc;
@@ -2175,6 +2526,9 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
               T.vq_tensor_n = vq_n_terms, T.fq_tensor_n = RH.fq_tensor_n;
               T.lds_bytes = TH.lds_bytes;
               T.split = TH.split;
+              T.task_pts = TH.task_pts;
+              ctx->terms_merge[0] = TH.n_cells_in, ctx->terms_merge[1] = TH.n_cells_out;
+              ctx->terms_merge[2] = TH.n_sf_in, ctx->terms_merge[3] = TH.n_sf_out;
               {
                 void *ds = nullptr;
                 const size_t nb = (size_t)std::max(K.n_owned, 1) * 16 * sizeof(long long);

@@ -156,19 +156,27 @@ struct TermTasks
   struct Pts // point data of one lane task: tangential x | w_self | w_cross; cell x | w; normal-direction task: x[0] = plane coordinate
   {
     double x[PMAX], ws[PMAX], wc[PMAX];
+    int npts; // live points: intervals x points of a rule
   };
   using TPts = Pts;
   using CPts = Pts;
-  __device__ __forceinline__ TPts tang_load(int info, int64_t pb, int dir) const
-  { // all loads of a task at once (fn <= PMAX, checked by the host)
+  // interval of point i of a composite rule of m-point rules (i < PMAX <= 8, m >= 2: at most TERMS_MI = 4 intervals)
+  __device__ __forceinline__ static int ivl_of(int i, int m) { return (i >= m ? 1 : 0) + (i >= 2 * m ? 1 : 0) + (i >= 3 * m ? 1 : 0); }
+  __device__ __forceinline__ static int sel4(int i, int a, int b, int c, int d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
+  // ivl: the TERMS_MI interval entries of this (sub-face, direction) - PdhTerms::sf_ivl
+  __device__ __forceinline__ TPts tang_load(int info, int64_t pb, int dir, const int32_t *__restrict__ ivl) const
+  { // all loads of a task at once (intervals x fn <= PMAX, checked by the host)
     TPts r;
     const int c = (info >> 8) & 3;
     const bool fast_j = ((info >> 11) & 1) != 0;
     const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
     const int64_t stp = ((dir == 1) == fast_j) ? 1 : fn;
+    r.npts = ((info >> (dir ? 15 : 12)) & 7) * fn;
+    const int o0 = ivl[0], o1 = ivl[1], o2 = ivl[2], o3 = ivl[3];
     static_for<0, PMAX>([&](auto i_) {
       constexpr int al = i_;
-      const int64_t q = al < fn ? pb + al * stp : pb;
+      const int ii = ivl_of(al, fn);
+      const int64_t q = al < r.npts ? pb + sel4(ii, o0, o1, o2, o3) + (al - ii * fn) * stp : pb;
       r.x[al] = P.ap_x[(int64_t)ax * P.ap_stride + q];
       r.ws[al] = P.ap_wself[q];
       r.wc[al] = P.ap_wcross[q]; // (zero on the boundary)
@@ -194,7 +202,7 @@ struct TermTasks
       Xm[i] = 0.0;
     static_for<0, PMAX>([&](auto i_) {
       constexpr int al = i_;
-      if (al < fn)
+      if (al < r.npts)
         {
           double bp[N1D], bq[N1D];
           basis((r.x[al] - lo_d) * ih_d - 0.5, bp);
@@ -255,15 +263,19 @@ struct TermTasks
     });
   }
   // (cell, direction): M_d and K_d.  The rule of a cell is a_i b_j c_k: direction 0 takes w_(i,0,0), the others w / w_000
-  __device__ __forceinline__ CPts cell_load(int ct) const
+  // ivl: the TERMS_MI interval entries of this (cell, direction) - PdhTerms::cell_ivl
+  __device__ __forceinline__ CPts cell_load(int ct, const int32_t *__restrict__ ivl) const
   {
     CPts r;
     const int cell = ct / 3, d = ct - 3 * cell;
-    const int64_t base = vq_b + (int64_t)cell * (tn * tn * tn);
+    const int c0 = ivl[0], c1 = ivl[1], c2 = ivl[2], c3 = ivl[3];
+    r.npts = ((c0 >= 0 ? 1 : 0) + (c1 >= 0 ? 1 : 0) + (c2 >= 0 ? 1 : 0) + (c3 >= 0 ? 1 : 0)) * tn;
+    const int64_t m3 = (int64_t)tn * tn * tn;
     const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
     static_for<0, PMAX>([&](auto i_) {
       constexpr int i = i_;
-      const int64_t q = i < tn ? base + i * step : base;
+      const int ii = ivl_of(i, tn);
+      const int64_t q = i < r.npts ? vq_b + sel4(ii, c0, c1, c2, c3) * m3 + (i - ii * tn) * step : vq_b + (c0 >= 0 ? c0 : 0) * m3;
       r.x[i] = P.vq_x[(int64_t)d * P.vq_stride + q];
       r.ws[i] = P.vq_w[q];
       r.wc[i] = 0.0;
@@ -280,7 +292,7 @@ struct TermTasks
       Mm[i] = Km[i] = 0.0;
     static_for<0, PMAX>([&](auto i_) {
       constexpr int i = i_;
-      if (i < tn)
+      if (i < r.npts)
         {
           double bp[N1D], dp[N1D];
           basis_d((r.x[i] - lo_d) * ih_d - 0.5, bp, dp);
@@ -348,6 +360,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
     info = T.sf_info[at];
     pb = T.sf_pt[at];
   };
+  auto sf_ivl = [&](int sf, int dir) { return T.sf_ivl + ((sfb + (sf < T.maxsf ? sf : 0)) * 2 + dir) * TERMS_MI; };
+  auto cell_ivl = [&](int ct) { return T.cell_ivl + ((int64_t)slot * T.maxcell * 3 + ct) * TERMS_MI; };
   int infoT, infoN;
   int64_t pbT, pbN;
   desc(lane >> 1, infoT, pbT);
@@ -383,19 +397,20 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
   using TPts = typename TT::TPts;
   using CPts = typename TT::CPts;
   const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, vq_b};
-  auto tang_load = [&](int info, int64_t pb, int dir) { return tt.tang_load(info, pb, dir); };
+  auto tang_load = [&](int info, int64_t pb, int sf, int dir) { return tt.tang_load(info, pb, dir, sf_ivl(sf, dir)); };
   auto tang_compute = [&](const TPts &r, int sf, int dir, int info) { tt.template tang_compute<true, !SPLIT>(r, sf, dir, info); };
   auto norm_compute = [&](double zeta, int sf, int info) { tt.template norm_compute<true, !SPLIT>(zeta, sf, info); };
-  auto cell_load = [&](int ct) { return tt.cell_load(ct); };
+  auto cell_load = [&](int ct) { return tt.cell_load(ct, cell_ivl(ct)); };
   auto cell_compute = [&](const CPts &r, int ct) { tt.cell_compute(r, ct); };
   PDHT_MARK(1);
   // ---- level 2: the point data of the first round of BOTH kinds of task are requested before anything is computed
   const int ntask2 = nsf + 3 * ncell; // second kind: normal-direction tasks, then cell tasks
-  TPts tp0 = tang_load(infoT, pbT, lane & 1);
+  TPts tp0 = tang_load(infoT, pbT, lane >> 1, lane & 1);
   double zeta0 = 0.0;
   CPts cp0;
   for (int i = 0; i < PMAX; ++i)
     cp0.x[i] = cp0.ws[i] = cp0.wc[i] = 0.0;
+  cp0.npts = 0;
   if (lane < nsf)
     zeta0 = P.ap_x[(int64_t)((infoN >> 8) & 3) * P.ap_stride + pbN];
   else if (lane < ntask2)
@@ -412,7 +427,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
           int info;
           int64_t pb;
           desc(tid >> 1, info, pb);
-          const TPts tp = tang_load(info, pb, tid & 1);
+          const TPts tp = tang_load(info, pb, tid >> 1, tid & 1);
           tang_compute(tp, tid >> 1, tid & 1, info);
         }
     }
@@ -531,7 +546,7 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
               int info;
               int64_t pb;
               desc(tid >> 1, info, pb);
-              const TPts tp = tang_load(info, pb, tid & 1);
+              const TPts tp = tang_load(info, pb, tid >> 1, tid & 1);
               tt.template tang_compute<false, true>(tp, tid >> 1, tid & 1, info);
             }
         }

@@ -65,7 +65,7 @@ extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int c
         return w == 8 ? 8 : 4;
       }();
       const size_t lds = (size_t)T->lds_bytes;
-      const bool small = T->fq_tensor_n <= 4 && T->vq_tensor_n <= 4;
+      const bool small = T->task_pts <= 4;
       auto go = [&](auto w_, auto shifted_, auto pmax_) {
         constexpr int W = decltype(w_)::value;
         hipLaunchKernelGGL((pdht::k_terms_wg<W, decltype(shifted_)::value, decltype(pmax_)::value>), dim3((unsigned)count), dim3(PDH_WAVE * W),
@@ -93,7 +93,7 @@ extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int c
     if (P->n != pdht::Kind<N, B>::NF)
       return;
     const size_t lds = (size_t)T->lds_bytes;
-    const bool small = T->fq_tensor_n <= 4 && T->vq_tensor_n <= 4; // (rules of up to 4 / up to 8 points per direction)
+    const bool small = T->task_pts <= 4; // (rules of up to 4 / up to 8 points per direction)
     auto go = [&](auto shifted_, auto pmax_) {
       constexpr bool S = decltype(shifted_)::value;
       constexpr int PM = decltype(pmax_)::value;

@@ -88,6 +88,8 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
     info = T.sf_info[at];
     pb = T.sf_pt[at];
   };
+  auto sf_ivl = [&](int sf, int dir) { return T.sf_ivl + ((sfb + (sf < T.maxsf ? sf : 0)) * 2 + dir) * TERMS_MI; };
+  auto cell_ivl = [&](int ct) { return T.cell_ivl + ((int64_t)slot * T.maxcell * 3 + ct) * TERMS_MI; };
   // ================= A: lane tasks, one kind per wave where they fit ==================================================
   // waves [0, W/2): (sub-face, tangential direction) tasks; waves [W/2, W): normal-direction tasks, then cell tasks - each wave a
   // contiguous share.  The descriptors and point data of a wave's first round are requested before the run entries are needed.
@@ -108,10 +110,11 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
     double zeta0 = 0.0;
     for (int i = 0; i < PMAX; ++i)
       tp0.x[i] = tp0.ws[i] = tp0.wc[i] = cp0.x[i] = cp0.ws[i] = cp0.wc[i] = 0.0;
+    tp0.npts = cp0.npts = 0;
     if (first_kind)
       {
         desc(on0 ? tid0 >> 1 : 0, info0, pb0);
-        tp0 = tt.tang_load(info0, pb0, tid0 & 1);
+        tp0 = tt.tang_load(info0, pb0, tid0 & 1, sf_ivl(on0 ? tid0 >> 1 : 0, tid0 & 1));
       }
     else if (on0 && tid0 < nsf)
       {
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
         zeta0 = P.ap_x[(int64_t)((info0 >> 8) & 3) * P.ap_stride + pb0];
       }
     else if (on0)
-      cp0 = tt.cell_load(tid0 - nsf);
+      cp0 = tt.cell_load(tid0 - nsf, cell_ivl(tid0 - nsf));
     __syncthreads(); // run entries in LDS (nothing of this workgroup is in flight towards HBM yet: the wait costs nothing)
     if (first_kind)
       {
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
             int info;
             int64_t pb;
             desc(tid >> 1, info, pb);
-            const typename TT::TPts tp = tt.tang_load(info, pb, tid & 1);
+            const typename TT::TPts tp = tt.tang_load(info, pb, tid & 1, sf_ivl(tid >> 1, tid & 1));
             tt.tang_compute(tp, tid >> 1, tid & 1, info);
           }
       }
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
               }
             else
               {
-                const typename TT::CPts cp = tt.cell_load(tid - nsf);
+                const typename TT::CPts cp = tt.cell_load(tid - nsf, cell_ivl(tid - nsf));
                 tt.cell_compute(cp, tid - nsf);
               }
           }

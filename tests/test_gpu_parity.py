@@ -1,4 +1,6 @@
 """GPU parity: HIP path (through the C ABI) vs the oracle on identical flattened inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1191,9 +1193,9 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world, basis, p):
     else:
         # the small elements take the term kernel (pdh_terms.h) while a polytope's tables fit its LDS budget (64 cells with 96
         # sub-faces do not), else the streamed kinds of pdh_rows.h - which must agree with it to rounding
-        # (degree 1: 2 x 2 matrices, even 64 cells fit; FE_AggloDGP(2): ten functions, tables in two passes, fit as well)
-        big = b == 4 and p >= 2 and not (basis == "dgp" and p == 2)
-        assert kern_0 == ("streamed" if big else "terms"), kern_0
+        # (blocks of 4^3 cells: 64 cells and 96 sub-faces would not fit, but they form tensor grids and are summed over as 8 cells and 24
+        # sub-faces with composite rules - pdh_terms_merge_stats; the box-shaped agglomerates of the b = 0 cases likewise)
+        assert kern_0 == "terms", kern_0
         vs, used_s, kern_s = _values_k(kw, "rows", terms=False)
         assert used_s == "rows" and kern_s == "streamed"
         assert_parity_ah(vs, ref, ah, diag_first, what="rows (streamed kind)")
@@ -1858,8 +1860,19 @@ def test_cartesian_description_refuses_what_it_cannot_describe():
     ah.distribute_agglomerated_dofs(fe)
     cf = ah.flatten_cartesian(pa.SipVariant.poisson_example(fe))
     ctx = pa.Context(0)
-    with pytest.raises(pa.PdhError, match="points"):
-        ctx.set_problem(cf)
+    os.environ["PDH_TERMS_MERGE"] = "0"  # (summed over as given; merged into 2^3 cells and 2 x 2 sub-faces per plane they fit, below)
+    try:
+        with pytest.raises(pa.PdhError, match="points"):
+            ctx.set_problem(cf)
+    finally:
+        del os.environ["PDH_TERMS_MERGE"]
     ctx.set_problem(ah.flatten(pa.SipVariant.poisson_example(fe)))  # the context is still usable; the points-based path takes it
-    assert ctx.algorithm_in_use() == "rows"
+    assert ctx.algorithm_in_use() == "rows" and ctx.rows_kernel_in_use() == "pieces"
+    ref = ctx.assemble()
+    ctx.set_problem(cf)
+    assert ctx.rows_kernel_in_use() == "terms"
+    st = ctx.terms_merge_stats()
+    assert st["cells"] == 512 and st["cells_merged"] == 64 and st["sub_faces_merged"] * 4 == st["sub_faces"]
+    got = ctx.assemble()
+    assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref))
     ctx.close()
