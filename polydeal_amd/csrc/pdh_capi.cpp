@@ -88,7 +88,9 @@ extern "C" hipError_t pdh_launch_gen_volume(int nq, const double *nodes, const d
 extern "C" hipError_t pdh_launch_gen_faces(int nqf, const double *nodes, const double *weights, const double *d_box, const int32_t *d_cell,
                                            const int32_t *d_face, int64_t n_points, double *fq_x, double *fq_n, double *fq_w,
                                            hipStream_t stream);
-extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell, int split);
+extern "C" hipError_t pdh_launch_terms_gather(const PdhDev *P, const PdhTerms *T, double *out, int count, hipStream_t stream);
+extern "C" int pdh_terms_task_doubles(int maxsf, int maxcell, int pm);
+extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell, int split, int task_pts);
 extern "C" int pdh_rows_max_faces(void);
 extern "C" int pdh_moment_table_doubles(int n1d);
 
@@ -1816,6 +1818,28 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
   const bool merge = !(me && me[0] == '0');
   std::vector<TermsMerged> MG((size_t)K.n_owned);
   host_parallel_for((size_t)K.n_owned, [&](size_t sl) { merge_terms_of_slot(p, K, RH, vq_n, fn, sl, order[sl], merge, MG[sl]); });
+  if (merge && !(me && me[0] == '2'))
+    { // composite rules cost every lane task of the problem 8 instead of 4 register slots and points: taken when they remove at least
+      // a third of what is summed over - block agglomerates lose 7 / 8 of their cells, METIS-like ones a few per cent (and ran 4-8 %
+      // slower merged, profiles/r04_terms_merge.txt).  PDH_TERMS_MERGE=2 merges whatever can be merged.
+      int64_t n_in = 0, n_out = 0;
+      for (int sl = 0; sl < K.n_owned; ++sl)
+        {
+          n_in += (K.vq_ptr[sl + 1] - K.vq_ptr[sl]) / m3;
+          n_out += (int64_t)MG[(size_t)sl].cells.size();
+          for (size_t e = 0; e < order[sl].size(); ++e)
+            {
+              n_in += K.run_cnt[order[sl][e]] / gsz;
+              n_out += (int64_t)MG[(size_t)sl].runs[e].size();
+            }
+        }
+      if (3 * n_out > 2 * n_in)
+        {
+          for (auto &m : MG)
+            m = TermsMerged();
+          host_parallel_for((size_t)K.n_owned, [&](size_t sl) { merge_terms_of_slot(p, K, RH, vq_n, fn, sl, order[sl], false, MG[sl]); });
+        }
+    }
   int ivl_c = 1, ivl_f = 1;
   for (int sl = 0; sl < K.n_owned; ++sl)
     {
@@ -1854,8 +1878,8 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
     // instructions), and so does FE_DGQ(2): with 27 functions its phases are bound by VALU issue rather than by latency, and the
     // second evaluation of the bases costs more than three more waves give (grown agglomerates of the bench cells: 0.79 ms in one
     // pass at 6 waves, 0.83 in two at 9; FE_AggloDGP(3) 0.71 -> 0.59, FE_AggloDGP(2) 0.29 -> 0.24: profiles/r04_terms_split.txt)
-    const int one = pdh_terms_lds_bytes(K.n1d, basis, T.maxruns, T.maxsf, T.maxsi, T.maxcell, 0);
-    const int two = pdh_terms_lds_bytes(K.n1d, basis, T.maxruns, T.maxsf, T.maxsi, T.maxcell, 1);
+    const int one = pdh_terms_lds_bytes(K.n1d, basis, T.maxruns, T.maxsf, T.maxsi, T.maxcell, 0, T.task_pts);
+    const int two = pdh_terms_lds_bytes(K.n1d, basis, T.maxruns, T.maxsf, T.maxsi, T.maxcell, 1, T.task_pts);
     auto waves = [](int bytes) { return bytes <= 0 ? 0 : std::min(12, (int)(160 * 1024 / (((int64_t)bytes + 1279) / 1280 * 1280))); };
     const char *fs = getenv("PDH_TERMS_SPLIT"); // (diagnostics: 0 / 1 forces the form)
     T.split = fs ? (fs[0] == '1') : ((waves(two) > waves(one) && K.n <= 20) ? 1 : 0);
@@ -2502,12 +2526,13 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
       // per neighbour.  PDH_TERMS=0 (diagnostics) keeps the kinds of pdh_rows.h.
       const char *terms_e = getenv("PDH_TERMS"); // (read per call: the tests compare both kernels in one process)
       const bool terms_env = !(terms_e && terms_e[0] == '0');
-      // (FE_DGQ(3) has the workgroup-per-polytope form of the term kernel, pdh_terms_wg.h: taken only on request - PDH_TERMS_DGQ3=1 -
-      // while pdh_rows.h is the measured default for that element)
+      // (FE_DGQ(3) has the workgroup-per-polytope form of the term kernel, pdh_terms_wg.h: the default where it applies since the records
+      // of 1-D rules and the merged cells - 1.28-1.35 ms on the bench mesh where pdh_rows.h takes 1.59-1.66, never slower on the other
+      // shapes tried, profiles/r04_wg_forms.txt; PDH_TERMS_DGQ3=0 keeps pdh_rows.h for that element)
       const int terms_kind = pdh_terms_has_kind(K.n1d, p->basis == PDH_BASIS_AGGLODGP ? 1 : 0);
       const char *terms_q3 = getenv("PDH_TERMS_DGQ3");
       if ((terms_env || cart) && RH.planar_ok && RH.fq_tensor_n > 0 &&
-          (terms_kind == 1 || (terms_kind == 2 && (cart || (terms_q3 && terms_q3[0] == '1')))))
+          (terms_kind == 1 || (terms_kind == 2 && (cart || !(terms_q3 && terms_q3[0] == '0')))))
         {
           if (vq_n_terms < 0)
             vq_n_terms = resolve_tensor_hint(p->vq_tensor_n, [&](int n) { return volume_rules_are_tensor(p, K, n); });
@@ -2527,6 +2552,31 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
               T.lds_bytes = TH.lds_bytes;
               T.split = TH.split;
               T.task_pts = TH.task_pts;
+              {
+                // the 1-D rules the kernels read, gathered on the device from the point arrays (zero-filled: slots behind a rule)
+                T.tpm = TH.task_pts > 4 ? 8 : 4;
+                T.tstride = pdh_terms_task_doubles(T.maxsf, T.maxcell, T.tpm);
+                void *dt = nullptr;
+                const size_t nb = (size_t)std::max(K.n_owned, 1) * T.tstride * sizeof(double);
+                hipError_t eg = hipMalloc(&dt, nb);
+                if (eg == hipSuccess)
+                  {
+                    ctx->allocs.push_back(dt);
+                    eg = hipMemsetAsync(dt, 0, nb, ctx->stream);
+                  }
+                if (eg == hipSuccess)
+                  {
+                    T.tdata = static_cast<const double *>(dt);
+                    eg = pdh_launch_terms_gather(&ctx->dev, &T, static_cast<double *>(dt), K.n_owned, ctx->stream);
+                  }
+                if (eg == hipSuccess)
+                  eg = hipStreamSynchronize(ctx->stream);
+                if (eg != hipSuccess)
+                  {
+                    free_problem(ctx);
+                    return fail(ctx, PDH_EDEVICE, std::string("term kernel: records of 1-D rules: ") + hipGetErrorString(eg));
+                  }
+              }
               ctx->terms_merge[0] = TH.n_cells_in, ctx->terms_merge[1] = TH.n_cells_out;
               ctx->terms_merge[2] = TH.n_sf_in, ctx->terms_merge[3] = TH.n_sf_out;
               {

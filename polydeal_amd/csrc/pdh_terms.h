@@ -112,6 +112,13 @@ __host__ __device__ constexpr int terms_lds_doubles(int maxruns, int maxsf, int 
   return terms_rec_doubles(maxruns) + dg + xa + da + (da & 1);
 }
 
+// A polytope's record of 1-D rules (PdhTerms::tdata): the points of every (sub-face, tangential direction) and (cell, direction) task
+// [task][x | w_self | w_cross][pmax], then per sub-face its plane coordinate and descriptor
+__host__ __device__ constexpr int terms_task_doubles(int maxsf, int maxcell, int pmax)
+{
+  return (2 * maxsf + 3 * maxcell) * pmax * 3 + 2 * maxsf;
+}
+
 // Phase A of the term kernels: the lane tasks that build the small matrices of a polytope in LDS.  Shared by the wave-per-polytope
 // kernel below and the workgroup-per-polytope kernel of pdh_terms_wg.h.  PMAX: most points per direction of a rule (4 or 8): the
 // point data of a task sit in registers.
@@ -125,7 +132,8 @@ struct TermTasks
   double *Xa, *Da, *Ca;
   double lo0, lo1, lo2, ih0, ih1, ih2; // own box: lower corner, 1 / side
   int nsfb, fn, tn;
-  int64_t vq_b;
+  const double *gr; // the polytope's record of 1-D rules (PdhTerms::tdata)
+  int maxsf, maxcell;
   __device__ __forceinline__ static double sel3(int c, double x0, double x1, double x2) { return c == 0 ? x0 : (c == 1 ? x1 : x2); }
   // 1-D basis in the centred variable of a box (pdh_basis.h: monomial coefficients, uniform -> scalar operands)
   __device__ __forceinline__ void basis(double t, double *b) const
@@ -160,29 +168,20 @@ struct TermTasks
   };
   using TPts = Pts;
   using CPts = Pts;
-  // interval of point i of a composite rule of m-point rules (i < PMAX <= 8, m >= 2: at most TERMS_MI = 4 intervals)
-  __device__ __forceinline__ static int ivl_of(int i, int m) { return (i >= m ? 1 : 0) + (i >= 2 * m ? 1 : 0) + (i >= 3 * m ? 1 : 0); }
-  __device__ __forceinline__ static int sel4(int i, int a, int b, int c, int d) { return i == 0 ? a : (i == 1 ? b : (i == 2 ? c : d)); }
-  // ivl: the TERMS_MI interval entries of this (sub-face, direction) - PdhTerms::sf_ivl
-  __device__ __forceinline__ TPts tang_load(int info, int64_t pb, int dir, const int32_t *__restrict__ ivl) const
-  { // all loads of a task at once (intervals x fn <= PMAX, checked by the host)
+  __device__ __forceinline__ TPts tang_load(int info, int sf, int dir) const
+  { // all loads of a task at once: one contiguous piece of the polytope's record
     TPts r;
-    const int c = (info >> 8) & 3;
-    const bool fast_j = ((info >> 11) & 1) != 0;
-    const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
-    const int64_t stp = ((dir == 1) == fast_j) ? 1 : fn;
+    const double *g = gr + (2 * sf + dir) * (3 * PMAX);
     r.npts = ((info >> (dir ? 15 : 12)) & 7) * fn;
-    const int o0 = ivl[0], o1 = ivl[1], o2 = ivl[2], o3 = ivl[3];
     static_for<0, PMAX>([&](auto i_) {
       constexpr int al = i_;
-      const int ii = ivl_of(al, fn);
-      const int64_t q = al < r.npts ? pb + sel4(ii, o0, o1, o2, o3) + (al - ii * fn) * stp : pb;
-      r.x[al] = P.ap_x[(int64_t)ax * P.ap_stride + q];
-      r.ws[al] = P.ap_wself[q];
-      r.wc[al] = P.ap_wcross[q]; // (zero on the boundary)
+      r.x[al] = g[al];
+      r.ws[al] = g[PMAX + al];
+      r.wc[al] = g[2 * PMAX + al]; // (zero on the boundary)
     });
     return r;
   }
+  __device__ __forceinline__ double zeta_load(int sf) const { return gr[(2 * maxsf + 3 * maxcell) * (3 * PMAX) + sf]; }
   // WANT_D / WANT_X: which of the two kinds of table a call produces (both by default; the kernel of FE_AggloDGP(3) makes them in
   // two phases so that the X tables can take the place of the D tables in LDS)
   template <bool WANT_D = true, bool WANT_X = true>
@@ -263,22 +262,17 @@ struct TermTasks
     });
   }
   // (cell, direction): M_d and K_d.  The rule of a cell is a_i b_j c_k: direction 0 takes w_(i,0,0), the others w / w_000
-  // ivl: the TERMS_MI interval entries of this (cell, direction) - PdhTerms::cell_ivl
-  __device__ __forceinline__ CPts cell_load(int ct, const int32_t *__restrict__ ivl) const
+  __device__ __forceinline__ CPts cell_load(int ct) const
   {
     CPts r;
-    const int cell = ct / 3, d = ct - 3 * cell;
-    const int c0 = ivl[0], c1 = ivl[1], c2 = ivl[2], c3 = ivl[3];
-    r.npts = ((c0 >= 0 ? 1 : 0) + (c1 >= 0 ? 1 : 0) + (c2 >= 0 ? 1 : 0) + (c3 >= 0 ? 1 : 0)) * tn;
-    const int64_t m3 = (int64_t)tn * tn * tn;
-    const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
+    const double *g = gr + (2 * maxsf + ct) * (3 * PMAX);
+    r.npts = 0;
     static_for<0, PMAX>([&](auto i_) {
       constexpr int i = i_;
-      const int ii = ivl_of(i, tn);
-      const int64_t q = i < r.npts ? vq_b + sel4(ii, c0, c1, c2, c3) * m3 + (i - ii * tn) * step : vq_b + (c0 >= 0 ? c0 : 0) * m3;
-      r.x[i] = P.vq_x[(int64_t)d * P.vq_stride + q];
-      r.ws[i] = P.vq_w[q];
+      r.x[i] = g[i];
+      r.ws[i] = g[PMAX + i];
       r.wc[i] = 0.0;
+      r.npts += r.ws[i] != 0.0 ? 1 : 0; // (slots behind the last interval carry zero weights)
     });
     return r;
   }
@@ -319,6 +313,70 @@ struct TermTasks
   }
 };
 
+// Set-up (once per problem): the 1-D rules of polytope `slot` gathered from the point arrays through the descriptors of PdhTerms into its
+// record out[tstride] (layout: PdhTerms::tdata).  nt threads share the work.
+__device__ __forceinline__ void terms_gather_record(const PdhDev &P, const PdhTerms &T, int slot, int tid, int nt, double *__restrict__ out)
+{
+  const int REC = TERMS_HDR + T.maxruns * TERMS_ENT;
+  const double *g = T.meta + (int64_t)slot * REC;
+  const int ncell = (int)((__double_as_longlong(g[0]) >> 16) & 0xffff), nsf = (int)__double_as_longlong(g[11]);
+  const int64_t vq_b = __double_as_longlong(g[10]);
+  const int fn = T.fq_tensor_n, tn = T.vq_tensor_n, pm = T.tpm;
+  const int ntt = 2 * nsf, ntc = 3 * ncell;
+  const int64_t sfb = (int64_t)slot * T.maxsf;
+  for (int it = tid; it < (ntt + ntc) * pm; it += nt)
+    {
+      const int task = it / pm, al = it - task * pm;
+      double x = 0.0, ws = 0.0, wc = 0.0;
+      int at;
+      if (task < ntt)
+        {
+          const int sf = task >> 1, dir = task & 1;
+          const int info = T.sf_info[sfb + sf];
+          const int64_t pb = T.sf_pt[sfb + sf];
+          const int c = (info >> 8) & 3;
+          const bool fast_j = ((info >> 11) & 1) != 0;
+          const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
+          const int64_t stp = ((dir == 1) == fast_j) ? 1 : fn;
+          const int npts = ((info >> (dir ? 15 : 12)) & 7) * fn;
+          if (al < npts)
+            {
+              const int ii = (al >= fn ? 1 : 0) + (al >= 2 * fn ? 1 : 0) + (al >= 3 * fn ? 1 : 0);
+              const int64_t q = pb + T.sf_ivl[((sfb + sf) * 2 + dir) * TERMS_MI + ii] + (al - ii * fn) * stp;
+              x = P.ap_x[(int64_t)ax * P.ap_stride + q];
+              ws = P.ap_wself[q];
+              wc = P.ap_wcross[q]; // (zero on the boundary)
+            }
+          at = task;
+        }
+      else
+        {
+          const int ct = task - ntt, cell = ct / 3, d = ct - 3 * cell;
+          const int ii = (al >= tn ? 1 : 0) + (al >= 2 * tn ? 1 : 0) + (al >= 3 * tn ? 1 : 0);
+          const int ci = ii < TERMS_MI ? T.cell_ivl[((int64_t)slot * T.maxcell * 3 + ct) * TERMS_MI + ii] : -1;
+          if (ci >= 0)
+            {
+              const int64_t step = d == 0 ? 1 : (d == 1 ? tn : tn * tn);
+              const int64_t q = vq_b + (int64_t)ci * (tn * tn * tn) + (al - ii * tn) * step;
+              x = P.vq_x[(int64_t)d * P.vq_stride + q];
+              ws = P.vq_w[q];
+            }
+          at = 2 * T.maxsf + ct;
+        }
+      double *pt = out + at * (3 * pm);
+      pt[al] = x;
+      pt[pm + al] = ws;
+      pt[2 * pm + al] = wc;
+    }
+  double *zt = out + (2 * T.maxsf + 3 * T.maxcell) * (3 * pm);
+  for (int sf = tid; sf < nsf; sf += nt)
+    {
+      const int info = T.sf_info[sfb + sf];
+      zt[sf] = P.ap_x[(int64_t)((info >> 8) & 3) * P.ap_stride + T.sf_pt[sfb + sf]];
+      zt[T.maxsf + sf] = __longlong_as_double((long long)info);
+    }
+}
+
 // PMAX: most points per direction of a rule the instantiation takes (4 or 8): the point data of a lane task sit in registers
 template <int N1D, int BASIS, bool SHIFTED, int PMAX, bool SPLIT>
 __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const PdhTerms T, const int n_owned)
@@ -352,20 +410,17 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
   const int64_t rbase = __double_as_longlong(g[7]);
   const int rlen = (int)__double_as_longlong(g[8]);
   const int L = (int)__double_as_longlong(g[9]);
-  const int64_t vq_b = __double_as_longlong(g[10]);
   const int fn = T.fq_tensor_n, tn = T.vq_tensor_n;
-  const int64_t sfb = (int64_t)slot * T.maxsf;
-  auto desc = [&](int sf, int &info, int64_t &pb) { // (entries behind a polytope's sub-faces are zero: harmless to load)
-    const int64_t at = sfb + (sf < T.maxsf ? sf : 0);
-    info = T.sf_info[at];
-    pb = T.sf_pt[at];
+  // the polytope's record of 1-D rules (PdhTerms::tdata): everything phase A reads from HBM besides the run entries, at addresses
+  // that depend on the slot alone
+  const double *gr = T.tdata + (int64_t)slot * T.tstride;
+  const double *gr_info = gr + (2 * T.maxsf + 3 * T.maxcell) * (3 * PMAX) + T.maxsf;
+  auto desc = [&](int sf, int &info) { // (entries behind a polytope's sub-faces are zero: harmless to load)
+    info = (int)__double_as_longlong(gr_info[sf < T.maxsf ? sf : 0]);
   };
-  auto sf_ivl = [&](int sf, int dir) { return T.sf_ivl + ((sfb + (sf < T.maxsf ? sf : 0)) * 2 + dir) * TERMS_MI; };
-  auto cell_ivl = [&](int ct) { return T.cell_ivl + ((int64_t)slot * T.maxcell * 3 + ct) * TERMS_MI; };
-  int infoT, infoN;
-  int64_t pbT, pbN;
-  desc(lane >> 1, infoT, pbT);
-  desc(lane, infoN, pbN);
+  int infoT = 0, infoN = 0;
+  desc(lane >> 1, infoT);
+  desc(lane, infoN);
   for (int k0 = 0; k0 < T.maxruns * TERMS_ENT; k0 += 4 * PDH_WAVE)
     { // (four loads in flight per lane: a rolled copy loop would wait for every single one)
       double rv[4];
@@ -396,23 +451,28 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
   using TT = TermTasks<N1D, BASIS, PMAX>;
   using TPts = typename TT::TPts;
   using CPts = typename TT::CPts;
-  const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, vq_b};
-  auto tang_load = [&](int info, int64_t pb, int sf, int dir) { return tt.tang_load(info, pb, dir, sf_ivl(sf, dir)); };
+  const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, gr, T.maxsf, T.maxcell};
+  auto tang_load = [&](int info, int sf, int dir) { return tt.tang_load(info, sf < T.maxsf ? sf : 0, dir); };
   auto tang_compute = [&](const TPts &r, int sf, int dir, int info) { tt.template tang_compute<true, !SPLIT>(r, sf, dir, info); };
   auto norm_compute = [&](double zeta, int sf, int info) { tt.template norm_compute<true, !SPLIT>(zeta, sf, info); };
-  auto cell_load = [&](int ct) { return tt.cell_load(ct, cell_ivl(ct)); };
+  auto cell_load = [&](int ct) { return tt.cell_load(ct); };
   auto cell_compute = [&](const CPts &r, int ct) { tt.cell_compute(r, ct); };
   PDHT_MARK(1);
+  TPts tp0; // (first round of the task form; the two-pass form uses its point data twice)
+  double zeta0 = 0.0;
+  tp0.npts = 0;
+  // (an "entry form" of phase A - lane = one entry (k, l) of one task's matrix, the points staged in LDS - was measured against these
+  // lane tasks: 1.6 x the instructions for a shorter critical path; FE_AggloDGP(3) 0.32 -> 0.39 ms, FE_DGQ(2) 0.41 -> 0.50 here, 1.30 vs
+  // 1.28 ms in the workgroup kernel of pdh_terms_wg.h whose waves share the entries - profiles/r04_wg_forms.txt; not kept)
   // ---- level 2: the point data of the first round of BOTH kinds of task are requested before anything is computed
   const int ntask2 = nsf + 3 * ncell; // second kind: normal-direction tasks, then cell tasks
-  TPts tp0 = tang_load(infoT, pbT, lane >> 1, lane & 1);
-  double zeta0 = 0.0;
+  tp0 = tang_load(infoT, lane >> 1, lane & 1);
   CPts cp0;
   for (int i = 0; i < PMAX; ++i)
     cp0.x[i] = cp0.ws[i] = cp0.wc[i] = 0.0;
   cp0.npts = 0;
   if (lane < nsf)
-    zeta0 = P.ap_x[(int64_t)((infoN >> 8) & 3) * P.ap_stride + pbN];
+    zeta0 = tt.zeta_load(lane);
   else if (lane < ntask2)
     cp0 = cell_load(lane - nsf);
   __builtin_amdgcn_sched_barrier(0);
@@ -425,9 +485,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
       if (tid < 2 * nsf)
         {
           int info;
-          int64_t pb;
-          desc(tid >> 1, info, pb);
-          const TPts tp = tang_load(info, pb, tid >> 1, tid & 1);
+          desc(tid >> 1, info);
+          const TPts tp = tang_load(info, tid >> 1, tid & 1);
           tang_compute(tp, tid >> 1, tid & 1, info);
         }
     }
@@ -442,9 +501,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
       if (tid < nsf)
         {
           int info;
-          int64_t pb;
-          desc(tid, info, pb);
-          norm_compute(P.ap_x[(int64_t)((info >> 8) & 3) * P.ap_stride + pb], tid, info);
+          desc(tid, info);
+          norm_compute(tt.zeta_load(tid), tid, info);
         }
       else if (tid < ntask2)
         {
@@ -544,9 +602,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
           if (tid < 2 * nsf)
             {
               int info;
-              int64_t pb;
-              desc(tid >> 1, info, pb);
-              const TPts tp = tang_load(info, pb, tid >> 1, tid & 1);
+              desc(tid >> 1, info);
+              const TPts tp = tang_load(info, tid >> 1, tid & 1);
               tt.template tang_compute<false, true>(tp, tid >> 1, tid & 1, info);
             }
         }
@@ -558,9 +615,8 @@ __global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const Pdh
           if (tid < nsf)
             {
               int info;
-              int64_t pb;
-              desc(tid, info, pb);
-              tt.template norm_compute<false, true>(P.ap_x[(int64_t)((info >> 8) & 3) * P.ap_stride + pb], tid, info);
+              desc(tid, info);
+              tt.template norm_compute<false, true>(tt.zeta_load(tid), tid, info);
             }
         }
       PDH_WAVE_SYNC();

@@ -36,9 +36,10 @@ extern "C" int pdh_terms_has_kind(int n1d, int basis)
 
 // dynamic LDS of a workgroup for the maxima of a resident problem, bytes (0: no such kind)
 // split: the two-phase form of the wave-per-polytope kernel (pdh_terms.h: SPLIT; ignored for the workgroup kernel)
-extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell, int split)
+extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, int maxsi, int maxcell, int split, int task_pts)
 {
   int bytes = 0;
+  (void)task_pts;
   if (n1d == 4 && basis == 0)
     return 8 * pdht::terms_lds_doubles<4, 0, false>(maxruns, maxsf, maxsi, maxcell);
   for_kind(n1d, basis, [&](auto n_, auto b_) {
@@ -48,6 +49,23 @@ extern "C" int pdh_terms_lds_bytes(int n1d, int basis, int maxruns, int maxsf, i
   });
   return bytes;
 }
+
+// Set-up, once per problem: the records of 1-D rules (PdhTerms::tdata) from the point arrays resident in HBM
+__global__ void __launch_bounds__(PDH_WAVE) k_terms_gather(const PdhDev P, const PdhTerms T, double *__restrict__ out, const int n_owned)
+{
+  const int slot = blockIdx.x;
+  if (slot < n_owned)
+    pdht::terms_gather_record(P, T, slot, threadIdx.x, PDH_WAVE, out + (int64_t)slot * T.tstride);
+}
+extern "C" hipError_t pdh_launch_terms_gather(const PdhDev *P, const PdhTerms *T, double *out, int count, hipStream_t stream)
+{
+  if (count <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(k_terms_gather, dim3((unsigned)count), dim3(PDH_WAVE), 0, stream, *P, *T, out, count);
+  return hipGetLastError();
+}
+// doubles of a polytope's record of 1-D rules
+extern "C" int pdh_terms_task_doubles(int maxsf, int maxcell, int pm) { return pdht::terms_task_doubles(maxsf, maxcell, pm); }
 
 extern "C" hipError_t pdh_launch_terms(const PdhDev *P, const PdhTerms *T, int count, hipStream_t stream)
 {

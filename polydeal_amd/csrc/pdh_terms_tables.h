@@ -22,6 +22,15 @@ struct PdhTerms
   const int32_t *cell_ivl; // [n_owned][maxcell][3][TERMS_MI] per direction: the polytope's cell (rule of vq_tensor_n^3 points) that carries
                           // the 1-D rule of every interval, -1: no such interval
   int32_t task_pts;       // most points of a 1-D composite rule (vq_tensor_n / fq_tensor_n x intervals): 4 or 8 register slots per lane task
+  // The 1-D rules the kernels work from, gathered ONCE per problem on the device (pdh_terms.hip: k_terms_gather) from the point arrays
+  // through the descriptors above - per owned polytope one record of tstride doubles (pdh_terms.h: terms_task_doubles):
+  //   task (sub-face sf, tangential direction dir) at (2 sf + dir) * 3 tpm: coordinates [tpm] | own-side weights [tpm] | side-1 weights [tpm]
+  //   task (cell c, direction d) at (2 maxsf + 3 c + d) * 3 tpm: coordinates | weights | unused          (slots behind a rule: zeros)
+  //   then the plane coordinate of every sub-face [maxsf] and its descriptor sf_info [maxsf] (integer bits)
+  // An assembly reads these 3 KB per polytope (block agglomerates) in one contiguous request instead of chasing descriptor -> interval
+  // -> point through three dependent loads into the point arrays.
+  const double *tdata;
+  int32_t tstride, tpm;   // tpm = 4 or 8: slots per 1-D rule in the records = PMAX of the kernel instantiation that is launched
   int32_t maxruns;        // runs a record provides for
   int32_t maxsf, maxsi, maxcell; // most sub-faces / interior sub-faces / cells of one owned polytope
   int32_t vq_tensor_n, fq_tensor_n; // verified points per direction of the sub-cell / sub-face rules

@@ -75,23 +75,18 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
   const int64_t rbase = __double_as_longlong(g[7]);
   const int rlen = (int)__double_as_longlong(g[8]);
   const int L = (int)__double_as_longlong(g[9]);
-  const int64_t vq_b = __double_as_longlong(g[10]);
   const int fn = T.fq_tensor_n, tn = T.vq_tensor_n;
-  const int64_t sfb = (int64_t)slot * T.maxsf;
+  const double *gr = T.tdata + (int64_t)slot * T.tstride; // the polytope's record of 1-D rules
+  const double *gr_info = gr + (2 * T.maxsf + 3 * T.maxcell) * (3 * PMAX) + T.maxsf;
   for (int k = threadIdx.x; k < T.maxruns * TERMS_ENT; k += PDH_WAVE * W)
     rec[TERMS_HDR + k] = g[TERMS_HDR + k];
   double *Ca = Da + nsf * 3 * SYMS;
   using TT = TermTasks<N1D, BASIS, PMAX>;
-  const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, vq_b};
-  auto desc = [&](int sf, int &info, int64_t &pb) {
-    const int64_t at = sfb + (sf < T.maxsf ? sf : 0);
-    info = T.sf_info[at];
-    pb = T.sf_pt[at];
-  };
-  auto sf_ivl = [&](int sf, int dir) { return T.sf_ivl + ((sfb + (sf < T.maxsf ? sf : 0)) * 2 + dir) * TERMS_MI; };
-  auto cell_ivl = [&](int ct) { return T.cell_ivl + ((int64_t)slot * T.maxcell * 3 + ct) * TERMS_MI; };
-  // ================= A: lane tasks, one kind per wave where they fit ==================================================
-  // waves [0, W/2): (sub-face, tangential direction) tasks; waves [W/2, W): normal-direction tasks, then cell tasks - each wave a
+  const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, gr, T.maxsf, T.maxcell};
+  auto desc = [&](int sf, int &info) { info = (int)__double_as_longlong(gr_info[sf < T.maxsf ? sf : 0]); };
+  // ================= A ===============================================================================================
+  // lane tasks, one kind per wave where they fit: waves [0, W/2): (sub-face, tangential direction) tasks; waves [W/2, W):
+  // normal-direction tasks, then cell tasks - each wave a
   // contiguous share.  The descriptors and point data of a wave's first round are requested before the run entries are needed.
   {
     constexpr int H = W / 2;
@@ -104,7 +99,6 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
     const int tid0 = t_begin + lane;
     const bool on0 = tid0 < t_end;
     int info0 = 0;
-    int64_t pb0 = 0;
     typename TT::TPts tp0;
     typename TT::CPts cp0;
     double zeta0 = 0.0;
@@ -113,16 +107,16 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
     tp0.npts = cp0.npts = 0;
     if (first_kind)
       {
-        desc(on0 ? tid0 >> 1 : 0, info0, pb0);
-        tp0 = tt.tang_load(info0, pb0, tid0 & 1, sf_ivl(on0 ? tid0 >> 1 : 0, tid0 & 1));
+        desc(on0 ? tid0 >> 1 : 0, info0);
+        tp0 = tt.tang_load(info0, on0 ? tid0 >> 1 : 0, tid0 & 1);
       }
     else if (on0 && tid0 < nsf)
       {
-        desc(tid0, info0, pb0);
-        zeta0 = P.ap_x[(int64_t)((info0 >> 8) & 3) * P.ap_stride + pb0];
+        desc(tid0, info0);
+        zeta0 = tt.zeta_load(tid0);
       }
     else if (on0)
-      cp0 = tt.cell_load(tid0 - nsf, cell_ivl(tid0 - nsf));
+      cp0 = tt.cell_load(tid0 - nsf);
     __syncthreads(); // run entries in LDS (nothing of this workgroup is in flight towards HBM yet: the wait costs nothing)
     if (first_kind)
       {
@@ -131,9 +125,8 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
         for (int tid = tid0 + PDH_WAVE; tid < t_end; tid += PDH_WAVE)
           {
             int info;
-            int64_t pb;
-            desc(tid >> 1, info, pb);
-            const typename TT::TPts tp = tt.tang_load(info, pb, tid & 1, sf_ivl(tid >> 1, tid & 1));
+            desc(tid >> 1, info);
+            const typename TT::TPts tp = tt.tang_load(info, tid >> 1, tid & 1);
             tt.tang_compute(tp, tid >> 1, tid & 1, info);
           }
       }
@@ -148,13 +141,12 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
             if (tid < nsf)
               {
                 int info;
-                int64_t pb;
-                desc(tid, info, pb);
-                tt.norm_compute(P.ap_x[(int64_t)((info >> 8) & 3) * P.ap_stride + pb], tid, info);
+                desc(tid, info);
+                tt.norm_compute(tt.zeta_load(tid), tid, info);
               }
             else
               {
-                const typename TT::CPts cp = tt.cell_load(tid - nsf, cell_ivl(tid - nsf));
+                const typename TT::CPts cp = tt.cell_load(tid - nsf);
                 tt.cell_compute(cp, tid - nsf);
               }
           }

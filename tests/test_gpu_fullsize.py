@@ -245,13 +245,15 @@ def test_config4_diffusion_reaction_128cubed_dgq2_one_gpu():
     assert interior.sum() == (nb - 2) ** 3, interior.sum()
 
 
-def test_multi_row_kernel_beyond_the_resident_waves():
+def test_multi_row_kernel_beyond_the_resident_waves(monkeypatch):
     """MULTI row kernel (irregular agglomerates, staircase faces) on MORE polytopes than the device holds resident waves
     (32^3 cells in 4096 grown agglomerates; 2048 waves on 256 CUs): every wave works through several polytopes and re-uses its
     row of the coupling-moment scratch (PdhRows::m2c_scratch) - the small parity cases against the oracle give every wave
     one polytope.  Checked against the moment form (no scratch, no persistent waves; itself parity-tested against the oracle
     on the small cases) entry by entry, and through the size-independent identities  A 1 = 0 on interior rows,
-    1^T A 1 = sigma |dOmega| with the polytope-wise penalty the caller variant sets."""
+    1^T A 1 = sigma |dOmega| with the polytope-wise penalty the caller variant sets.  (PDH_TERMS_DGQ3=0: AUTO would take the
+    workgroup term kernel, which has no persistent waves.)"""
+    monkeypatch.setenv("PDH_TERMS_DGQ3", "0")
     grid = pa.BackgroundGrid.subdivided_hyper_cube(3, 32, 0.0, 1.0)
     ah = pa.AgglomerationHandler(grid)
     ah.define_grown_agglomerates(8, seed=3)

@@ -1188,18 +1188,15 @@ def test_row_kernel_parity(lg, b, vname, diag_first, world, basis, p):
     v0, used_0, kern_0 = _values_k(kw, "rows")
     assert used_0 == "rows"
     assert_parity_ah(v0, ref, ah, diag_first, what="rows")
-    if p == 3 and basis == "dgq":
-        assert kern_0 == "pieces"
-    else:
-        # the small elements take the term kernel (pdh_terms.h) while a polytope's tables fit its LDS budget (64 cells with 96
-        # sub-faces do not), else the streamed kinds of pdh_rows.h - which must agree with it to rounding
-        # (blocks of 4^3 cells: 64 cells and 96 sub-faces would not fit, but they form tensor grids and are summed over as 8 cells and 24
-        # sub-faces with composite rules - pdh_terms_merge_stats; the box-shaped agglomerates of the b = 0 cases likewise)
-        assert kern_0 == "terms", kern_0
-        vs, used_s, kern_s = _values_k(kw, "rows", terms=False)
-        assert used_s == "rows" and kern_s == "streamed"
-        assert_parity_ah(vs, ref, ah, diag_first, what="rows (streamed kind)")
-        assert np.max(np.abs(vs - v0)) <= 1e-13 * sc
+    # every element takes a term kernel (pdh_terms.h; FE_DGQ(3): its workgroup form, pdh_terms_wg.h) while a polytope's tables fit
+    # the LDS budget, else the kinds of pdh_rows.h - which must agree with it to rounding
+    # (blocks of 4^3 cells: 64 cells and 96 sub-faces would not fit, but they form tensor grids and are summed over as 8 cells and 24
+    # sub-faces with composite rules - pdh_terms_merge_stats; the box-shaped agglomerates of the b = 0 cases likewise)
+    assert kern_0 == "terms", kern_0
+    vs, used_s, kern_s = _values_k(kw, "rows", terms=False)
+    assert used_s == "rows" and kern_s == ("pieces" if (p == 3 and basis == "dgq") else "streamed")
+    assert_parity_ah(vs, ref, ah, diag_first, what="rows (kinds of pdh_rows.h)")
+    assert np.max(np.abs(vs - v0)) <= 1e-13 * sc
     # verified claims: bit-identical
     vf, used_f = _values(dict(kw, fq_tensor_n=nq, vq_tensor_n=nq), "rows")
     assert used_f == "rows" and np.array_equal(v0, vf)
@@ -1287,14 +1284,15 @@ def _grown_agglomerates(grid, cells_per_polytope, seed):
 
 @pytest.mark.parametrize("cells,per,vname,diag_first,seed", [(4, 4, "poisson", True, 0), (4, 8, "dr", False, 1), (6, 6, "adm", True, 2),
                                                              (6, 3, "test", True, 3), (8, 8, "poisson", True, 4)])
-def test_row_kernel_staircase_agglomerates(cells, per, vname, diag_first, seed):
+def test_row_kernel_staircase_agglomerates(cells, per, vname, diag_first, seed, monkeypatch):
     """Irregular agglomerates of Cartesian cells (regions grown over the cell graph, the METIS stand-in): neighbours are met
     along several planes, polytopes have many more than six faces, boundary runs span up to five planes.  FE_DGQ(3) takes the row
     kernel (MULTI instantiation: a coupling block is the sum of the Kronecker products of its planes): parity with the oracle
     per block, both CSR layouts, with and without the tensor structure of the rules, on row ranges; agreement with the moment
-    form to rounding."""
+    form to rounding.  (PDH_TERMS_DGQ3=0: AUTO would take the workgroup term kernel, test_term_kernel_workgroup_form_for_dgq3.)"""
     from polydeal_amd.partition import row_range
 
+    monkeypatch.setenv("PDH_TERMS_DGQ3", "0")
     fe = po.FE_DGQ(3, 3)
     grid = po.subdivided_hyper_cube(3, cells, 0.0, 1.0)
     groups = _grown_agglomerates(grid, per, seed)
@@ -1396,7 +1394,7 @@ def test_term_kernel_rules_of_up_to_eight_points(basis, p, nq):
                                                                 ("grown", 6, 6, "adm", True, 4), ("grown", 8, 8, "poisson", False, 4), ("grown", 6, 3, "minsip", True, 4),
                                                                 ("block", 4, 2, "adm", True, 7), ("boxes", 4, 0, "poisson", True, 4)])
 def test_term_kernel_workgroup_form_for_dgq3(kind, cells, per, vname, diag_first, nq, waves, monkeypatch):
-    """FE_DGQ(3) through the workgroup-per-polytope form of the term kernel (pdh_terms_wg.h; on request: PDH_TERMS_DGQ3=1, four or
+    """FE_DGQ(3) through the workgroup-per-polytope form of the term kernel (pdh_terms_wg.h: what AUTO takes for that element; four or
     eight waves per polytope): blocks, boxes of different sizes, staircase agglomerates, both CSR layouts, rules of 4 and 7 points
     per direction, row ranges - per-block parity with the oracle and agreement with the kinds of pdh_rows.h to rounding."""
     import subprocess
@@ -1442,8 +1440,10 @@ def _wg_case(kind, cells, per, vname, diag_first, nq):
     assert used == "rows" and kern == "terms"
     assert_parity_ah(v0, ref, ah, diag_first, what="workgroup term kernel")
     os.environ["PDH_TERMS_DGQ3"] = "0"
-    v1, used1, kern1 = _values_k(kw, "auto")
-    os.environ["PDH_TERMS_DGQ3"] = "1"
+    try:
+        v1, used1, kern1 = _values_k(kw, "auto")
+    finally:
+        os.environ["PDH_TERMS_DGQ3"] = "1"
     assert used1 == "rows" and kern1 in ("pieces", "multi")
     assert np.max(np.abs(v0 - v1)) <= 1e-13 * np.max(np.abs(ref))
     n = fe.n_dofs_per_cell
@@ -1456,11 +1456,12 @@ def _wg_case(kind, cells, per, vname, diag_first, nq):
     assert_parity_ah(np.concatenate(parts), ref, ah, diag_first, what="workgroup term kernel, row ranges")
 
 
-def test_row_kernel_staircase_with_large_plane_entries():
+def test_row_kernel_staircase_with_large_plane_entries(monkeypatch):
     """MULTI instantiation with plane entries of MORE sub-faces than one staging round of its S takes (14): 4x4x4 blocks of an
     8^3 grid, one corner cell moved from block A to its +x neighbour B - A and B then meet along a 15-sub-face plane, a
     16-sub-face plane's worth of neighbours elsewhere, and the moved cell adds one-sub-face planes of three axes.  Parity with
-    the oracle per block; tensor rules and general points."""
+    the oracle per block; tensor rules and general points.  (PDH_TERMS_DGQ3=0: pdh_rows.h, not the workgroup term kernel.)"""
+    monkeypatch.setenv("PDH_TERMS_DGQ3", "0")
     fe = po.FE_DGQ(3, 3)
     grid = po.subdivided_hyper_cube(3, 8, 0.0, 1.0)
     c = lambda i, j, k: int(grid.ijk_to_cell[(i, j, k)])
@@ -1743,7 +1744,7 @@ def test_row_kernel_staircase_rank_local_descriptions(world, basis, p):
     ctx = pa.Context(0)
     ctx.set_problem(gflat)
     assert ctx.algorithm_in_use() == "rows"
-    assert ctx.rows_kernel_in_use() == ("multi" if (basis, p) == ("dgq", 3) else "terms")
+    assert ctx.rows_kernel_in_use() == "terms"
     gvals = ctx.assemble()
     ctx.close()
     # oracle on the same agglomerates
@@ -1866,7 +1867,11 @@ def test_cartesian_description_refuses_what_it_cannot_describe():
             ctx.set_problem(cf)
     finally:
         del os.environ["PDH_TERMS_MERGE"]
-    ctx.set_problem(ah.flatten(pa.SipVariant.poisson_example(fe)))  # the context is still usable; the points-based path takes it
+    os.environ["PDH_TERMS_DGQ3"] = "0"
+    try:
+        ctx.set_problem(ah.flatten(pa.SipVariant.poisson_example(fe)))  # the context is still usable; pdh_rows.h takes the points
+    finally:
+        del os.environ["PDH_TERMS_DGQ3"]
     assert ctx.algorithm_in_use() == "rows" and ctx.rows_kernel_in_use() == "pieces"
     ref = ctx.assemble()
     ctx.set_problem(cf)

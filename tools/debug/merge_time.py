@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Term kernels with and without merged cells / sub-faces (PDH_TERMS_MERGE), same process, same device: ms per assembly (HIP events), the
 numbers of cells and sub-faces summed over, largest difference between the two results; for FE_DGQ(3) also pdh_rows.h.
-usage: merge_time.py [cells=64] [cases: dgq3,dgp3,dgq2,dgp2,dgq1,dgp1] [block=2] [cartesian description: 0|1]"""
+usage: merge_time.py [cells=64] [cases: dgq3,dgp3,dgq2,dgp2,dgq1,dgp1] [block=2] [cartesian description: 0|1] [grown agglomerates: 0|1]"""
 import os
 import statistics
 import sys
@@ -17,9 +17,10 @@ cells = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cases = (sys.argv[2] if len(sys.argv) > 2 else "dgq3,dgp3,dgq2,dgp2,dgq1,dgp1").split(",")
 block = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 cart = len(sys.argv) > 4 and sys.argv[4] == "1"
+grown = len(sys.argv) > 5 and sys.argv[5] == "1"
 for cs in cases:
     basis, p = cs[:3], int(cs[3])
-    grid, ah, fe = bench.build_handler(pa, 3, cells, block, basis, p, p + 1)
+    grid, ah, fe = bench.build_handler(pa, 3, cells, block, basis, p, p + 1, grown=grown)
     var = pa.SipVariant.poisson_example(fe)
     flat = ah.flatten_cartesian(var, True, False) if cart else ah.flatten(var, True, False)
     res = {}
