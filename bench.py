@@ -602,6 +602,19 @@ def main():
             extra.update(algorithmic_bytes_per_step=by2, hbm_GBs=by2 / (r2["dt"] / args.steps) * 1e-9,
                          frac_of_hbm_peak=by2 / (r2["dt"] / args.steps) * 1e-9 / HBM_PEAK_GBS,
                          fp64_bound_ms=1e3 * sum(r2["work"]["flops"]) / (FP64_PEAK_TFLOPS * 1e12))
+    if not args.no_extra and world == 1 and main_res.get("rows_kernel") == "terms" and main_res["n"] == 64:
+        # the same workload through the kernel that was AUTO's choice for FE_DGQ(3) until round 4 (pdh_rows.h: moment form + MFMA
+        # contraction, one wave per polytope), same process, same device
+        os.environ["PDH_TERMS_DGQ3"] = "0"
+        try:
+            r9 = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, args.steps, args.warmup)
+            extra["pdh_rows_h"] = {"what": "headline workload with PDH_TERMS_DGQ3=0", "rows_kernel": r9["rows_kernel"],
+                                   "ms_per_step": 1e3 * r9["dt"] / args.steps, "kernel_ms": r9["kms"][0],
+                                   "frac_of_hbm_peak": r9["work"]["bytes_total"] / (r9["kms"][0] * 1e-3) * 1e-9 / HBM_PEAK_GBS}
+        except Exception as e:  # noqa: BLE001
+            extra["pdh_rows_h"] = {"error": str(e)[:200]}
+        finally:
+            del os.environ["PDH_TERMS_DGQ3"]
     if not args.no_extra and world == 1 and args.dim == 3 and args.degree == 3:
         # the lower degrees of the same mesh (streamed kinds of the row kernel; degree 2 is the element of BASELINE configs[1] / [3])
         import copy
@@ -749,19 +762,27 @@ def main():
             # ONE kernel writes every block of the rows (pdh_rows.h): its algorithmic bytes / flops are those of the whole step
             # (values once, volume q-data once, every face's q-data ONCE)
             tot_b, tot_f = w["bytes_total"] * frac_rows, (w["flops"][0] + w["flops"][1]) * frac_rows
-            ke[0] = {"kernel": "k_rows", "kernel_ms": t_k[0] * 1e3, "algorithmic_flops_per_launch": tot_f,
+            # the kernel that ran: term kernels (pdh_terms.h; FE_DGQ(3): the workgroup form, pdh_terms_wg.h) or a kind of pdh_rows.h
+            kname = ("k_terms_wg" if r["n"] == 64 else "k_terms") if r.get("rows_kernel") == "terms" else "k_rows"
+            ke[0] = {"kernel": kname, "kernel_ms": t_k[0] * 1e3, "algorithmic_flops_per_launch": tot_f,
                      "algorithmic_bytes_per_launch": tot_b, "algorithmic_TFLOPs": tot_f / t_k[0] * 1e-12,
-                     "hbm_achieved_GBs": tot_b / t_k[0] * 1e-9, "traffic": tj.get("k_rows_bytes")}
+                     "hbm_achieved_GBs": tot_b / t_k[0] * 1e-9, "traffic": tj.get(kname + "_bytes")}
         if r["alg"] == "rows":
-            roof = {"bound": "hbm", "kernel": "k_rows", "achieved": ke[0]["hbm_achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": ke[0]["kernel"], "achieved": ke[0]["hbm_achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ke[0]["hbm_achieved_GBs"] / HBM_PEAK_GBS, "traffic": ke[0]["traffic"],
                     "kernel_ms": ke[0]["kernel_ms"], "launches_timed": r["nl"],
+                    "traffic_GBs": None if ke[0]["traffic"] is None else ke[0]["traffic"] / (ke[0]["kernel_ms"] * 1e-3) * 1e-9,
+                    "traffic_note": ("`achieved` is SURVEY 8(d)'s algorithmic byte count / kernel time; the term kernels read the 1-D rules of a "
+                                     "polytope from one record gathered on the device at pdh_set_problem (3 KB per polytope here) instead of "
+                                     "the point arrays, so measured traffic lies BELOW the algorithmic bytes by most of their quadrature share")
+                                    if r.get("rows_kernel") == "terms" else None,
                     "algorithmic_bytes_per_launch": ke[0]["algorithmic_bytes_per_launch"],
                     "algorithmic_bytes_parts": {k: v * frac_rows for k, v in w["bytes_parts"].items()},
                     "algorithmic_flops_per_launch": ke[0]["algorithmic_flops_per_launch"],
-                    "algorithm": ("term kernel (pdh_terms.h): one wave per polytope writes all blocks of its rows; every entry a short "
-                                  "sum of products of three 1-D matrix entries (mass / stiffness per cell, trace / flux per sub-face) "
-                                  "held in LDS; no moments, no MFMA"
+                    "algorithm": ("term kernel (pdh_terms.h; FE_DGQ(3): pdh_terms_wg.h, a workgroup of four waves per polytope): the owner "
+                                  "writes all blocks of its rows; every entry a short sum of products of three 1-D matrix entries (mass / "
+                                  "stiffness per cell, trace / flux per sub-face) held in LDS; cells and sub-faces that form tensor grids are "
+                                  "summed over as one with composite 1-D rules; no moments, no MFMA"
                                   if r.get("rows_kernel") == "terms" else
                                   "row kernel (pdh_rows.h): one wave per polytope writes all blocks of its 64 rows as whole 128-byte "
                                   "lines; planar axis-aligned faces -> rank-one face moments, Kronecker form C (x) S of the coupling "

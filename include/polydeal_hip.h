@@ -284,12 +284,17 @@ int pdh_check_terms(const pdh_problem *problem, int32_t row_begin, int32_t row_e
 int pdh_terms_merge_stats(pdh_ctx *ctx, int64_t *out4);
 int pdh_set_algorithm(pdh_ctx *ctx, int algorithm);
 /* Which row kernel serves the resident problem (PDH_ALG_ROWS has several; all write whole rows, owner computes rows):
- *   PIECES   FE_DGQ(3), one plane per neighbour: moments + Kronecker form, rows in aligned 512-byte pieces (pdh_rows.h)
+ *   TERMS    every element of degree 1 .. 3 on agglomerates of Cartesian cells with tensor-product rules, while a polytope's 1-D tables
+ *            fit the kernels' LDS budget: every entry a short sum of products of three 1-D matrix entries per sub-cell / sub-face, any
+ *            number of planes per neighbour; cells / sub-faces that form tensor grids summed over as one with composite rules
+ *            (pdh_terms.h, one wave per polytope; FE_DGQ(3): pdh_terms_wg.h, a workgroup per polytope - PDH_TERMS_DGQ3=0 in the
+ *            environment keeps pdh_rows.h for that element; reference examples/poisson.cc:413, 543-566 - FE_AggloDGP on METIS
+ *            agglomerates - is this case)
+ *   PIECES   FE_DGQ(3), one plane per neighbour: moments + Kronecker form, rows in aligned 512-byte pieces (pdh_rows.h) - also
+ *            for rules without tensor structure
  *   MULTI    FE_DGQ(3), several planes per neighbour (METIS-like agglomerates of Cartesian cells; pdh_rows.h)
- *   STREAMED FE_DGQ(1,2) / FE_AggloDGP(1..3), moment form, one plane per neighbour (pdh_rows.h)
- *   TERMS    FE_DGQ(1,2) / FE_AggloDGP(1..3) on any agglomerate of Cartesian cells with tensor-product rules: every entry a
- *            short sum of products of three 1-D matrix entries, any number of planes per neighbour (pdh_terms.h; reference
- *            examples/poisson.cc:413, 543-566 - FE_AggloDGP on METIS agglomerates - is this case)                       */
+ *   STREAMED FE_DGQ(1,2) / FE_AggloDGP(1..3), moment form, one plane per neighbour (pdh_rows.h): polytopes beyond the LDS budget of
+ *            TERMS                                                                                                              */
 #define PDH_ROWS_NONE 0
 #define PDH_ROWS_PIECES 1
 #define PDH_ROWS_MULTI 2

@@ -1483,14 +1483,25 @@ struct TermsMerged
     int32_t ivl[2][TERMS_MI];
   };
   std::vector<Cell> cells;
-  std::vector<std::vector<Sf>> runs; // in the order of the record's runs
+  std::vector<Sf> sfs;      // run by run, in the order of the record's runs
+  std::vector<int> run_off; // [runs + 1] into sfs
+  int nsf = 0, nsi = 0, ivl_c = 1, ivl_f = 1; // sub-faces, interior sub-faces, most intervals of a cell / sub-face rule
+  int64_t n_in = 0;                           // cells + sub-faces as given
+  size_t run_size(size_t e) const { return (size_t)(run_off[e + 1] - run_off[e]); }
+  const Sf *run_begin(size_t e) const { return sfs.data() + run_off[e]; }
 };
 namespace
 {
+struct TermsSfGeom // a sub-face as the merge sees it: normal axis, side, orientation of its rule, plane and first tangential coordinates
+{
+  int c, pos, fj;
+  double z, xi, xj;
+};
 // indices of the values of v in the sorted list of its distinct values (equal within tol); returns the number of distinct values
 int cluster_1d(const std::vector<double> &v, double tol, std::vector<int> &idx)
 {
-  std::vector<size_t> o(v.size());
+  static thread_local std::vector<size_t> o; // (scratch: this runs once per polytope and plane on every host thread)
+  o.resize(v.size());
   for (size_t i = 0; i < o.size(); ++i)
     o[i] = i;
   std::sort(o.begin(), o.end(), [&](size_t a, size_t b) { return v[a] < v[b]; });
@@ -1532,8 +1543,8 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
       auto cellbox = [&](int u) { return K.cart->cell_box + (size_t)K.cart->vq_cell[p->vq_ptr[a] / m3 + u] * 6; };
       const int64_t b0 = K.vq_ptr[sl], st = K.vq_stride_h;
       const int64_t step[3] = {1, tn, (int64_t)tn * tn};
-      std::vector<double> key[3];
-      std::vector<int> idx[3];
+      static thread_local std::vector<double> key[3];
+      static thread_local std::vector<int> idx[3];
       int nd[3];
       for (int d = 0; d < 3; ++d)
         {
@@ -1543,7 +1554,7 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
           nd[d] = cluster_1d(key[d], 1e-9 * hbox[d], idx[d]);
         }
       bool ok = (int64_t)nd[0] * nd[1] * nd[2] == ncell;
-      std::vector<int> grid;
+      static thread_local std::vector<int> grid;
       if (ok)
         {
           grid.assign((size_t)ncell, -1);
@@ -1621,18 +1632,21 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
     single_cells();
   // ---------------- sub-faces, run by run
   const int mf = fn >= 1 && fn <= 4 ? std::min(TERMS_MI, 8 / fn) : 1;
-  M.runs.resize(order.size());
-  for (size_t e = 0; e < order.size(); ++e)
+  M.run_off.assign(order.size() + 1, 0);
+  {
+    size_t tot = 0;
+    for (size_t t : order)
+      tot += (size_t)(K.run_cnt[t] / gsz);
+    M.sfs.reserve(tot);
+  }
+  auto &out = M.sfs;
+  for (size_t e = 0; e < order.size(); M.run_off[e + 1] = (int)M.sfs.size(), ++e)
     {
       const size_t t = order[e];
       const int ns = (int)(K.run_cnt[t] / gsz);
-      auto &out = M.runs[e];
-      struct G
-      {
-        int c, pos, fj;
-        double z, xi, xj;
-      };
-      std::vector<G> gs((size_t)ns);
+      static thread_local std::vector<TermsSfGeom> gs;
+      using G = TermsSfGeom;
+      gs.resize((size_t)ns);
       for (int g = 0; g < ns; ++g)
         {
           G &s = gs[(size_t)g];
@@ -1676,13 +1690,16 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
           continue;
         }
       // planes of the run: (axis, side, coordinate)
-      std::vector<char> used((size_t)ns, 0);
+      static thread_local std::vector<char> used;
+      used.assign((size_t)ns, 0);
+      static thread_local std::vector<int> mem, ii, jj, fgrid;
+      static thread_local std::vector<double> ki, kj;
       for (int g0 = 0; g0 < ns; ++g0)
         {
           if (used[(size_t)g0])
             continue;
           const G &r0 = gs[(size_t)g0];
-          std::vector<int> mem;
+          mem.clear();
           for (int g = g0; g < ns; ++g)
             if (!used[(size_t)g] && gs[(size_t)g].c == r0.c && gs[(size_t)g].pos == r0.pos && gs[(size_t)g].fj == r0.fj &&
                 std::fabs(gs[(size_t)g].z - r0.z) <= 1e-9 * hbox[r0.c])
@@ -1691,24 +1708,28 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
                 used[(size_t)g] = 1;
               }
           const int c = r0.c, ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2;
-          std::vector<double> ki(mem.size()), kj(mem.size());
+          if (mem.size() <= 1)
+            { // (a plane with one sub-face: nothing to merge)
+              for (int g : mem)
+                single(g);
+              continue;
+            }
+          ki.resize(mem.size()), kj.resize(mem.size());
           for (size_t m = 0; m < mem.size(); ++m)
             ki[m] = gs[(size_t)mem[m]].xi, kj[m] = gs[(size_t)mem[m]].xj;
-          std::vector<int> ii, jj;
           const int ni = cluster_1d(ki, 1e-9 * hbox[ti], ii), nj = cluster_1d(kj, 1e-9 * hbox[tj], jj);
-          bool ok = mem.size() > 1 && (size_t)ni * nj == mem.size();
-          std::vector<int> grid;
+          bool ok = (size_t)ni * nj == mem.size();
           if (ok)
             {
-              grid.assign(mem.size(), -1);
+              fgrid.assign(mem.size(), -1);
               for (size_t m = 0; m < mem.size() && ok; ++m)
                 {
-                  int &gg = grid[(size_t)(ii[m] + ni * jj[m])];
+                  int &gg = fgrid[(size_t)(ii[m] + ni * jj[m])];
                   ok = gg < 0;
                   gg = (int)m;
                 }
             }
-          auto at = [&](int i, int j) { return mem[(size_t)grid[(size_t)(i + ni * j)]]; };
+          auto at = [&](int i, int j) { return mem[(size_t)fgrid[(size_t)(i + ni * j)]]; };
           if (ok)
             for (size_t m = 0; m < mem.size() && ok; ++m)
               {
@@ -1767,6 +1788,25 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
               }
         }
     }
+  // summary (build_terms_tables reduces these instead of walking the lists again)
+  M.n_in = ncell;
+  for (size_t e = 0; e < order.size(); ++e)
+    {
+      M.n_in += K.run_cnt[order[e]] / gsz;
+      M.nsf += (int)M.run_size(e);
+      if (K.run_nbr[order[e]] >= 0)
+        M.nsi += (int)M.run_size(e);
+    }
+  for (const auto &f : M.sfs)
+    M.ivl_f = std::max(M.ivl_f, std::max(f.ni, f.nj));
+  for (const auto &c : M.cells)
+    for (int d = 0; d < 3; ++d)
+      {
+        int k = 0;
+        for (int i = 0; i < TERMS_MI; ++i)
+          k += c.ivl[d][i] >= 0 ? 1 : 0;
+        M.ivl_c = std::max(M.ivl_c, k);
+      }
 }
 static constexpr int PDH_TERMS_LDS_CAP = 40 * 1024; // bytes per workgroup: four resident waves per CU at least
 static bool build_terms_tables(const pdh_problem *p, const Packed &K, const RowsHost &RH, int vq_n, TermsHost &T, std::string *why = nullptr)
@@ -1816,6 +1856,15 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
   // cells and sub-faces the kernel sums over: merged where they form tensor grids (merge_terms_of_slot); PDH_TERMS_MERGE=0: as given
   const char *me = getenv("PDH_TERMS_MERGE");
   const bool merge = !(me && me[0] == '0');
+  const bool trace = getenv("PDH_TRACE_SETUP") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_prev = tnow();
+  auto tlap = [&](const char *what) {
+    if (trace)
+      fprintf(stderr, "[build_terms_tables] %-28s %6.1f ms\n", what, std::chrono::duration<double, std::milli>(tnow() - t_prev).count());
+    t_prev = tnow();
+  };
+  tlap("run order");
   std::vector<TermsMerged> MG((size_t)K.n_owned);
   host_parallel_for((size_t)K.n_owned, [&](size_t sl) { merge_terms_of_slot(p, K, RH, vq_n, fn, sl, order[sl], merge, MG[sl]); });
   if (merge && !(me && me[0] == '2'))
@@ -1823,16 +1872,8 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
       // a third of what is summed over - block agglomerates lose 7 / 8 of their cells, METIS-like ones a few per cent (and ran 4-8 %
       // slower merged, profiles/r04_terms_merge.txt).  PDH_TERMS_MERGE=2 merges whatever can be merged.
       int64_t n_in = 0, n_out = 0;
-      for (int sl = 0; sl < K.n_owned; ++sl)
-        {
-          n_in += (K.vq_ptr[sl + 1] - K.vq_ptr[sl]) / m3;
-          n_out += (int64_t)MG[(size_t)sl].cells.size();
-          for (size_t e = 0; e < order[sl].size(); ++e)
-            {
-              n_in += K.run_cnt[order[sl][e]] / gsz;
-              n_out += (int64_t)MG[(size_t)sl].runs[e].size();
-            }
-        }
+      for (const auto &m : MG)
+        n_in += m.n_in, n_out += (int64_t)m.cells.size() + m.nsf;
       if (3 * n_out > 2 * n_in)
         {
           for (auto &m : MG)
@@ -1840,38 +1881,24 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
           host_parallel_for((size_t)K.n_owned, [&](size_t sl) { merge_terms_of_slot(p, K, RH, vq_n, fn, sl, order[sl], false, MG[sl]); });
         }
     }
+  tlap("merge");
   int ivl_c = 1, ivl_f = 1;
   for (int sl = 0; sl < K.n_owned; ++sl)
     {
       const TermsMerged &M = MG[(size_t)sl];
-      int nsf = 0, nsi = 0;
-      for (size_t e = 0; e < order[sl].size(); ++e)
-        {
-          nsf += (int)M.runs[e].size();
-          if (K.run_nbr[order[sl][e]] >= 0)
-            nsi += (int)M.runs[e].size();
-          T.n_sf_in += K.run_cnt[order[sl][e]] / gsz;
-          for (const auto &f : M.runs[e])
-            ivl_f = std::max(ivl_f, std::max(f.ni, f.nj));
-        }
-      for (const auto &c : M.cells)
-        for (int d = 0; d < 3; ++d)
-          {
-            int k = 0;
-            for (int i = 0; i < TERMS_MI; ++i)
-              k += c.ivl[d][i] >= 0 ? 1 : 0;
-            ivl_c = std::max(ivl_c, k);
-          }
-      T.n_sf_out += nsf;
+      ivl_c = std::max(ivl_c, M.ivl_c), ivl_f = std::max(ivl_f, M.ivl_f);
+      T.n_sf_out += M.nsf;
+      T.n_sf_in += M.n_in - (K.vq_ptr[sl + 1] - K.vq_ptr[sl]) / m3;
       T.n_cells_in += (K.vq_ptr[sl + 1] - K.vq_ptr[sl]) / m3;
       T.n_cells_out += (int64_t)M.cells.size();
-      if (nsf > 65535)
+      if (M.nsf > 65535)
         return no("term kernel: too many sub-faces on a polytope");
-      T.maxsf = std::max(T.maxsf, nsf);
-      T.maxsi = std::max(T.maxsi, nsi);
+      T.maxsf = std::max(T.maxsf, M.nsf);
+      T.maxsi = std::max(T.maxsi, M.nsi);
       T.maxcell = std::max<int>(T.maxcell, (int)M.cells.size());
     }
   T.task_pts = std::max(vq_n * ivl_c, fn * ivl_f);
+  tlap("maxima");
   {
     // one pass or two (pdh_terms.h: SPLIT): whichever lets more single-wave workgroups stay resident on a CU - by LDS (160 KB in
     // granules of 1280 bytes), capped by the 12 waves the kernels' registers allow; a tie goes to the single pass (fewer
@@ -1915,8 +1942,8 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
     int nsfb = 0, e = 0;
     for (size_t t : idx)
       {
-        const auto &fs = M.runs[(size_t)e];
-        const int ns = (int)fs.size(), nb = K.run_nbr[t];
+        const TermsMerged::Sf *fs = M.run_begin((size_t)e);
+        const int ns = (int)M.run_size((size_t)e), nb = K.run_nbr[t];
         double *en = rec + HDR + e * ENT;
         en[0] = as_d((long long)(uint32_t)(at - at0) | ((long long)ns << 32));
         en[1] = as_d((long long)K.run_blk[t]);
@@ -1932,8 +1959,9 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
             if (e != 0)
               bad[sl] = 1; // (the kernel takes the boundary run to be run 0)
           }
-        for (const auto &f : fs)
+        for (int q = 0; q < ns; ++q)
           {
+            const TermsMerged::Sf &f = fs[q];
             T.sf_pt[(size_t)at] = f.pb;
             T.sf_info[(size_t)at] = e | (f.c << 8) | (f.pos << 10) | (f.fj << 11) | (f.ni << 12) | (f.nj << 15);
             for (int d = 0; d < 2; ++d)
@@ -1959,6 +1987,7 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
     rec[10] = as_d(K.vq_ptr[sl]);
     rec[11] = as_d((long long)(at - at0));
   });
+  tlap("tables");
   for (char c : bad)
     if (c)
       return no("term kernel: run order");
@@ -2539,6 +2568,7 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
           TermsHost TH;
           if (vq_n_terms > 0 && build_terms_tables(p, K, RH, vq_n_terms, TH))
             {
+              lap("term kernel: tables (host)");
               PdhTerms &T = ctx->terms;
               if ((rc = upload(ctx, TH.meta, &T.meta)) != PDH_OK || (rc = upload(ctx, TH.sf_pt, &T.sf_pt)) != PDH_OK ||
                   (rc = upload(ctx, TH.sf_info, &T.sf_info)) != PDH_OK || (rc = upload(ctx, TH.sf_ivl, &T.sf_ivl)) != PDH_OK ||
@@ -2547,6 +2577,7 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
                   free_problem(ctx);
                   return rc;
                 }
+              lap("term kernel: upload");
               T.maxruns = TH.maxruns, T.maxsf = TH.maxsf, T.maxsi = TH.maxsi, T.maxcell = TH.maxcell;
               T.vq_tensor_n = vq_n_terms, T.fq_tensor_n = RH.fq_tensor_n;
               T.lds_bytes = TH.lds_bytes;
@@ -2592,7 +2623,7 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
               }
               ctx->terms_ok = true;
               ctx->rows_auto = true;
-              lap("term kernel: tables + upload");
+              lap("term kernel: records of 1-D rules (device)");
             }
         }
     }

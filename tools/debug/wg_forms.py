@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""FE_DGQ(3) on the bench mesh: the workgroup term kernel in its four forms (cells / sub-faces merged or as given x phase A as entries or
-as lane tasks) against pdh_rows.h; each form in its own child process (the launcher reads its switches once), several contexts each.
+"""FE_DGQ(3) on the bench mesh: the workgroup term kernel (cells / sub-faces merged into composite rules, or as given) against pdh_rows.h;
+each form in its own child process, several contexts each (the spread between contexts is the allocation placement).  (profiles/
+r04_wg_forms.txt was taken while an "entry form" of phase A still existed behind PDH_TERMS_WG_ENTRY.)
 usage: wg_forms.py [cells=64] [contexts=3]"""
 import os
 import subprocess
@@ -33,10 +34,9 @@ print("%%-34s %%-7s median %%.3f ms  min %%.3f  max %%.3f  sum %%.10e" %% (sys.a
 cells = sys.argv[1] if len(sys.argv) > 1 else "64"
 nctx = sys.argv[2] if len(sys.argv) > 2 else "3"
 forms = [("pdh_rows.h", dict(PDH_TERMS_DGQ3="0")),
-         ("terms_wg merged, entries", dict(PDH_TERMS_DGQ3="1", PDH_TERMS_MERGE="1", PDH_TERMS_WG_ENTRY="1")),
-         ("terms_wg merged, lane tasks", dict(PDH_TERMS_DGQ3="1", PDH_TERMS_MERGE="1", PDH_TERMS_WG_ENTRY="0")),
-         ("terms_wg as given, entries", dict(PDH_TERMS_DGQ3="1", PDH_TERMS_MERGE="0", PDH_TERMS_WG_ENTRY="1")),
-         ("terms_wg as given, lane tasks", dict(PDH_TERMS_DGQ3="1", PDH_TERMS_MERGE="0", PDH_TERMS_WG_ENTRY="0")),
+         ("terms_wg merged", dict(PDH_TERMS_DGQ3="1", PDH_TERMS_MERGE="1")),
+         ("terms_wg as given", dict(PDH_TERMS_DGQ3="1", PDH_TERMS_MERGE="0")),
+         ("terms_wg merged (again)", dict(PDH_TERMS_DGQ3="1", PDH_TERMS_MERGE="1")),
          ("pdh_rows.h (again)", dict(PDH_TERMS_DGQ3="0"))]
 for name, env in forms:
     e = dict(os.environ)
