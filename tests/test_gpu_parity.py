@@ -1389,6 +1389,74 @@ def test_term_kernel_rules_of_up_to_eight_points(basis, p, nq):
         assert_parity_ah(v0, ref, ah, what="term kernel, %d points per direction" % nq)
 
 
+def _merge_stats_and_values(kw, mode):
+    import polydeal_amd as pa
+
+    old = os.environ.get("PDH_TERMS_MERGE")
+    os.environ["PDH_TERMS_MERGE"] = mode
+    try:
+        ctx = pa.Context(0)
+        ctx.set_problem(pa.Problem(**kw))
+        kern, st = ctx.rows_kernel_in_use(), ctx.terms_merge_stats()
+        v = ctx.assemble()
+        ctx.close()
+    finally:
+        if old is None:
+            del os.environ["PDH_TERMS_MERGE"]
+        else:
+            os.environ["PDH_TERMS_MERGE"] = old
+    return v, kern, st
+
+
+@pytest.mark.parametrize("basis,p", [("dgq", 3), ("dgp", 3), ("dgq", 2), ("dgp", 1)])
+@pytest.mark.parametrize("shape,diag_first,vname", [("blocks3", True, "poisson"), ("blocks3", False, "dr"), ("slabs", True, "adm"),
+                                                   ("grown", True, "poisson"), ("grown", False, "test")])
+def test_term_kernels_merge_cells_and_sub_faces_that_form_tensor_grids(basis, p, shape, diag_first, vname):
+    """The term kernels sum over cells and sub-faces; those that form tensor grids are merged into ONE with composite 1-D rules
+    (csrc/pdh_capi.cpp: merge_terms_of_slot).  Shapes that exercise the analysis: blocks of 3^3 cells (three intervals per axis: sub-grids of
+    2 + 1), slabs of 4 x 2 x 1 cells (different counts per axis, composite rules of 8 and 4 and 2 points... per the element's rule), and
+    METIS-like grown agglomerates with PDH_TERMS_MERGE=2 (every polytope a mix of merged sub-grids, merged planes and single cells /
+    sub-faces - the rule of build_terms_tables would leave them as given).  Merged, as given and the oracle must agree."""
+    fe = po.FE_DGQ(3, p) if basis == "dgq" else po.FE_AggloDGP(3, p)
+    nq = p + 1
+    if shape == "blocks3":
+        grid = po.subdivided_hyper_cube(3, 6, 0.0, 1.0)
+        groups = po.block_agglomerates(grid, 3)
+    elif shape == "slabs":
+        grid = po.subdivided_hyper_cube(3, 4, 0.0, 1.0)
+        groups = {}
+        for i, j, k in np.ndindex(*grid.ijk_to_cell.shape):
+            groups.setdefault((i // 4, j // 2, k), []).append(int(grid.ijk_to_cell[i, j, k]))
+        groups = [sorted(g) for _, g in sorted(groups.items())]
+    else:
+        grid = po.subdivided_hyper_cube(3, 6, 0.0, 1.0)
+        groups = _grown_agglomerates(grid, 6, 5)
+    ah = po.AgglomerationHandler(grid)
+    for g in groups:
+        ah.define_agglomerate(g)
+    ah.initialize_fe_values(nq, nq)
+    ah.distribute_agglomerated_dofs(fe)
+    var = variant(vname, fe)
+    kw = flatten(ah, var, diag_first=diag_first)
+    ref = po.assemble_csr(ah, var, diag_first=diag_first)[2]
+    vm, kern_m, st_m = _merge_stats_and_values(kw, "2")
+    vg, kern_g, st_g = _merge_stats_and_values(kw, "0")
+    assert kern_m == "terms" and kern_g == "terms"
+    assert st_g["cells_merged"] == st_g["cells"] and st_g["sub_faces_merged"] == st_g["sub_faces"]
+    assert st_m["cells"] == st_g["cells"] == grid.n_cells and st_m["sub_faces"] == st_g["sub_faces"]
+    m = min(4, 8 // nq)       # intervals of a composite rule: 8 points, 4 intervals at most
+    up = lambda a: -(-a // m)
+    if shape == "blocks3":    # 27 cells -> sub-grids of m intervals per axis; a face of 9 sub-faces likewise
+        assert st_m["cells_merged"] * 27 == st_m["cells"] * up(3) ** 3 and st_m["sub_faces_merged"] * 9 == st_m["sub_faces"] * up(3) ** 2
+    elif shape == "slabs":    # 4 x 2 x 1 cells
+        assert st_m["cells_merged"] * 8 == st_m["cells"] * up(4) * up(2)
+    else:
+        assert st_m["sub_faces_merged"] < st_m["sub_faces"]
+    assert_parity_ah(vm, ref, ah, diag_first, what="term kernel, merged")
+    assert_parity_ah(vg, ref, ah, diag_first, what="term kernel, as given")
+    assert np.max(np.abs(vm - vg)) <= 1e-13 * np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("waves", ["4", "8"])
 @pytest.mark.parametrize("kind,cells,per,vname,diag_first,nq", [("block", 4, 2, "poisson", True, 4), ("block", 6, 2, "dr", False, 4), ("block", 4, 1, "test", True, 4),
                                                                 ("grown", 6, 6, "adm", True, 4), ("grown", 8, 8, "poisson", False, 4), ("grown", 6, 3, "minsip", True, 4),
