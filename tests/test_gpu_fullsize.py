@@ -317,7 +317,7 @@ def test_bench_strong_scaling_rehearsal_on_one_gpu():
     assert d["config"]["workload"].endswith("%d dofs, %d nnz" % (n_agg * n, n * n * (n_agg + 2 * 3 * 8 * 8 * 7)))
     assert "split in 4 contiguous ranges" in d["config"]["parallelism"]
     assert d["checksum"]["non_finite"] == 0 and d["checksum"]["rel_err"] < 1e-9
-    assert d["value"] > 0 and d["roofline"]["kernel"] == "k_rows"
+    assert d["value"] > 0 and d["roofline"]["kernel"] == "k_terms_wg"  # (rank-local descriptions: the workgroup term kernel)
 
 
 def test_config3_distorted_mesh_fullsize():
