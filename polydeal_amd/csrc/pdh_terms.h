@@ -378,8 +378,12 @@ __device__ __forceinline__ void terms_gather_record(const PdhDev &P, const PdhTe
 }
 
 // PMAX: most points per direction of a rule the instantiation takes (4 or 8): the point data of a lane task sit in registers
+#ifndef PDHT_WAVES
+#define PDHT_WAVES 3 // waves per SIMD the register allocation aims at (4: 128 VGPRs - the 8-slot lane tasks then spill 50-190 bytes; measured
+                     // equal or slower, profiles/r04_terms_waves.txt)
+#endif
 template <int N1D, int BASIS, bool SHIFTED, int PMAX, bool SPLIT>
-__global__ void __launch_bounds__(PDH_WAVE, 3) k_terms(const PdhDev P, const PdhTerms T, const int n_owned)
+__global__ void __launch_bounds__(PDH_WAVE, PDHT_WAVES) k_terms(const PdhDev P, const PdhTerms T, const int n_owned)
 {
   using K = Kind<N1D, BASIS>;
   constexpr int NF = K::NF, NS = K::NS, NSYM = K::NSYM, SYMS = K::SYMS, FULL = K::FULL, FULLS = K::FULLS, NSUB = K::NSUB;
