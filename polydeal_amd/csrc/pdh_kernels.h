@@ -117,6 +117,21 @@ struct PdhDev
 
 namespace pdh
 {
+// Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md: blocks b and b + 8 share one); each XCD has its own
+// L2.  Work item of block b such that every XCD works through ONE contiguous eighth of the n items: items that write neighbouring
+// pieces of the same rows (the blocks of a polytope's rows in the two-kernel forms) then meet in one L2, where partial lines merge
+// before they leave for HBM.  Speed only - correctness never depends on placement.  -DPDH_NO_XCD_CHUNKS: item = block.
+__device__ __forceinline__ int xcd_chunked(int b, int n)
+{
+#ifdef PDH_NO_XCD_CHUNKS
+  (void)n;
+  return b;
+#else
+  const int x = b & 7, k = b >> 3, q = n >> 3, r = n & 7;
+  return x * q + (x < r ? x : r) + k;
+#endif
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f)
 {
@@ -654,9 +669,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_diag(const PdhDev P, const int 
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using RC = Rec<DIM, N1D>;
   const int lane = threadIdx.x;
-  const int slot = blockIdx.x;
-  if (slot >= n_owned)
+  if ((int)blockIdx.x >= n_owned)
     return;
+  const int slot = xcd_chunked((int)blockIdx.x, n_owned); // (neighbouring blocks of a row from one L2: see xcd_chunked)
   const int agg = P.own_agg[slot];
   // Points per chunk.  Large blocks (NT >= 3) run at 2 waves per SIMD (register-limited): 64-point chunks
   // (one point per lane in the point phase, 15.9 KB of LDS per wave at n1d = 4, DIM = 3 = 10 waves per CU).
@@ -843,9 +858,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_offdiag(const PdhDev P, const i
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using RC = Rec<DIM, N1D>;
   const int lane = threadIdx.x;
-  const int item = blockIdx.x;
-  if (item >= n_items)
+  if ((int)blockIdx.x >= n_items)
     return;
+  const int item = xcd_chunked((int)blockIdx.x, n_items);
   const int slot = P.it_own[item];
   const int agg = P.own_agg[slot];
   const int nbr = P.it_nbr[item];

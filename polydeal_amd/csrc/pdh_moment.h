@@ -893,9 +893,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_mdiag(const PdhDev P, const dou
   constexpr int NA = M::NA, NAP = M::NAP, DIM = 3;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x;
-  const int slot = blockIdx.x;
-  if (slot >= n_owned)
+  if ((int)blockIdx.x >= n_owned)
     return;
+  const int slot = pdh::xcd_chunked((int)blockIdx.x, n_owned); // (an XCD per contiguous eighth of the polytopes: see k_moffdiag)
   const int agg = P.own_agg[slot];
   double lo[DIM], ih[DIM];
   for (int c = 0; c < DIM; ++c)
@@ -1247,7 +1247,9 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_moffdiag(const PdhDev P, const 
   constexpr int NA = M::NA, NAP = M::NAP, NG = M::NG, DIM = 3;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x;
-  const int item = blockIdx.x;
+  // an XCD per contiguous eighth of the items: in deal.II's diagonal-first rows the blocks left of the diagonal are shifted by one entry,
+  // so neighbouring blocks of a row share 128-byte lines; written from one L2 they merge there instead of reaching HBM as partial lines
+  const int item = (int)blockIdx.x < n_items ? pdh::xcd_chunked((int)blockIdx.x, n_items) : (int)blockIdx.x;
   if (item >= n_items)
     return;
   const int slot = P.it_own[item];

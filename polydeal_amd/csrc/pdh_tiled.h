@@ -93,10 +93,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_tdiag(const PdhDev P, const int
   using RC = Rec<DIM, N1D>;
   const int lane = threadIdx.x;
   const int npairs = ntile * (ntile + 1) / 2;
-  const int slot = blockIdx.x / npairs;
-  if (slot >= n_owned)
+  if ((int)blockIdx.x >= n_owned * npairs)
     return;
-  int pr = blockIdx.x - slot * npairs, ti = 0;
+  // (an XCD per contiguous eighth of the work items: the tiles of a block and the blocks of a row - n is no multiple of 16, so all of
+  // them share 128-byte lines with their neighbours - are then written from one L2; pdh_kernels.h: xcd_chunked)
+  const int bid = xcd_chunked((int)blockIdx.x, n_owned * npairs);
+  const int slot = bid / npairs;
+  int pr = bid - slot * npairs, ti = 0;
   while (pr >= ntile - ti) // pairs (ti, ti), (ti, ti + 1), ...
     {
       pr -= ntile - ti;
@@ -254,10 +257,11 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_toffdiag(const PdhDev P, const 
   using RC = Rec<DIM, N1D>;
   const int lane = threadIdx.x;
   const int nt2 = ntile * ntile;
-  const int item = blockIdx.x / nt2;
-  if (item >= n_items)
+  if ((int)blockIdx.x >= n_items * nt2)
     return;
-  const int pr = blockIdx.x - item * nt2;
+  const int bid = xcd_chunked((int)blockIdx.x, n_items * nt2);
+  const int item = bid / nt2;
+  const int pr = bid - item * nt2;
   const int ti = pr / ntile, tj = pr - ti * ntile;
   const int i0 = 64 * ti, j0 = 64 * tj;
   const int slot = P.it_own[item];
