@@ -1467,9 +1467,11 @@ struct TermsHost
 // and its weight factorises - the sum over a sub-grid of products is the product of the sums over the intervals:
 //   sum_ijk A_i (x) B_j (x) C_k = (sum_i A_i) (x) (sum_j B_j) (x) (sum_k C_k),
 // i.e. the sub-grid is ONE cell with composite 1-D rules of several intervals.  Block agglomerates (what an R-tree gives on a structured
-// grid) are such grids as a whole; so are the sub-faces a polytope shares with one neighbour in one plane.  Found on the data (first
-// points of the rules, compared to rounding; weights checked for the factorisation), never assumed; anything else stays unmerged.  A
-// composite rule has at most 8 points and TERMS_MI intervals (register slots of a lane task): larger grids are cut into sub-grids.
+// grid) are such grids as a whole; so are the sub-faces a polytope shares with one neighbour in one plane; METIS-like agglomerates
+// contain pairs and quads of cells that are.  The cells (the sub-faces of a plane) are covered greedily by boxes (rectangles) of
+// occupied grid slots - found on the data (first points of the rules, compared to rounding; weights checked for the factorisation),
+// never assumed; what fits no larger box stays a box of one.  A composite rule has at most 8 points and TERMS_MI intervals (register
+// slots of a lane task).
 struct TermsMerged
 {
   struct Cell
@@ -1535,7 +1537,10 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
         for (int i = 0; i < TERMS_MI; ++i)
           M.cells[(size_t)u].ivl[d][i] = i == 0 ? u : -1;
   };
-  // ---------------- cells
+  // ---------------- cells: a greedy cover by boxes of at most mc intervals per direction.  The cells are placed on the tensor grid of
+  // their clustered first points; from every cell not yet taken, in index order, the largest box of taken-free, occupied slots whose
+  // cells share their 1-D rules per interval (and whose weights factorise) becomes one cell with composite rules.  A polytope that is a
+  // full grid is cut into sub-grids of mc intervals exactly as a chunking would; METIS-like agglomerates keep what pairs and quads they have.
   const int mc = tn >= 1 && tn <= 4 ? std::min(TERMS_MI, 8 / tn) : 1;
   bool done = false;
   if (enabled && mc > 1 && ncell > 1)
@@ -1553,77 +1558,108 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
             key[d][(size_t)u] = cart ? cellbox(u)[d] : K.vqx_h[d * st + b0 + u * m3];
           nd[d] = cluster_1d(key[d], 1e-9 * hbox[d], idx[d]);
         }
-      bool ok = (int64_t)nd[0] * nd[1] * nd[2] == ncell;
+      const int64_t nslot = (int64_t)nd[0] * nd[1] * nd[2];
+      bool ok = nslot <= 4096;
       static thread_local std::vector<int> grid;
+      static thread_local std::vector<char> taken;
       if (ok)
         {
-          grid.assign((size_t)ncell, -1);
+          grid.assign((size_t)nslot, -1);
           for (int u = 0; u < ncell && ok; ++u)
             {
               int &g = grid[(size_t)(idx[0][u] + nd[0] * (idx[1][u] + nd[1] * idx[2][u]))];
-              ok = g < 0;
+              ok = g < 0; // (two cells on one slot: no grid)
               g = u;
             }
         }
       auto at = [&](int i, int j, int k) { return grid[(size_t)(i + nd[0] * (j + nd[1] * k))]; };
-      // sub-grids of at most mc intervals per direction
-      int cb[3];
-      for (int d = 0; d < 3; ++d)
-        cb[d] = (nd[d] + mc - 1) / mc;
-      if (ok)
-        for (int u = 0; u < ncell && ok; ++u)
-          {
-            const int o[3] = {idx[0][u] / mc * mc, idx[1][u] / mc * mc, idx[2][u] / mc * mc}; // origin of the cell's sub-grid
-            if (cart)
-              { // same interval = same extent along the direction
-                for (int d = 0; d < 3 && ok; ++d)
-                  {
-                    int r[3] = {o[0], o[1], o[2]};
-                    r[d] = idx[d][u];
-                    const double *bu = cellbox(u), *br = cellbox(at(r[0], r[1], r[2]));
-                    ok = std::fabs(bu[d] - br[d]) <= 1e-12 * hbox[d] && std::fabs(bu[3 + d] - br[3 + d]) <= 1e-12 * hbox[d];
-                  }
-                continue;
-              }
-            // points mode: 1-D nodes and weight ratios of the cell equal those of the sub-grid's reference cell of its interval, and
-            // the weight of the first point factorises over the sub-grid
-            const int64_t bu = b0 + u * m3;
-            const double wu = K.vqw_h[bu];
-            double wf = 1.0;
-            const int uo = at(o[0], o[1], o[2]);
-            const double w0 = K.vqw_h[b0 + uo * m3];
-            for (int d = 0; d < 3 && ok; ++d)
+      // does cell u carry, along every direction, the 1-D rule of the box's reference cell of its interval, and does its weight factorise?
+      auto fits = [&](int u, const int *o) {
+        if (cart)
+          { // same interval = same extent along the direction
+            for (int d = 0; d < 3; ++d)
               {
                 int r[3] = {o[0], o[1], o[2]};
                 r[d] = idx[d][u];
-                const int64_t br = b0 + at(r[0], r[1], r[2]) * m3;
-                const double wr = K.vqw_h[br];
-                wf *= wr / w0;
-                for (int i = 0; i < tn && ok; ++i)
-                  {
-                    const double X = K.vqx_h[d * st + br + i * step[d]];
-                    ok = std::fabs(K.vqx_h[d * st + bu + i * step[d]] - X) <= 3e-15 * (std::fabs(X) + hbox[d]) &&
-                         std::fabs(K.vqw_h[bu + i * step[d]] / wu - K.vqw_h[br + i * step[d]] / wr) <= wtol * (K.vqw_h[br + i * step[d]] / wr);
-                  }
+                const double *bu = cellbox(u), *br = cellbox(at(r[0], r[1], r[2]));
+                if (!(std::fabs(bu[d] - br[d]) <= 1e-12 * hbox[d] && std::fabs(bu[3 + d] - br[3 + d]) <= 1e-12 * hbox[d]))
+                  return false;
               }
-            ok = ok && std::fabs(wu - w0 * wf) <= wtol * wu;
+            return true;
           }
+        const int64_t bu = b0 + u * m3;
+        const double wu = K.vqw_h[bu];
+        double wf = 1.0;
+        const double w0 = K.vqw_h[b0 + at(o[0], o[1], o[2]) * m3];
+        for (int d = 0; d < 3; ++d)
+          {
+            int r[3] = {o[0], o[1], o[2]};
+            r[d] = idx[d][u];
+            const int64_t br = b0 + at(r[0], r[1], r[2]) * m3;
+            const double wr = K.vqw_h[br];
+            wf *= wr / w0;
+            for (int i = 0; i < tn; ++i)
+              {
+                const double X = K.vqx_h[d * st + br + i * step[d]];
+                if (!(std::fabs(K.vqx_h[d * st + bu + i * step[d]] - X) <= 3e-15 * (std::fabs(X) + hbox[d]) &&
+                      std::fabs(K.vqw_h[bu + i * step[d]] / wu - K.vqw_h[br + i * step[d]] / wr) <= wtol * (K.vqw_h[br + i * step[d]] / wr)))
+                  return false;
+              }
+          }
+        return std::fabs(wu - w0 * wf) <= wtol * wu;
+      };
+      auto box_ok = [&](const int *o, const int *sz) {
+        for (int d = 0; d < 3; ++d)
+          if (o[d] + sz[d] > nd[d])
+            return false;
+        for (int k = 0; k < sz[2]; ++k)
+          for (int j = 0; j < sz[1]; ++j)
+            for (int i = 0; i < sz[0]; ++i)
+              {
+                const int u = at(o[0] + i, o[1] + j, o[2] + k);
+                if (u < 0 || taken[(size_t)u])
+                  return false;
+              }
+        for (int k = 0; k < sz[2]; ++k)
+          for (int j = 0; j < sz[1]; ++j)
+            for (int i = 0; i < sz[0]; ++i)
+              if (!fits(at(o[0] + i, o[1] + j, o[2] + k), o))
+                return false;
+        return true;
+      };
       if (ok)
         {
-          for (int k = 0; k < cb[2]; ++k)
-            for (int j = 0; j < cb[1]; ++j)
-              for (int i = 0; i < cb[0]; ++i)
+          taken.assign((size_t)ncell, 0);
+          for (int k0 = 0; k0 < nd[2]; ++k0)
+            for (int j0 = 0; j0 < nd[1]; ++j0)
+              for (int i0 = 0; i0 < nd[0]; ++i0)
                 {
-                  TermsMerged::Cell c;
-                  const int o[3] = {i * mc, j * mc, k * mc};
+                  const int u0 = at(i0, j0, k0);
+                  if (u0 < 0 || taken[(size_t)u0])
+                    continue;
+                  const int o[3] = {i0, j0, k0};
+                  int best[3] = {1, 1, 1}, bestv = 1;
+                  for (int c = mc; c >= 1; --c) // the largest box anchored here (volume; ties: the first found)
+                    for (int b = mc; b >= 1; --b)
+                      for (int aa = mc; aa >= 1; --aa)
+                        {
+                          const int sz[3] = {aa, b, c};
+                          if (aa * b * c > bestv && box_ok(o, sz))
+                            best[0] = aa, best[1] = b, best[2] = c, bestv = aa * b * c;
+                        }
+                  TermsMerged::Cell cm;
                   for (int d = 0; d < 3; ++d)
                     for (int t = 0; t < TERMS_MI; ++t)
                       {
                         int r[3] = {o[0], o[1], o[2]};
                         r[d] = o[d] + t;
-                        c.ivl[d][t] = (t < mc && r[d] < nd[d]) ? at(r[0], r[1], r[2]) : -1;
+                        cm.ivl[d][t] = t < best[d] ? at(r[0], r[1], r[2]) : -1;
                       }
-                  M.cells.push_back(c);
+                  for (int k = 0; k < best[2]; ++k)
+                    for (int j = 0; j < best[1]; ++j)
+                      for (int i = 0; i < best[0]; ++i)
+                        taken[(size_t)at(i0 + i, j0 + j, k0 + k)] = 1;
+                  M.cells.push_back(cm);
                 }
           done = true;
         }
@@ -1718,10 +1754,11 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
           for (size_t m = 0; m < mem.size(); ++m)
             ki[m] = gs[(size_t)mem[m]].xi, kj[m] = gs[(size_t)mem[m]].xj;
           const int ni = cluster_1d(ki, 1e-9 * hbox[ti], ii), nj = cluster_1d(kj, 1e-9 * hbox[tj], jj);
-          bool ok = (size_t)ni * nj == mem.size();
+          // greedy cover of the plane's sub-faces by rectangles of at most mf x mf intervals (as for the cells above)
+          bool ok = (int64_t)ni * nj <= 4096;
           if (ok)
             {
-              fgrid.assign(mem.size(), -1);
+              fgrid.assign((size_t)ni * nj, -1);
               for (size_t m = 0; m < mem.size() && ok; ++m)
                 {
                   int &gg = fgrid[(size_t)(ii[m] + ni * jj[m])];
@@ -1729,61 +1766,91 @@ static void merge_terms_of_slot(const pdh_problem *p, const Packed &K, const Row
                   gg = (int)m;
                 }
             }
-          auto at = [&](int i, int j) { return mem[(size_t)fgrid[(size_t)(i + ni * j)]]; };
-          if (ok)
-            for (size_t m = 0; m < mem.size() && ok; ++m)
-              {
-                const int g = mem[m];
-                const int o[2] = {ii[m] / mf * mf, jj[m] / mf * mf};
-                if (cart)
-                  { // same interval = same extent along the tangential direction (the side-0 cell's box carries the sub-face)
-                    const int64_t grp = K.pk_fq[t] / gsz;
-                    const double *bu = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + g] * 6;
-                    const double *bi = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + at(ii[m], o[1])] * 6;
-                    const double *bj = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + at(o[0], jj[m])] * 6;
-                    ok = std::fabs(bu[ti] - bi[ti]) <= 1e-12 * hbox[ti] && std::fabs(bu[3 + ti] - bi[3 + ti]) <= 1e-12 * hbox[ti] &&
-                         std::fabs(bu[tj] - bj[tj]) <= 1e-12 * hbox[tj] && std::fabs(bu[3 + tj] - bj[3 + tj]) <= 1e-12 * hbox[tj];
-                    continue;
-                  }
-                const int fj = r0.fj;
-                const int64_t st_i = fj ? fn : 1, st_j = fj ? 1 : fn;
-                const int gi = at(ii[m], o[1]), gj = at(o[0], jj[m]), go = at(o[0], o[1]);
-                for (int which = 0; which < 2 && ok; ++which)
-                  { // own-side and cross weights (the latter zero on the boundary)
-                    auto W = [&](int gq, int64_t q) { return which ? K.ap_wcross(t, gq * gsz + q) : K.ap_wself(t, gq * gsz + q); };
-                    const double wu = W(g, 0), wi = W(gi, 0), wj = W(gj, 0), wo = W(go, 0);
-                    if (which && wu == 0.0 && wo == 0.0)
-                      continue;
-                    ok = wu > 0.0 && wo > 0.0 && std::fabs(wu - wi * wj / wo) <= wtol * wu;
-                    for (int al = 0; al < fn && ok; ++al)
-                      {
-                        const double Xi = K.ap_x(ti, t, gi * gsz + al * st_i), Xj = K.ap_x(tj, t, gj * gsz + al * st_j);
-                        ok = std::fabs(K.ap_x(ti, t, g * gsz + al * st_i) - Xi) <= 3e-15 * (std::fabs(Xi) + hbox[ti]) &&
-                             std::fabs(K.ap_x(tj, t, g * gsz + al * st_j) - Xj) <= 3e-15 * (std::fabs(Xj) + hbox[tj]) &&
-                             std::fabs(W(g, al * st_i) / wu - W(gi, al * st_i) / wi) <= wtol * (W(gi, al * st_i) / wi) &&
-                             std::fabs(W(g, al * st_j) / wu - W(gj, al * st_j) / wj) <= wtol * (W(gj, al * st_j) / wj);
-                      }
-                  }
-              }
           if (!ok)
             {
               for (int g : mem)
                 single(g);
               continue;
             }
-          for (int j0 = 0; j0 < nj; j0 += mf)
-            for (int i0 = 0; i0 < ni; i0 += mf)
+          auto atm = [&](int i, int j) { return fgrid[(size_t)(i + ni * j)]; };        // member index or -1
+          auto at = [&](int i, int j) { return mem[(size_t)fgrid[(size_t)(i + ni * j)]]; }; // sub-face of the run
+          static thread_local std::vector<char> ftaken;
+          ftaken.assign(mem.size(), 0);
+          auto fits = [&](int m, const int *o) {
+            const int g = mem[(size_t)m];
+            if (cart)
+              { // same interval = same extent along the tangential direction (the side-0 cell's box carries the sub-face)
+                const int64_t grp = K.pk_fq[t] / gsz;
+                const double *bu = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + g] * 6;
+                const double *bi = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + at(ii[(size_t)m], o[1])] * 6;
+                const double *bj = K.cart->cell_box + (size_t)K.cart->fq_cell[grp + at(o[0], jj[(size_t)m])] * 6;
+                return std::fabs(bu[ti] - bi[ti]) <= 1e-12 * hbox[ti] && std::fabs(bu[3 + ti] - bi[3 + ti]) <= 1e-12 * hbox[ti] &&
+                       std::fabs(bu[tj] - bj[tj]) <= 1e-12 * hbox[tj] && std::fabs(bu[3 + tj] - bj[3 + tj]) <= 1e-12 * hbox[tj];
+              }
+            const int fj = r0.fj;
+            const int64_t st_i = fj ? fn : 1, st_j = fj ? 1 : fn;
+            const int gi = at(ii[(size_t)m], o[1]), gj = at(o[0], jj[(size_t)m]), go = at(o[0], o[1]);
+            for (int which = 0; which < 2; ++which)
+              { // own-side and cross weights (the latter zero on the boundary)
+                auto W = [&](int gq, int64_t q) { return which ? K.ap_wcross(t, gq * gsz + q) : K.ap_wself(t, gq * gsz + q); };
+                const double wu = W(g, 0), wi = W(gi, 0), wj = W(gj, 0), wo = W(go, 0);
+                if (which && wu == 0.0 && wo == 0.0)
+                  continue;
+                if (!(wu > 0.0 && wo > 0.0 && std::fabs(wu - wi * wj / wo) <= wtol * wu))
+                  return false;
+                for (int al = 0; al < fn; ++al)
+                  {
+                    const double Xi = K.ap_x(ti, t, gi * gsz + al * st_i), Xj = K.ap_x(tj, t, gj * gsz + al * st_j);
+                    if (!(std::fabs(K.ap_x(ti, t, g * gsz + al * st_i) - Xi) <= 3e-15 * (std::fabs(Xi) + hbox[ti]) &&
+                          std::fabs(K.ap_x(tj, t, g * gsz + al * st_j) - Xj) <= 3e-15 * (std::fabs(Xj) + hbox[tj]) &&
+                          std::fabs(W(g, al * st_i) / wu - W(gi, al * st_i) / wi) <= wtol * (W(gi, al * st_i) / wi) &&
+                          std::fabs(W(g, al * st_j) / wu - W(gj, al * st_j) / wj) <= wtol * (W(gj, al * st_j) / wj)))
+                      return false;
+                  }
+              }
+            return true;
+          };
+          auto rect_ok = [&](const int *o, int si, int sj) {
+            if (o[0] + si > ni || o[1] + sj > nj)
+              return false;
+            for (int j = 0; j < sj; ++j)
+              for (int i = 0; i < si; ++i)
+                {
+                  const int m = atm(o[0] + i, o[1] + j);
+                  if (m < 0 || ftaken[(size_t)m])
+                    return false;
+                }
+            for (int j = 0; j < sj; ++j)
+              for (int i = 0; i < si; ++i)
+                if (!fits(atm(o[0] + i, o[1] + j), o))
+                  return false;
+            return true;
+          };
+          for (int j0 = 0; j0 < nj; ++j0)
+            for (int i0 = 0; i0 < ni; ++i0)
               {
+                const int m0 = atm(i0, j0);
+                if (m0 < 0 || ftaken[(size_t)m0])
+                  continue;
+                const int o[2] = {i0, j0};
+                int bi = 1, bj = 1;
+                for (int sj = mf; sj >= 1; --sj)
+                  for (int si = mf; si >= 1; --si)
+                    if (si * sj > bi * bj && rect_ok(o, si, sj))
+                      bi = si, bj = sj;
                 TermsMerged::Sf f;
                 const int go = at(i0, j0);
                 f.pb = K.run_ap[t] + go * gsz;
                 f.c = c, f.pos = r0.pos, f.fj = r0.fj;
-                f.ni = std::min(mf, ni - i0), f.nj = std::min(mf, nj - j0);
+                f.ni = bi, f.nj = bj;
                 for (int q = 0; q < TERMS_MI; ++q)
                   {
-                    f.ivl[0][q] = q < f.ni ? (int32_t)((at(i0 + q, j0) - go) * gsz) : 0;
-                    f.ivl[1][q] = q < f.nj ? (int32_t)((at(i0, j0 + q) - go) * gsz) : 0;
+                    f.ivl[0][q] = q < bi ? (int32_t)((at(i0 + q, j0) - go) * gsz) : 0;
+                    f.ivl[1][q] = q < bj ? (int32_t)((at(i0, j0 + q) - go) * gsz) : 0;
                   }
+                for (int j = 0; j < bj; ++j)
+                  for (int i = 0; i < bi; ++i)
+                    ftaken[(size_t)atm(i0 + i, j0 + j)] = 1;
                 out.push_back(f);
               }
         }
@@ -1868,9 +1935,10 @@ static bool build_terms_tables(const pdh_problem *p, const Packed &K, const Rows
   std::vector<TermsMerged> MG((size_t)K.n_owned);
   host_parallel_for((size_t)K.n_owned, [&](size_t sl) { merge_terms_of_slot(p, K, RH, vq_n, fn, sl, order[sl], merge, MG[sl]); });
   if (merge && !(me && me[0] == '2'))
-    { // composite rules cost every lane task of the problem 8 instead of 4 register slots and points: taken when they remove at least
-      // a third of what is summed over - block agglomerates lose 7 / 8 of their cells, METIS-like ones a few per cent (and ran 4-8 %
-      // slower merged, profiles/r04_terms_merge.txt).  PDH_TERMS_MERGE=2 merges whatever can be merged.
+    { // composite rules cost every lane task of the problem 8 instead of 4 register slots: taken when they remove at least a third of
+      // what is summed over - block agglomerates lose 7 / 8 of their cells and 3 / 4 of their sub-faces, METIS-like ones 44 % of their
+      // cells but only 17 % of their sub-faces (23 % together) and ran 2-10 % slower merged (profiles/r04_terms_merge.txt).
+      // PDH_TERMS_MERGE=2 merges whatever can be merged.
       int64_t n_in = 0, n_out = 0;
       for (const auto &m : MG)
         n_in += m.n_in, n_out += (int64_t)m.cells.size() + m.nsf;

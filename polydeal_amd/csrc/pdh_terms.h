@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(PDH_WAVE, PDHT_WAVES) k_terms(const PdhDev P, 
   constexpr int NF = K::NF, NS = K::NS, NSYM = K::NSYM, SYMS = K::SYMS, FULL = K::FULL, FULLS = K::FULLS, NSUB = K::NSUB;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x;
-  const int slot = blockIdx.x;
+  const int slot = blockIdx.x; // (an XCD-chunked order of the polytopes, as in the two-kernel forms, changes nothing here: whole lines)
   if (slot >= n_owned)
     return;
   PDHT_MARK(0);

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & (PDH_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slot = blockIdx.x;
+  const int slot = blockIdx.x; // (an XCD-chunked order of the polytopes, as in the two-kernel forms, changes nothing here: whole lines)
   if (slot >= n_owned)
     return;
   PDHW_MARK(0);
