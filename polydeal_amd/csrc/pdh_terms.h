@@ -122,9 +122,14 @@ __host__ __device__ constexpr int terms_task_doubles(int maxsf, int maxcell, int
 // Phase A of the term kernels: the lane tasks that build the small matrices of a polytope in LDS.  Shared by the wave-per-polytope
 // kernel below and the workgroup-per-polytope kernel of pdh_terms_wg.h.  PMAX: most points per direction of a rule (4 or 8): the
 // point data of a task sit in registers.
-template <int N1D, int BASIS, int PMAX>
+// PAIR: a task of up to 8 points (composite rules of merged cells / sub-faces, rules of more than four points) is worked on by TWO
+// neighbouring lanes, four slots each, whose partial matrices are added through one DPP exchange - half the serial chain of an 8-slot
+// lane task and its 48 registers of point data (measured: 156 -> 122 VGPRs in the workgroup kernel).  PMAX = slots per lane (4);
+// the records have TPM = 8 slots per task then.
+template <int N1D, int BASIS, int PMAX, bool PAIR = false>
 struct TermTasks
 {
+  static constexpr int TPM = PAIR ? 2 * PMAX : PMAX; // slots per 1-D rule in the polytope's record
   using K = Kind<N1D, BASIS>;
   static constexpr int NSYM = K::NSYM, SYMS = K::SYMS, FULL = K::FULL, FULLS = K::FULLS;
   const PdhDev &P;
@@ -164,28 +169,41 @@ struct TermTasks
   struct Pts // point data of one lane task: tangential x | w_self | w_cross; cell x | w; normal-direction task: x[0] = plane coordinate
   {
     double x[PMAX], ws[PMAX], wc[PMAX];
-    int npts; // live points: intervals x points of a rule
+    double ws0, wc0; // weights of the task's FIRST point (the normalisation of the second tangential / the other cell directions)
+    int npts;        // live points of this lane: intervals x points of a rule (PAIR: its half of them)
   };
   using TPts = Pts;
   using CPts = Pts;
-  __device__ __forceinline__ TPts tang_load(int info, int sf, int dir) const
+  // sum of v over the two lanes of a pair (lanes 2 k and 2 k + 1, both active)
+  __device__ __forceinline__ static double pair_sum(double v)
+  {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+  }
+  // half: which four slots of the task this lane takes (PAIR only; else 0)
+  __device__ __forceinline__ TPts tang_load(int info, int sf, int dir, int half = 0) const
   { // all loads of a task at once: one contiguous piece of the polytope's record
     TPts r;
-    const double *g = gr + (2 * sf + dir) * (3 * PMAX);
-    r.npts = ((info >> (dir ? 15 : 12)) & 7) * fn;
+    const double *g = gr + (2 * sf + dir) * (3 * TPM);
+    const int npts = ((info >> (dir ? 15 : 12)) & 7) * fn;
+    r.npts = PAIR ? (npts - PMAX * half < 0 ? 0 : (npts - PMAX * half > PMAX ? PMAX : npts - PMAX * half)) : npts;
+    r.ws0 = g[TPM];
+    r.wc0 = g[2 * TPM];
+    const double *gh = g + (PAIR ? PMAX * half : 0);
     static_for<0, PMAX>([&](auto i_) {
       constexpr int al = i_;
-      r.x[al] = g[al];
-      r.ws[al] = g[PMAX + al];
-      r.wc[al] = g[2 * PMAX + al]; // (zero on the boundary)
+      r.x[al] = gh[al];
+      r.ws[al] = gh[TPM + al];
+      r.wc[al] = gh[2 * TPM + al]; // (zero on the boundary)
     });
     return r;
   }
-  __device__ __forceinline__ double zeta_load(int sf) const { return gr[(2 * maxsf + 3 * maxcell) * (3 * PMAX) + sf]; }
+  __device__ __forceinline__ double zeta_load(int sf) const { return gr[(2 * maxsf + 3 * maxcell) * (3 * TPM) + sf]; }
   // WANT_D / WANT_X: which of the two kinds of table a call produces (both by default; the kernel of FE_AggloDGP(3) makes them in
   // two phases so that the X tables can take the place of the D tables in LDS)
   template <bool WANT_D = true, bool WANT_X = true>
-  __device__ __forceinline__ void tang_compute(const TPts &r, int sf, int dir, int info) const
+  __device__ __forceinline__ void tang_compute(const TPts &r, int sf, int dir, int info, int half = 0) const
   {
     const int run = info & 0xff, c = (info >> 8) & 3;
     const int ti = c == 0 ? 1 : 0, tj = c == 2 ? 1 : 2, ax = dir ? tj : ti;
@@ -193,7 +211,7 @@ struct TermTasks
     const bool interior = (int)__double_as_longlong(re[1]) >= 0;
     const double lo_d = sel3(ax, lo0, lo1, lo2), ih_d = sel3(ax, ih0, ih1, ih2);
     const double loq = re[3 + ax], ihq = re[6 + ax];
-    const double sS = dir ? 1.0 / r.ws[0] : 1.0, sC = (dir && interior) ? 1.0 / r.wc[0] : 1.0;
+    const double sS = dir ? 1.0 / r.ws0 : 1.0, sC = (dir && interior) ? 1.0 / r.wc0 : 1.0;
     double Dm[NSYM], Xm[FULL];
     for (int i = 0; i < NSYM; ++i)
       Dm[i] = 0.0;
@@ -217,6 +235,17 @@ struct TermTasks
           });
         }
     });
+    if constexpr (PAIR)
+      { // the other half of the task's points sits in the neighbouring lane
+        if constexpr (WANT_D)
+          for (int i = 0; i < NSYM; ++i)
+            Dm[i] = pair_sum(Dm[i]);
+        if constexpr (WANT_X)
+          for (int i = 0; i < FULL; ++i)
+            Xm[i] = pair_sum(Xm[i]);
+        if (half != 0)
+          return;
+      }
     if constexpr (WANT_D)
       {
         double *dd = Da + (sf * 3 + ax) * SYMS;
@@ -262,25 +291,28 @@ struct TermTasks
     });
   }
   // (cell, direction): M_d and K_d.  The rule of a cell is a_i b_j c_k: direction 0 takes w_(i,0,0), the others w / w_000
-  __device__ __forceinline__ CPts cell_load(int ct) const
+  __device__ __forceinline__ CPts cell_load(int ct, int half = 0) const
   {
     CPts r;
-    const double *g = gr + (2 * maxsf + ct) * (3 * PMAX);
+    const double *g = gr + (2 * maxsf + ct) * (3 * TPM);
     r.npts = 0;
+    r.ws0 = g[TPM];
+    r.wc0 = 0.0;
+    const double *gh = g + (PAIR ? PMAX * half : 0);
     static_for<0, PMAX>([&](auto i_) {
       constexpr int i = i_;
-      r.x[i] = g[i];
-      r.ws[i] = g[PMAX + i];
+      r.x[i] = gh[i];
+      r.ws[i] = gh[TPM + i];
       r.wc[i] = 0.0;
       r.npts += r.ws[i] != 0.0 ? 1 : 0; // (slots behind the last interval carry zero weights)
     });
     return r;
   }
-  __device__ __forceinline__ void cell_compute(const CPts &r, int ct) const
+  __device__ __forceinline__ void cell_compute(const CPts &r, int ct, int half = 0) const
   {
     const int cell = ct / 3, d = ct - 3 * cell;
     const double lo_d = sel3(d, lo0, lo1, lo2), ih_d = sel3(d, ih0, ih1, ih2);
-    const double sc = d == 0 ? 1.0 : 1.0 / r.ws[0];
+    const double sc = d == 0 ? 1.0 : 1.0 / r.ws0;
     double Mm[NSYM], Km[NSYM];
     for (int i = 0; i < NSYM; ++i)
       Mm[i] = Km[i] = 0.0;
@@ -301,6 +333,13 @@ struct TermTasks
           });
         }
     });
+    if constexpr (PAIR)
+      {
+        for (int i = 0; i < NSYM; ++i)
+          Mm[i] = pair_sum(Mm[i]), Km[i] = pair_sum(Km[i]);
+        if (half != 0)
+          return;
+      }
     if (d == 0 && P.reaction_c != 0.0) // c phi_i phi_j rides on the first term of the cell
       for (int i = 0; i < NSYM; ++i)
         Km[i] += P.reaction_c * Mm[i];
@@ -423,7 +462,6 @@ __global__ void __launch_bounds__(PDH_WAVE, PDHT_WAVES) k_terms(const PdhDev P, 
     info = (int)__double_as_longlong(gr_info[sf < T.maxsf ? sf : 0]);
   };
   int infoT = 0, infoN = 0;
-  desc(lane >> 1, infoT);
   desc(lane, infoN);
   for (int k0 = 0; k0 < T.maxruns * TERMS_ENT; k0 += 4 * PDH_WAVE)
     { // (four loads in flight per lane: a rolled copy loop would wait for every single one)
@@ -452,15 +490,27 @@ __global__ void __launch_bounds__(PDH_WAVE, PDHT_WAVES) k_terms(const PdhDev P, 
       dig[lane] = k0 | (k1 << 4) | (k2 << 8);
     }
   double *Ca = Da + nsf * 3 * SYMS; // [cell][direction][M | K] behind the sub-faces' tables
-  using TT = TermTasks<N1D, BASIS, PMAX>;
+  // PMAX = slots per 1-D rule in the records (PdhTerms::tpm); rules of more than four slots are worked on by pairs of lanes (TermTasks)
+  constexpr bool PAIR = PMAX > 4;
+  constexpr int PL = PAIR ? PMAX / 2 : PMAX, TS = PAIR ? 2 : 1; // slots per lane, lanes per task
+  using TT = TermTasks<N1D, BASIS, PL, PAIR>;
   using TPts = typename TT::TPts;
   using CPts = typename TT::CPts;
   const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, gr, T.maxsf, T.maxcell};
-  auto tang_load = [&](int info, int sf, int dir) { return tt.tang_load(info, sf < T.maxsf ? sf : 0, dir); };
-  auto tang_compute = [&](const TPts &r, int sf, int dir, int info) { tt.template tang_compute<true, !SPLIT>(r, sf, dir, info); };
+  // lanes of the first kind: (sub-face, tangential direction[, half]); of the second: the normal-direction tasks, then - from an even
+  // lane on, pairs must be neighbours - (cell, direction[, half])
+  const int n1 = 2 * nsf * TS, ncs = PAIR ? (nsf + 1) & ~1 : nsf, n2 = ncs + 3 * ncell * TS;
+  auto dec1 = [&](int tid, int &sf, int &dir, int &half) {
+    const int task = tid / TS;
+    half = tid - task * TS, sf = task >> 1, dir = task & 1;
+  };
+  auto dec2 = [&](int tid, int &ct, int &half) {
+    const int u = tid - ncs;
+    ct = u / TS, half = u - ct * TS;
+  };
+  auto tang_load = [&](int info, int sf, int dir, int half) { return tt.tang_load(info, sf < T.maxsf ? sf : 0, dir, half); };
+  auto tang_compute = [&](const TPts &r, int sf, int dir, int info, int half) { tt.template tang_compute<true, !SPLIT>(r, sf, dir, info, half); };
   auto norm_compute = [&](double zeta, int sf, int info) { tt.template norm_compute<true, !SPLIT>(zeta, sf, info); };
-  auto cell_load = [&](int ct) { return tt.cell_load(ct); };
-  auto cell_compute = [&](const CPts &r, int ct) { tt.cell_compute(r, ct); };
   PDHT_MARK(1);
   TPts tp0; // (first round of the task form; the two-pass form uses its point data twice)
   double zeta0 = 0.0;
@@ -469,37 +519,44 @@ __global__ void __launch_bounds__(PDH_WAVE, PDHT_WAVES) k_terms(const PdhDev P, 
   // lane tasks: 1.6 x the instructions for a shorter critical path; FE_AggloDGP(3) 0.32 -> 0.39 ms, FE_DGQ(2) 0.41 -> 0.50 here, 1.30 vs
   // 1.28 ms in the workgroup kernel of pdh_terms_wg.h whose waves share the entries - profiles/r04_wg_forms.txt; not kept)
   // ---- level 2: the point data of the first round of BOTH kinds of task are requested before anything is computed
-  const int ntask2 = nsf + 3 * ncell; // second kind: normal-direction tasks, then cell tasks
-  tp0 = tang_load(infoT, lane >> 1, lane & 1);
+  int sfT, dirT, halfT;
+  dec1(lane, sfT, dirT, halfT);
+  desc(sfT, infoT);
+  tp0 = tang_load(infoT, sfT, dirT, halfT);
   CPts cp0;
-  for (int i = 0; i < PMAX; ++i)
+  for (int i = 0; i < PL; ++i)
     cp0.x[i] = cp0.ws[i] = cp0.wc[i] = 0.0;
-  cp0.npts = 0;
+  cp0.npts = 0, cp0.ws0 = 1.0, cp0.wc0 = 0.0;
+  int ct0 = 0, halfC = 0;
   if (lane < nsf)
     zeta0 = tt.zeta_load(lane);
-  else if (lane < ntask2)
-    cp0 = cell_load(lane - nsf);
+  else if (lane >= ncs && lane < n2)
+    {
+      dec2(lane, ct0, halfC);
+      cp0 = tt.cell_load(ct0, halfC);
+    }
   __builtin_amdgcn_sched_barrier(0);
   PDH_WAVE_SYNC(); // (run entries and digit table are in LDS)
-  if (lane < 2 * nsf)
-    tang_compute(tp0, lane >> 1, lane & 1, infoT);
-  for (int t0 = PDH_WAVE; t0 < 2 * nsf; t0 += PDH_WAVE)
+  if (lane < n1)
+    tang_compute(tp0, sfT, dirT, infoT, halfT);
+  for (int t0 = PDH_WAVE; t0 < n1; t0 += PDH_WAVE)
     {
       const int tid = t0 + lane;
-      if (tid < 2 * nsf)
+      if (tid < n1)
         {
-          int info;
-          desc(tid >> 1, info);
-          const TPts tp = tang_load(info, tid >> 1, tid & 1);
-          tang_compute(tp, tid >> 1, tid & 1, info);
+          int info, sf, dir, half;
+          dec1(tid, sf, dir, half);
+          desc(sf, info);
+          const TPts tp = tang_load(info, sf, dir, half);
+          tang_compute(tp, sf, dir, info, half);
         }
     }
   PDHT_MARK(2);
   if (lane < nsf)
     norm_compute(zeta0, lane, infoN);
-  else if (lane < ntask2)
-    cell_compute(cp0, lane - nsf);
-  for (int t0 = PDH_WAVE; t0 < ntask2; t0 += PDH_WAVE)
+  else if (lane >= ncs && lane < n2)
+    tt.cell_compute(cp0, ct0, halfC);
+  for (int t0 = PDH_WAVE; t0 < n2; t0 += PDH_WAVE)
     {
       const int tid = t0 + lane;
       if (tid < nsf)
@@ -508,10 +565,12 @@ __global__ void __launch_bounds__(PDH_WAVE, PDHT_WAVES) k_terms(const PdhDev P, 
           desc(tid, info);
           norm_compute(tt.zeta_load(tid), tid, info);
         }
-      else if (tid < ntask2)
+      else if (tid >= ncs && tid < n2)
         {
-          const CPts cp = cell_load(tid - nsf);
-          cell_compute(cp, tid - nsf);
+          int ct, half;
+          dec2(tid, ct, half);
+          const CPts cp = tt.cell_load(ct, half);
+          tt.cell_compute(cp, ct, half);
         }
     }
   PDH_WAVE_SYNC();
@@ -598,17 +657,18 @@ __global__ void __launch_bounds__(PDH_WAVE, PDHT_WAVES) k_terms(const PdhDev P, 
     {
       // ---- second pass of the lane tasks: the X tables, from the point data of the first round still in registers (later rounds:
       // loaded again), into the space behind the block
-      if (lane < 2 * nsf)
-        tt.template tang_compute<false, true>(tp0, lane >> 1, lane & 1, infoT);
-      for (int t0 = PDH_WAVE; t0 < 2 * nsf; t0 += PDH_WAVE)
+      if (lane < n1)
+        tt.template tang_compute<false, true>(tp0, sfT, dirT, infoT, halfT);
+      for (int t0 = PDH_WAVE; t0 < n1; t0 += PDH_WAVE)
         {
           const int tid = t0 + lane;
-          if (tid < 2 * nsf)
+          if (tid < n1)
             {
-              int info;
-              desc(tid >> 1, info);
-              const TPts tp = tang_load(info, tid >> 1, tid & 1);
-              tt.template tang_compute<false, true>(tp, tid >> 1, tid & 1, info);
+              int info, sf, dir, half;
+              dec1(tid, sf, dir, half);
+              desc(sf, info);
+              const TPts tp = tang_load(info, sf, dir, half);
+              tt.template tang_compute<false, true>(tp, sf, dir, info, half);
             }
         }
       if (lane < nsf)

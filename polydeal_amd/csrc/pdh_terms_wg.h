@@ -81,61 +81,79 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
   for (int k = threadIdx.x; k < T.maxruns * TERMS_ENT; k += PDH_WAVE * W)
     rec[TERMS_HDR + k] = g[TERMS_HDR + k];
   double *Ca = Da + nsf * 3 * SYMS;
-  using TT = TermTasks<N1D, BASIS, PMAX>;
+  // PMAX = slots per 1-D rule in the records (PdhTerms::tpm); rules of more than four slots are worked on by pairs of lanes (TermTasks)
+  constexpr bool PAIR = PMAX > 4;
+  constexpr int PL = PAIR ? PMAX / 2 : PMAX, TS = PAIR ? 2 : 1; // slots per lane, lanes per task
+  using TT = TermTasks<N1D, BASIS, PL, PAIR>;
   const TT tt{P, rec, Xa, Da, Ca, lo0, lo1, lo2, ih0, ih1, ih2, nsfb, fn, tn, gr, T.maxsf, T.maxcell};
   auto desc = [&](int sf, int &info) { info = (int)__double_as_longlong(gr_info[sf < T.maxsf ? sf : 0]); };
   // ================= A ===============================================================================================
-  // lane tasks, one kind per wave where they fit: waves [0, W/2): (sub-face, tangential direction) tasks; waves [W/2, W):
-  // normal-direction tasks, then cell tasks - each wave a
-  // contiguous share.  The descriptors and point data of a wave's first round are requested before the run entries are needed.
+  // lane tasks, one kind per wave where they fit: waves [0, W/2): (sub-face, tangential direction[, half]) tasks; waves [W/2, W): the
+  // normal-direction tasks, then - from an even lane on - the (cell, direction[, half]) tasks; each wave a contiguous, even share.
+  // The point data of a wave's first round are requested before the run entries are needed.
   {
     constexpr int H = W / 2;
     const bool first_kind = wave < H;
     const int hw = first_kind ? wave : wave - H;
-    const int ntask = first_kind ? 2 * nsf : nsf + 3 * ncell;
-    const int share = (ntask + H - 1) / H;
+    const int ncs = PAIR ? (nsf + 1) & ~1 : nsf;
+    const int ntask = first_kind ? 2 * nsf * TS : ncs + 3 * ncell * TS;
+    const int share = ((ntask + H - 1) / H + 1) & ~1;
     const int t_begin = hw * share, t_end = t_begin + share < ntask ? t_begin + share : ntask;
+    auto dec1 = [&](int tid, int &sf, int &dir, int &half) {
+      const int task = tid / TS;
+      half = tid - task * TS, sf = task >> 1, dir = task & 1;
+    };
+    auto dec2 = [&](int tid, int &ct, int &half) {
+      const int u = tid - ncs;
+      ct = u / TS, half = u - ct * TS;
+    };
     // first round of this wave: loads now, arithmetic behind the barrier-free part (the run entries must be in LDS first)
     const int tid0 = t_begin + lane;
     const bool on0 = tid0 < t_end;
-    int info0 = 0;
+    int info0 = 0, a0 = 0, b0 = 0, h0_ = 0; // (sf, dir, half) or (cell task, -, half)
     typename TT::TPts tp0;
     typename TT::CPts cp0;
     double zeta0 = 0.0;
-    for (int i = 0; i < PMAX; ++i)
+    for (int i = 0; i < PL; ++i)
       tp0.x[i] = tp0.ws[i] = tp0.wc[i] = cp0.x[i] = cp0.ws[i] = cp0.wc[i] = 0.0;
     tp0.npts = cp0.npts = 0;
+    tp0.ws0 = tp0.wc0 = cp0.ws0 = 1.0, cp0.wc0 = 0.0;
     if (first_kind)
       {
-        desc(on0 ? tid0 >> 1 : 0, info0);
-        tp0 = tt.tang_load(info0, on0 ? tid0 >> 1 : 0, tid0 & 1);
+        dec1(on0 ? tid0 : 0, a0, b0, h0_);
+        desc(a0, info0);
+        tp0 = tt.tang_load(info0, a0 < T.maxsf ? a0 : 0, b0, h0_);
       }
     else if (on0 && tid0 < nsf)
       {
         desc(tid0, info0);
         zeta0 = tt.zeta_load(tid0);
       }
-    else if (on0)
-      cp0 = tt.cell_load(tid0 - nsf);
+    else if (on0 && tid0 >= ncs)
+      {
+        dec2(tid0, a0, h0_);
+        cp0 = tt.cell_load(a0, h0_);
+      }
     __syncthreads(); // run entries in LDS (nothing of this workgroup is in flight towards HBM yet: the wait costs nothing)
     if (first_kind)
       {
         if (on0)
-          tt.tang_compute(tp0, tid0 >> 1, tid0 & 1, info0);
+          tt.tang_compute(tp0, a0, b0, info0, h0_);
         for (int tid = tid0 + PDH_WAVE; tid < t_end; tid += PDH_WAVE)
           {
-            int info;
-            desc(tid >> 1, info);
-            const typename TT::TPts tp = tt.tang_load(info, tid >> 1, tid & 1);
-            tt.tang_compute(tp, tid >> 1, tid & 1, info);
+            int info, sf, dir, half;
+            dec1(tid, sf, dir, half);
+            desc(sf, info);
+            const typename TT::TPts tp = tt.tang_load(info, sf, dir, half);
+            tt.tang_compute(tp, sf, dir, info, half);
           }
       }
     else
       {
         if (on0 && tid0 < nsf)
           tt.norm_compute(zeta0, tid0, info0);
-        else if (on0)
-          tt.cell_compute(cp0, tid0 - nsf);
+        else if (on0 && tid0 >= ncs)
+          tt.cell_compute(cp0, a0, h0_);
         for (int tid = tid0 + PDH_WAVE; tid < t_end; tid += PDH_WAVE)
           {
             if (tid < nsf)
@@ -144,10 +162,12 @@ __global__ void __launch_bounds__(PDH_WAVE *W, 3) k_terms_wg(const PdhDev P, con
                 desc(tid, info);
                 tt.norm_compute(tt.zeta_load(tid), tid, info);
               }
-            else
+            else if (tid >= ncs)
               {
-                const typename TT::CPts cp = tt.cell_load(tid - nsf);
-                tt.cell_compute(cp, tid - nsf);
+                int ct, half;
+                dec2(tid, ct, half);
+                const typename TT::CPts cp = tt.cell_load(ct, half);
+                tt.cell_compute(cp, ct, half);
               }
           }
       }
