@@ -2497,9 +2497,10 @@ static int set_problem_impl(pdh_ctx *ctx, const pdh_problem *p, int32_t row_begi
     ctx->mfma_diag = kv * (p->dim + (p->reaction_c != 0.0 ? 1 : 0)) * i_sym + kf * 2 * i_sym;
     ctx->mfma_offdiag = ko * 2 * i_full;
     if (K.tiled)
-      { // every tile (ti <= tj of the own block, all of a coupling block) is one full 64 x 64 product: 64 instructions per k-step
-        const int64_t nt = (K.n + 63) / 64;
-        ctx->mfma_diag = (kv * (p->dim + (p->reaction_c != 0.0 ? 1 : 0)) + kf * 2) * 64 * (nt * (nt + 1) / 2);
+      { // tiles ti < tj of the own block and all tiles of a coupling block are full 64 x 64 products (64 instructions per k-step), the
+        // tiles ti == tj symmetric ones (the schedule of a full n = 64 block)
+        const int64_t nt = (K.n + 63) / 64, i64 = sched_instr_rt(4, 4, true);
+        ctx->mfma_diag = (kv * (p->dim + (p->reaction_c != 0.0 ? 1 : 0)) + kf * 2) * (64 * (nt * (nt - 1) / 2) + i64 * nt);
         ctx->mfma_offdiag = ko * 2 * 64 * nt * nt;
       }
   }

@@ -4,7 +4,7 @@
 // Same sums as pdh_kernels.h (reference include/poly_utils.h:2034-2193, 1870-1926), same point records, same f64-MFMA contraction over
 // the quadrature points - but an n x n block no longer fits the registers of one wave (n^2 / 64 accumulators per lane), so a block is
 // cut into (i, j) TILES of 64 x 64 basis functions and one wave computes one tile:
-//   k_tdiag    : tile (ti <= tj) of the own block A[P,P]: sum_q grad phi_i . grad phi_j JxW (+ c phi_i phi_j JxW) over the volume points
+//   k_tdiag    : tile (ti <= tj) of the own block A[P,P] (two launches: the symmetric tiles ti == tj, then the pairs ti < tj): sum_q grad phi_i . grad phi_j JxW (+ c phi_i phi_j JxW) over the volume points
 //                plus the own-side SIP terms over all face points of P, rows i in tile ti against columns j in tile tj; written into the
 //                rows of tile ti and, for ti < tj, transposed into the rows of tile tj (the block is symmetric).
 //   k_toffdiag : tile (ti, tj) of the coupling block A[P,Q] of one interior face, P's functions of tile ti against Q's of tile tj;
@@ -67,7 +67,8 @@ __device__ __forceinline__ void store_tile_strip(double *values, int64_t base, i
     }
 }
 
-template <bool DIAG, bool TRANSPOSE>
+// SYM: the accumulators hold the upper tile pairs of a symmetric tile (ti == tj of the own block): mirrored while the strip is filled
+template <bool DIAG, bool TRANSPOSE, bool SYM = false>
 __device__ __forceinline__ void write_tile(const double *acc, double *strip, double *values, int64_t base, int row_len, int pos0,
                                            int diag_first, int i0, int j0, int n, int lane)
 {
@@ -77,7 +78,7 @@ __device__ __forceinline__ void write_tile(const double *acc, double *strip, dou
   static_for<0, 4>([&](auto s_) {
     constexpr int s = s_;
     __syncthreads();
-    fill_strip<4, 4, false, TRANSPOSE, s, true>(acc, strip, ncol_pad, sm, 64);
+    fill_strip<4, 4, SYM, TRANSPOSE, s, true>(acc, strip, ncol_pad, sm, 64);
     __syncthreads();
     store_tile_strip<DIAG>(values, base, row_len, pos0, diag_first, strip, ncol_pad, s, i0, j0, n, lane);
   });
@@ -86,13 +87,15 @@ __device__ __forceinline__ void write_tile(const double *acc, double *strip, dou
 // ------------------------------------------------------------------------------------------------
 // Own block: one wave per (owned polytope, tile pair ti <= tj).
 // ------------------------------------------------------------------------------------------------
-template <int DIM, int N1D, bool REACT>
+// DIAGT: the ntile tiles ti == tj of a polytope - symmetric, so only the upper 4 x 4-tile pairs are multiplied (the schedule of k_diag:
+// 40 instead of 64 MFMA per product) and mirrored in the epilogue; else the ntile (ntile - 1) / 2 pairs ti < tj with the full schedule.
+template <int DIM, int N1D, bool REACT, bool DIAGT>
 __global__ void __launch_bounds__(PDH_WAVE, 2) k_tdiag(const PdhDev P, const int n_owned, const int ntile)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   using RC = Rec<DIM, N1D>;
   const int lane = threadIdx.x;
-  const int npairs = ntile * (ntile + 1) / 2;
+  const int npairs = DIAGT ? ntile : ntile * (ntile - 1) / 2;
   if ((int)blockIdx.x >= n_owned * npairs)
     return;
   // (an XCD per contiguous eighth of the work items: the tiles of a block and the blocks of a row - n is no multiple of 16, so all of
@@ -100,12 +103,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_tdiag(const PdhDev P, const int
   const int bid = xcd_chunked((int)blockIdx.x, n_owned * npairs);
   const int slot = bid / npairs;
   int pr = bid - slot * npairs, ti = 0;
-  while (pr >= ntile - ti) // pairs (ti, ti), (ti, ti + 1), ...
-    {
-      pr -= ntile - ti;
-      ++ti;
-    }
-  const int tj = ti + pr;
+  if constexpr (!DIAGT)
+    while (pr >= ntile - 1 - ti) // pairs (ti, ti + 1), (ti, ti + 2), ...
+      {
+        pr -= ntile - 1 - ti;
+        ++ti;
+      }
+  else
+    ti = pr;
+  const int tj = DIAGT ? ti : ti + 1 + pr;
   const int i0 = 64 * ti, j0 = 64 * tj;
   const int agg = P.own_agg[slot];
   constexpr int CH = PDH_WAVE;
@@ -168,7 +174,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_tdiag(const PdhDev P, const int
                 GI[a] = dI[a][c];
                 GJ[a] = dJ[a][c];
               });
-              product_full<4, 4>(acc, GI, GJ, rt); // sum_q (sqrt(w) d_c phi_i)(sqrt(w) d_c phi_j)
+              // sum_q (sqrt(w) d_c phi_i)(sqrt(w) d_c phi_j)
+              if constexpr (DIAGT)
+                {
+                  RotSet<4> RG;
+                  make_rot<4, ROT_SYM>(GI, rt, RG);
+                  product<4, 4, true>(acc, RG, RG);
+                }
+              else
+                product_full<4, 4>(acc, GI, GJ, rt);
             });
             if constexpr (REACT)
               {
@@ -177,7 +191,15 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_tdiag(const PdhDev P, const int
                   constexpr int a = a_;
                   RI[a] = P.reaction_c * phiI[a];
                 });
-                product_full<4, 4>(acc, RI, phiJ, rt);
+                if constexpr (DIAGT)
+                  {
+                    RotSet<4> RP, RA;
+                    make_rot<4, ROT_SYM>(phiI, rt, RP);
+                    make_rot<4, ROT_SYM>(RI, rt, RA);
+                    product<4, 4, true>(acc, RA, RP);
+                  }
+                else
+                  product_full<4, 4>(acc, RI, phiJ, rt);
               }
           }
       }
@@ -231,8 +253,19 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_tdiag(const PdhDev P, const int
               r.load(rb, lbJ.off[a]);
               r.eval_u(hs, PhiJ[a], UJ[a]);
             });
-            product_full<4, 4>(acc, UI, PhiJ, rt);
-            product_full<4, 4>(acc, PhiI, UJ, rt);
+            if constexpr (DIAGT)
+              {
+                RotSet<4> RU, RPhi;
+                make_rot<4, ROT_SYM>(UI, rt, RU);
+                make_rot<4, ROT_SYM>(PhiI, rt, RPhi);
+                product<4, 4, true>(acc, RU, RPhi);
+                product<4, 4, true>(acc, RPhi, RU);
+              }
+            else
+              {
+                product_full<4, 4>(acc, UI, PhiJ, rt);
+                product_full<4, 4>(acc, PhiI, UJ, rt);
+              }
           }
       }
   }
@@ -242,9 +275,13 @@ __global__ void __launch_bounds__(PDH_WAVE, 2) k_tdiag(const PdhDev P, const int
   const int64_t rbase = P.row_base[slot];
   const int rlen = P.row_len[slot];
   const int L = P.diag_L[slot];
-  write_tile<true, false>(acc, strip, P.values, rbase, rlen, L, P.diag_first, i0, j0, P.n, lane);
-  if (ti != tj)
-    write_tile<true, true>(acc, strip, P.values, rbase, rlen, L, P.diag_first, j0, i0, P.n, lane);
+  if constexpr (DIAGT)
+    write_tile<true, false, true>(acc, strip, P.values, rbase, rlen, L, P.diag_first, i0, j0, P.n, lane);
+  else
+    {
+      write_tile<true, false>(acc, strip, P.values, rbase, rlen, L, P.diag_first, i0, j0, P.n, lane);
+      write_tile<true, true>(acc, strip, P.values, rbase, rlen, L, P.diag_first, j0, i0, P.n, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

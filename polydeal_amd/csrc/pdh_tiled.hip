@@ -5,19 +5,33 @@ template <int N1D>
 static hipError_t launch_n1d(int which, const PdhDev *P, int count, int ntile, hipStream_t stream)
 {
   const size_t lds = which == 1 ? pdht2::lds_bytes_toffdiag(3, N1D) : pdht2::lds_bytes_tdiag(3, N1D);
-  const long long per = which == 1 ? (long long)ntile * ntile : (long long)ntile * (ntile + 1) / 2;
-  const long long blocks = per * count;
-  if (blocks <= 0)
+  const dim3 block(PDH_WAVE);
+  if (count <= 0)
     return hipSuccess;
-  if (blocks > 0x7fffffffLL)
+  if (which == 1)
+    {
+      const long long blocks = (long long)ntile * ntile * count;
+      if (blocks > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+      hipLaunchKernelGGL((pdht2::k_toffdiag<3, N1D>), dim3((unsigned)blocks), block, lds, stream, *P, count, ntile);
+      return hipGetLastError();
+    }
+  // own blocks: the symmetric tiles ti == tj, then the pairs ti < tj
+  const long long bd = (long long)ntile * count, bo = (long long)ntile * (ntile - 1) / 2 * count;
+  if (bd > 0x7fffffffLL || bo > 0x7fffffffLL)
     return hipErrorInvalidValue;
-  const dim3 grid((unsigned)blocks), block(PDH_WAVE);
   if (which == 0)
-    hipLaunchKernelGGL((pdht2::k_tdiag<3, N1D, false>), grid, block, lds, stream, *P, count, ntile);
-  else if (which == 2)
-    hipLaunchKernelGGL((pdht2::k_tdiag<3, N1D, true>), grid, block, lds, stream, *P, count, ntile);
+    {
+      hipLaunchKernelGGL((pdht2::k_tdiag<3, N1D, false, true>), dim3((unsigned)bd), block, lds, stream, *P, count, ntile);
+      if (bo > 0)
+        hipLaunchKernelGGL((pdht2::k_tdiag<3, N1D, false, false>), dim3((unsigned)bo), block, lds, stream, *P, count, ntile);
+    }
   else
-    hipLaunchKernelGGL((pdht2::k_toffdiag<3, N1D>), grid, block, lds, stream, *P, count, ntile);
+    {
+      hipLaunchKernelGGL((pdht2::k_tdiag<3, N1D, true, true>), dim3((unsigned)bd), block, lds, stream, *P, count, ntile);
+      if (bo > 0)
+        hipLaunchKernelGGL((pdht2::k_tdiag<3, N1D, true, false>), dim3((unsigned)bo), block, lds, stream, *P, count, ntile);
+    }
   return hipGetLastError();
 }
 
