@@ -1410,13 +1410,16 @@ def _merge_stats_and_values(kw, mode):
 
 @pytest.mark.parametrize("basis,p", [("dgq", 3), ("dgp", 3), ("dgq", 2), ("dgp", 1)])
 @pytest.mark.parametrize("shape,diag_first,vname", [("blocks3", True, "poisson"), ("blocks3", False, "dr"), ("slabs", True, "adm"),
-                                                   ("grown", True, "poisson"), ("grown", False, "test")])
+                                                   ("grown", True, "poisson"), ("grown", False, "test"), ("graded", True, "poisson"),
+                                                   ("graded", False, "dr")])
 def test_term_kernels_merge_cells_and_sub_faces_that_form_tensor_grids(basis, p, shape, diag_first, vname):
     """The term kernels sum over cells and sub-faces; those that form tensor grids are merged into ONE with composite 1-D rules
     (csrc/pdh_capi.cpp: merge_terms_of_slot).  Shapes that exercise the analysis: blocks of 3^3 cells (three intervals per axis: sub-grids of
     2 + 1), slabs of 4 x 2 x 1 cells (different counts per axis, composite rules of 8 and 4 and 2 points... per the element's rule), and
     METIS-like grown agglomerates with PDH_TERMS_MERGE=2 (every polytope a mix of merged sub-grids, merged planes and single cells /
-    sub-faces - the rule of build_terms_tables would leave them as given).  Merged, as given and the oracle must agree."""
+    sub-faces - the rule of build_terms_tables would leave them as given), and 2^3-cell blocks of a GRADED Cartesian grid (vertices
+    x -> x^1.6 per axis: the intervals of a composite rule differ in length, the weights of a polytope's cells still factorise).
+    Merged, as given and the oracle must agree."""
     fe = po.FE_DGQ(3, p) if basis == "dgq" else po.FE_AggloDGP(3, p)
     nq = p + 1
     if shape == "blocks3":
@@ -1428,6 +1431,10 @@ def test_term_kernels_merge_cells_and_sub_faces_that_form_tensor_grids(basis, p,
         for i, j, k in np.ndindex(*grid.ijk_to_cell.shape):
             groups.setdefault((i // 4, j // 2, k), []).append(int(grid.ijk_to_cell[i, j, k]))
         groups = [sorted(g) for _, g in sorted(groups.items())]
+    elif shape == "graded":
+        grid = po.subdivided_hyper_cube(3, 4, 0.0, 1.0)
+        grid.vertices[...] = grid.vertices ** 1.6  # (a tensor-product grading: cells stay axis-aligned boxes)
+        groups = po.block_agglomerates(grid, 2)
     else:
         grid = po.subdivided_hyper_cube(3, 6, 0.0, 1.0)
         groups = _grown_agglomerates(grid, 6, 5)
@@ -1450,6 +1457,8 @@ def test_term_kernels_merge_cells_and_sub_faces_that_form_tensor_grids(basis, p,
         assert st_m["cells_merged"] * 27 == st_m["cells"] * up(3) ** 3 and st_m["sub_faces_merged"] * 9 == st_m["sub_faces"] * up(3) ** 2
     elif shape == "slabs":    # 4 x 2 x 1 cells
         assert st_m["cells_merged"] * 8 == st_m["cells"] * up(4) * up(2)
+    elif shape == "graded":   # 2^3 cells of unequal size -> one
+        assert st_m["cells_merged"] * 8 == st_m["cells"] and st_m["sub_faces_merged"] * 4 == st_m["sub_faces"]
     else:
         assert st_m["sub_faces_merged"] < st_m["sub_faces"]
     assert_parity_ah(vm, ref, ah, diag_first, what="term kernel, merged")
