@@ -601,6 +601,9 @@ def main():
             by2 = r2["work"]["bytes_total"] if r2["alg"] == "rows" else sum(r2["work"]["bytes"])
             extra.update(algorithmic_bytes_per_step=by2, hbm_GBs=by2 / (r2["dt"] / args.steps) * 1e-9,
                          frac_of_hbm_peak=by2 / (r2["dt"] / args.steps) * 1e-9 / HBM_PEAK_GBS,
+                         frac_note=("SURVEY 8(d) bytes / time; the term kernels read 1-D rules instead of the point arrays that count "
+                                    "charges (more than half of it for FE_AggloDGP(3)): measured traffic in "
+                                    "profiles/r04b_hbm_small_elements.txt") if r2["rows_kernel"] == "terms" else None,
                          fp64_bound_ms=1e3 * sum(r2["work"]["flops"]) / (FP64_PEAK_TFLOPS * 1e12))
     if not args.no_extra and world == 1 and main_res.get("rows_kernel") == "terms" and main_res["n"] == 64:
         # the same workload through the kernel that was AUTO's choice for FE_DGQ(3) until round 4 (pdh_rows.h: moment form + MFMA
