@@ -108,7 +108,7 @@ def build_handler(pa, dim, cells, block, basis, degree, nq, stack=1, grown=False
 
 
 def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup, alg="auto", look_for_tensor_rules=True, grown=False,
-            distort=0.0):
+            distort=0.0, diag_first=True):
     t0 = time.time()
     stack = world if args.scaling == "weak" else 1
     grid, ah, fe = build_handler(pa, args.dim, args.cells, args.block, basis, args.degree, args.degree + 1, stack, grown, distort)
@@ -127,9 +127,9 @@ def run_gpu(pa, torch, dist, args, basis, rank, world, local_rank, steps, warmup
     if world > 1:
         # every rank describes ONLY its own polytopes + their ghost neighbours (pdh_problem.local = 1), like an MPI rank of
         # the reference (source/agglomeration_handler.cc:1026-1091)
-        flat = ah.flatten_local(var, r0, r1, diag_first=True, with_colind=False, row_splits=splits)
+        flat = ah.flatten_local(var, r0, r1, diag_first=diag_first, with_colind=False, row_splits=splits)
     else:
-        flat = ah.flatten(var, diag_first=True, with_colind=False)
+        flat = ah.flatten(var, diag_first=diag_first, with_colind=False)
     if not look_for_tensor_rules:  # general-point paths only (pdh_problem::vq_tensor_n / fq_tensor_n < 0)
         flat.c.vq_tensor_n = flat.c.fq_tensor_n = -1
     t_flatten = time.time() - t0 - t_handler
@@ -681,6 +681,11 @@ def main():
                 "n_dofs": r8["n_dofs"], "nnz": r8["nnz"], "algorithm": r8["alg"], "rows_kernel": r8["rows_kernel"],
                 "ms_per_step": 1e3 * t8, "value": r8["n_dofs"] / t8, "kernel_ms": r8["kms"],
                 "algorithmic_bytes_per_step": by8, "frac_of_hbm_peak": by8 / t8 * 1e-9 / HBM_PEAK_GBS, "checksum": r8["checksum"]}
+            # the same mesh with plain ascending columns (Epetra / Trilinos rows: no shifted blocks, the coupling kernel writes whole lines)
+            r8a = run_gpu(pa, torch, dist, args, args.fe, rank, world, local_rank, max(3, args.steps // 2), 1, distort=0.1, diag_first=False)
+            t8a = r8a["dt"] / max(3, args.steps // 2)
+            extra["distorted"]["ascending_layout"] = {"ms_per_step": 1e3 * t8a, "kernel_ms": r8a["kms"], "algorithm": r8a["alg"],
+                                                      "frac_of_hbm_peak": by8 / t8a * 1e-9 / HBM_PEAK_GBS}
         except Exception as exc:
             extra["distorted"] = {"error": repr(exc)}
     if world == 1 and not args.no_extra and args.dim == 3:
