@@ -1,6 +1,6 @@
 // diffusion_reaction.cpp — the flow of the reference's examples/diffusion_reaction.cc (BASELINE.json configs[3]) through the C ABI,
 // with the MPI ranks of the reference played one after the other on one GPU:
-//   main :840-868            degree 1 .. 3 of FE_DGQ (degree 4 has 125 dofs per polytope: beyond the 64 the kernels take), c = 0.5
+//   main :840-868            degree 1 .. 4 of FE_DGQ (the HEX branch of the reference; degree 4 = 125 dofs per polytope: 64 x 64 tiles), c = 0.5
 //   make_grid :372-396       unit cube, refined globally, cells partitioned over the ranks
 //   setup_agglomerated_problem :402-417   METIS inside every rank, n_local_agglomerates each (-> regions grown over the cell graph:
 //                            METIS is not available offline); whole agglomerates per rank (source/agglomeration_handler.cc:83-87)
@@ -41,7 +41,7 @@ int main(int argc, char **argv)
     double l2, h1, assemble_s;
   };
   std::vector<Row> table;
-  for (const unsigned degree : {1u, 2u, 3u})
+  for (const unsigned degree : {1u, 2u, 3u, 4u})
     {
       const BackgroundGrid tria = BackgroundGrid::hyper_cube_refined(dim, 0., 1., n_refinements);
       AgglomerationHandler ah(tria);
